@@ -1,0 +1,176 @@
+/*
+ * zkp_hip.h — C ABI of libzkp_hip.so: MI355X (gfx950) batched Paillier ZK-proof engine.
+ *
+ * This is the drop-in boundary for the hot path of ZenGo-X/zk-paillier.  The reference has
+ * no FFI of its own: its proof modules (L3) call the big-integer layer (L1: curv::BigInt
+ * over GMP, kzen-paillier) through ordinary Rust calls.  Every entry point below replaces
+ * one of those L3->L1 call shapes, batched; the reference call site each one replaces is
+ * cited as file:line relative to the reference tree.  The Rust-side binding a maintainer
+ * would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Big integers are fixed-width little-endian arrays of 32-bit limbs (limb 0 = least
+ *    significant), zero padded.  kw = n_bits/32 limbs for values of the size of n
+ *    (n, r, m, w, x, sigma, masked_r ...); 2*kw limbs for values mod n^2 (ciphertexts).
+ *    n_bits / mod_bits is the kernel width: 2048, 4096 or 8192 bits for moduli
+ *    (n^2 of a 2048-bit n is a 4096-bit modulus).  Moduli must be odd.
+ *  - Batches are structure-of-arrays, element i at ptr + i*stride (stride in limbs).  A
+ *    modulus/key stride of 0 means one shared modulus/key for the whole batch.
+ *  - All pointers of one call live in the same memory space: host memory by default,
+ *    device (HBM) memory of the context's GPU when ZKP_F_DEVICE_PTRS is set.  The caller
+ *    owns every buffer; the library keeps no pointer after a call returns.
+ *  - Every function returns a zkp_status.  Proof rejection is DATA (verdict byte 0), never
+ *    an error code (mirrors Result<(), IncorrectProof>, src/zkproofs/errors.rs:5-13).
+ *    Nothing aborts or throws across this boundary.
+ *  - One ctx = one GPU + one HIP stream.  Calls on one ctx are serialised by the caller;
+ *    different ctxs are independent (one per GPU / per rank).
+ *  - There is NO CPU fallback: if no gfx950 device is present zkp_ctx_create fails with
+ *    ZKP_EDEVICE.
+ */
+#ifndef ZKP_HIP_H
+#define ZKP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  ZKP_OK = 0,
+  ZKP_EINVAL = 1,        /* bad width / null pointer / count overflow */
+  ZKP_ENONCANONICAL = 2, /* even modulus (Montgomery needs odd) */
+  ZKP_EDEVICE = 3,       /* HIP error; text via zkp_last_error_string */
+  ZKP_ENOMEM = 4
+} zkp_status;
+
+enum { ZKP_F_DEVICE_PTRS = 1u };
+
+/* verdict bytes written by the *_verify_batch entry points */
+enum {
+  ZKP_VERDICT_REJECT = 0,    /* Err(IncorrectProof) */
+  ZKP_VERDICT_ACCEPT = 1,    /* Ok(()) */
+  ZKP_VERDICT_MALFORMED = 2  /* the reference would panic (index out of bounds / assert) */
+};
+
+/* response kinds (src/zkproofs/range_proof.rs:53-78, enum Response) */
+enum { ZKP_RESP_OPEN = 0, ZKP_RESP_MASK = 1 };
+
+#define ZKP_SECURITY_PARAMETER 128 /* src/zkproofs/range_proof_ni.rs:23 */
+#define ZKP_CORRECT_KEY_M2 11      /* src/zkproofs/correct_key_ni.rs:29 */
+
+typedef struct zkp_ctx zkp_ctx;
+
+int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out_ctx);
+int32_t zkp_ctx_destroy(zkp_ctx* ctx);
+const char* zkp_backend_name(void);               /* "hip-gfx950" */
+const char* zkp_last_error_string(zkp_ctx* ctx);  /* valid until the next call on ctx */
+void* zkp_ctx_stream(zkp_ctx* ctx);               /* the hipStream_t every launch uses */
+int32_t zkp_ctx_synchronize(zkp_ctx* ctx);
+
+/* Kernel timing of the dominant (modexp) kernels, measured with HIP events on the ctx
+ * stream.  zkp_timing_reset clears the accumulators and arms event recording;
+ * zkp_timing_get synchronises and returns total milliseconds, launch count and the
+ * number of modular exponentiations those launches performed. */
+int32_t zkp_timing_reset(zkp_ctx* ctx, int32_t enable);
+int32_t zkp_timing_get(zkp_ctx* ctx, double* out_ms, uint64_t* out_launches, uint64_t* out_modexps);
+
+/* ------------------------------------------------------------------ L1 primitives
+ * out[i] = base[i]^exp[i] mod mod[i].
+ * Replaces BigInt::mod_pow (src/zkproofs/correct_key_ni.rs:92; wi_dlog_proof.rs:55,81,82).
+ * mod_bits in {2048,4096,8192}; exp_bits a multiple of 32, 32..mod_bits.
+ * base/out: mod_bits/32 limbs each; exp: exp_bits/32 limbs; *_stride in limbs, 0 = shared. */
+int32_t zkp_modexp_batch(zkp_ctx* ctx, uint32_t mod_bits, uint32_t exp_bits, uint64_t count,
+                         const uint32_t* base, const uint32_t* exp, uint64_t exp_stride,
+                         const uint32_t* mod, uint64_t mod_stride, uint32_t* out, uint32_t flags);
+
+/* out[i] = a[i]*b[i] mod mod[i].  Replaces BigInt::mod_mul (wi_dlog_proof.rs:83) and the
+ * `x * y % m` forms at range_proof.rs:239,245,325,327. */
+int32_t zkp_modmul_batch(zkp_ctx* ctx, uint32_t mod_bits, uint64_t count, const uint32_t* a,
+                         const uint32_t* b, const uint32_t* mod, uint64_t mod_stride,
+                         uint32_t* out, uint32_t flags);
+
+/* c[i] = (1 + m[i]*n[i]) * r[i]^n[i] mod n[i]^2.
+ * Replaces Paillier::encrypt_with_chosen_randomness (kzen-paillier 0.4.3; call sites
+ * src/zkproofs/range_proof.rs:165-169,179-183,280-291,330-334,361).
+ * n, m, r: n_bits/32 limbs; out_c: 2*n_bits/32 limbs.  n_bits in {1024,2048,4096}. */
+int32_t zkp_paillier_enc_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t count, const uint32_t* n,
+                               uint64_t n_stride, const uint32_t* m, const uint32_t* r,
+                               uint32_t* out_c, uint32_t flags);
+
+/* ------------------------------------------------------------------ RangeProofNi
+ * Batch of B non-interactive range proofs, structure-of-arrays
+ * (src/zkproofs/range_proof_ni.rs:36-44 RangeProofNi; range_proof.rs:32-81 EncryptedPairs,
+ * Response, Proof).  EF = error_factor rows per proof. */
+typedef struct {
+  uint32_t n_bits;        /* width of n: 1024, 2048 or 4096 */
+  uint32_t error_factor;  /* rows per proof; prove always writes ZKP_SECURITY_PARAMETER */
+  uint64_t batch;         /* B */
+  uint64_t n_stride;      /* kw, or 0 = every proof uses n[0] */
+  const uint32_t* n;      /* [B or 1][kw]          ek.n                        */
+  const uint32_t* range;  /* [B][kw]               q                           */
+  const uint32_t* ciphertext; /* [B][2kw]          c = Enc(x, r)               */
+  uint32_t* c1;           /* [B][EF][2kw]          encrypted_pairs.c1          */
+  uint32_t* c2;           /* [B][EF][2kw]          encrypted_pairs.c2          */
+  uint8_t* resp_kind;     /* [B][EF]               ZKP_RESP_OPEN | ZKP_RESP_MASK */
+  uint8_t* resp_j;        /* [B][EF]               Mask.j (0 for Open)         */
+  uint32_t* resp_w1;      /* [B][EF][kw]           Open.w1 | Mask.masked_x     */
+  uint32_t* resp_r1;      /* [B][EF][kw]           Open.r1 | Mask.masked_r     */
+  uint32_t* resp_w2;      /* [B][EF][kw]           Open.w2 | 0                 */
+  uint32_t* resp_r2;      /* [B][EF][kw]           Open.r2 | 0                 */
+} zkp_range_ni_proofs;
+
+/* Secret prover inputs.  The reference draws (w1,w2,r1,r2) from the OS RNG inside
+ * generate_encrypted_pairs (range_proof.rs:136-159); the boundary takes them as inputs
+ * (already coin-flip swapped) so that proving is reproducible. */
+typedef struct {
+  const uint32_t* x;   /* [B][kw]      secret_x */
+  const uint32_t* r;   /* [B][kw]      secret_r */
+  const uint32_t* w1;  /* [B][EF][kw]  */
+  const uint32_t* w2;  /* [B][EF][kw]  */
+  const uint32_t* r1;  /* [B][EF][kw]  */
+  const uint32_t* r2;  /* [B][EF][kw]  */
+} zkp_range_ni_witness;
+
+/* RangeProofNi::prove (src/zkproofs/range_proof_ni.rs:47-82) for B proofs:
+ * generate_encrypted_pairs (range_proof.rs:161-187) -> Fiat-Shamir challenge
+ * (range_proof_ni.rs:58-61, utils.rs:9-22) -> generate_proof (range_proof.rs:210-252).
+ * Writes c1,c2,resp_* of `p`; out_e [B][32] receives the challenge bytes left-aligned,
+ * out_e_len [B] their count (leading zero digest bytes are dropped, N2); either may be null.
+ * out_status [B] (nullable): 0 ok, ZKP_VERDICT_MALFORMED if the reference would panic. */
+int32_t zkp_range_ni_prove_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p,
+                                 const zkp_range_ni_witness* w, uint8_t* out_e,
+                                 uint8_t* out_e_len, uint8_t* out_status, uint32_t flags);
+
+/* RangeProofNi::verify_self / verify (range_proof_ni.rs:84-128 -> range_proof.rs:254-355).
+ * out_verdict [B]: ZKP_VERDICT_*.  (verify()'s two assert_eq! on ek and ciphertext are the
+ * host layer's job: here the statement is whatever `p` holds.) */
+int32_t zkp_range_ni_verify_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p,
+                                  uint8_t* out_verdict, uint32_t flags);
+
+/* ------------------------------------------------------------------ NiCorrectKeyProof
+ * NiCorrectKeyProof::verify (src/zkproofs/correct_key_ni.rs:73-100) for B (key, proof)
+ * pairs: rho_i from the SHA-256 MGF (:77-86,105-117), sigma_i^n mod n (:90-93),
+ * gcd(primorial(6370), n) == 1 (:87-88).  n: [B][kw]; sigma: [B][11][kw]. */
+int32_t zkp_correct_key_ni_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch,
+                                        const uint32_t* n, const uint32_t* sigma,
+                                        const uint8_t* salt, uint32_t salt_len,
+                                        uint8_t* out_verdict, uint32_t flags);
+
+/* ------------------------------------------------------------------ CompositeDLogProof
+ * src/zkproofs/wi_dlog_proof.rs:46-91.  N,g,ni,x: [B][kw]; y/r: [B][y_bits/32] (y_bits a
+ * multiple of 32, >= 544 for honest proofs: y = r + e*s < 2^513); secret s: [B][8].
+ * prove takes the 512-bit nonce r as an input (reference: BigInt::sample_below(2^512)). */
+int32_t zkp_dlog_prove_batch(zkp_ctx* ctx, uint32_t n_bits, uint32_t y_bits, uint64_t batch,
+                             const uint32_t* N, const uint32_t* g, const uint32_t* ni,
+                             const uint32_t* secret, const uint32_t* r, uint32_t* out_x,
+                             uint32_t* out_y, uint32_t flags);
+int32_t zkp_dlog_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint32_t y_bits, uint64_t batch,
+                              const uint32_t* N, const uint32_t* g, const uint32_t* ni,
+                              const uint32_t* x, const uint32_t* y, uint8_t* out_verdict,
+                              uint32_t flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKP_HIP_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of oracle/liboracle.so (the TEST-ONLY C/GMP oracle).  Lives under tests/
+because only tests (and smoke()/bench cpu_baseline) may touch the oracle."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+capi = importlib.import_module("zk-paillier_amd.capi")
+RangeNiProofs, RangeNiWitness = capi.RangeNiProofs, capi.RangeNiWitness
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(ORACLE_DIR, "zkp_oracle.c")):
+            build()
+        self.lib = C.CDLL(LIB)
+        self.lib.oracle_get_max_threads.restype = C.c_int
+
+    def set_threads(self, n):
+        self.lib.oracle_set_threads(C.c_int(n))
+
+    def max_threads(self):
+        return self.lib.oracle_get_max_threads()
+
+    def sha256(self, data: bytes) -> bytes:
+        out = (C.c_uint8 * 32)()
+        self.lib.oracle_sha256(data, C.c_uint64(len(data)), out)
+        return bytes(out)
+
+    def modexp(self, mod_bits, exp_bits, base, exp, exp_stride, mod, mod_stride):
+        count = base.shape[0]
+        out = np.zeros_like(base)
+        self.lib.oracle_modexp_batch(C.c_uint32(mod_bits), C.c_uint32(exp_bits), C.c_uint64(count), p(base), p(exp),
+                                     C.c_uint64(exp_stride), p(mod), C.c_uint64(mod_stride), p(out))
+        return out
+
+    def modmul(self, mod_bits, a, b, mod, mod_stride):
+        out = np.zeros_like(a)
+        self.lib.oracle_modmul_batch(C.c_uint32(mod_bits), C.c_uint64(a.shape[0]), p(a), p(b), p(mod),
+                                     C.c_uint64(mod_stride), p(out))
+        return out
+
+    def paillier_enc(self, n_bits, n, n_stride, m, r):
+        count = m.shape[0]
+        out = np.zeros((count, 2 * n_bits // 32), dtype=np.uint32)
+        self.lib.oracle_paillier_enc_batch(C.c_uint32(n_bits), C.c_uint64(count), p(n), C.c_uint64(n_stride), p(m), p(r), p(out))
+        return out
+
+    def range_ni_prove(self, proofs: RangeNiProofs, wit: RangeNiWitness, out_e, out_e_len, out_status):
+        return self.lib.oracle_range_ni_prove_batch(C.byref(proofs), C.byref(wit), p(out_e), p(out_e_len), p(out_status))
+
+    def range_ni_verify(self, proofs: RangeNiProofs, out_verdict):
+        return self.lib.oracle_range_ni_verify_batch(C.byref(proofs), p(out_verdict))
+
+    def correct_key_ni_verify(self, n_bits, n, sigma, salt: bytes):
+        batch = n.shape[0]
+        out = np.zeros(batch, dtype=np.uint8)
+        self.lib.oracle_correct_key_ni_verify_batch(C.c_uint32(n_bits), C.c_uint64(batch), p(n), p(sigma), salt,
+                                                    C.c_uint32(len(salt)), p(out))
+        return out
+
+    def correct_key_ni_prove(self, n_bits, pp, qq, salt: bytes):
+        kw = n_bits // 32
+        n = np.zeros(kw, dtype=np.uint32)
+        sigma = np.zeros((11, kw), dtype=np.uint32)
+        rc = self.lib.oracle_correct_key_ni_prove(C.c_uint32(n_bits), p(pp), p(qq), salt, C.c_uint32(len(salt)), p(n), p(sigma))
+        assert rc == 0
+        return n, sigma
+
+    def correct_key_rho(self, n_bits, n, salt: bytes):
+        rho = np.zeros((11, n_bits // 32), dtype=np.uint32)
+        self.lib.oracle_correct_key_rho(C.c_uint32(n_bits), p(n), salt, C.c_uint32(len(salt)), p(rho))
+        return rho
+
+    def dlog_prove(self, n_bits, y_bits, N, g, ni, secret, r):
+        batch = N.shape[0]
+        x = np.zeros_like(N)
+        y = np.zeros((batch, y_bits // 32), dtype=np.uint32)
+        self.lib.oracle_dlog_prove_batch(C.c_uint32(n_bits), C.c_uint32(y_bits), C.c_uint64(batch), p(N), p(g), p(ni),
+                                         p(secret), p(r), p(x), p(y))
+        return x, y
+
+    def dlog_verify(self, n_bits, y_bits, N, g, ni, x, y):
+        batch = N.shape[0]
+        out = np.zeros(batch, dtype=np.uint8)
+        self.lib.oracle_dlog_verify_batch(C.c_uint32(n_bits), C.c_uint32(y_bits), C.c_uint64(batch), p(N), p(g), p(ni),
+                                          p(x), p(y), p(out))
+        return out
+
+    def fs_challenge(self, n_bits, ef, n, c1, c2):
+        e = np.zeros(32, dtype=np.uint8)
+        elen = C.c_uint8()
+        self.lib.oracle_fs_challenge(C.c_uint32(n_bits), C.c_uint32(ef), p(n), p(c1), p(c2), p(e), C.byref(elen))
+        return bytes(e[:elen.value])

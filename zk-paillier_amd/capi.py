@@ -1,0 +1,182 @@
+"""ctypes binding of libzkp_hip.so (include/zkp_hip.h).
+
+There is no CPU fallback: importing this module without the built library, or creating a
+context without a gfx950 GPU, raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkp_hip.so")
+
+ZKP_OK, ZKP_EINVAL, ZKP_ENONCANONICAL, ZKP_EDEVICE, ZKP_ENOMEM = range(5)
+ZKP_F_DEVICE_PTRS = 1
+VERDICT_REJECT, VERDICT_ACCEPT, VERDICT_MALFORMED = 0, 1, 2
+RESP_OPEN, RESP_MASK = 0, 1
+SECURITY_PARAMETER = 128
+CORRECT_KEY_M2 = 11
+
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+class RangeNiProofs(C.Structure):
+    """zkp_range_ni_proofs"""
+    _fields_ = [
+        ("n_bits", C.c_uint32), ("error_factor", C.c_uint32), ("batch", C.c_uint64),
+        ("n_stride", C.c_uint64), ("n", C.c_void_p), ("range", C.c_void_p),
+        ("ciphertext", C.c_void_p), ("c1", C.c_void_p), ("c2", C.c_void_p),
+        ("resp_kind", C.c_void_p), ("resp_j", C.c_void_p), ("resp_w1", C.c_void_p),
+        ("resp_r1", C.c_void_p), ("resp_w2", C.c_void_p), ("resp_r2", C.c_void_p),
+    ]
+
+
+class RangeNiWitness(C.Structure):
+    """zkp_range_ni_witness"""
+    _fields_ = [("x", C.c_void_p), ("r", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p),
+                ("r1", C.c_void_p), ("r2", C.c_void_p)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "zkp_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "zkp_ctx_destroy": (C.c_int32, [C.c_void_p]),
+    "zkp_backend_name": (C.c_char_p, []),
+    "zkp_last_error_string": (C.c_char_p, [C.c_void_p]),
+    "zkp_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "zkp_ctx_synchronize": (C.c_int32, [C.c_void_p]),
+    "zkp_timing_reset": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "zkp_timing_get": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "zkp_modexp_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
+    "zkp_modmul_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_uint64, C.c_void_p, C.c_uint32]),
+    "zkp_paillier_enc_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_range_ni_prove_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_range_ni_verify_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_uint32]),
+    "zkp_correct_key_ni_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "zkp_dlog_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_dlog_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libzkp_hip.so and attach signatures.  Raises if the library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class ZkpError(RuntimeError):
+    pass
+
+
+def ptr(a):
+    """numpy array / torch tensor / None -> void* address."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):   # torch tensor (host or device)
+        assert a.is_contiguous()
+        return a.data_ptr()
+    raise TypeError(type(a))
+
+
+class Context:
+    """One GPU + one stream (zkp_ctx)."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        st = self.lib.zkp_ctx_create(device_id, C.byref(h))
+        if st != ZKP_OK:
+            raise ZkpError(f"zkp_ctx_create(device {device_id}) failed with status {st} "
+                           "(no gfx950 GPU / HIP runtime error; there is no CPU fallback)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zkp_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def check(self, st):
+        if st != ZKP_OK:
+            msg = self.lib.zkp_last_error_string(self.h)
+            raise ZkpError(f"status {st}: {msg.decode() if msg else ''}")
+
+    def synchronize(self):
+        self.check(self.lib.zkp_ctx_synchronize(self.h))
+
+    def stream(self):
+        return self.lib.zkp_ctx_stream(self.h)
+
+    def timing_reset(self, enable=True):
+        self.check(self.lib.zkp_timing_reset(self.h, 1 if enable else 0))
+
+    def timing_get(self):
+        ms, launches, modexps = C.c_double(), C.c_uint64(), C.c_uint64()
+        self.check(self.lib.zkp_timing_get(self.h, C.byref(ms), C.byref(launches), C.byref(modexps)))
+        return ms.value, launches.value, modexps.value
+
+    # ---- L1 primitives (buffers: numpy arrays = host pointers, torch cuda tensors = device pointers)
+    @staticmethod
+    def _flags(*arrs):
+        dev = [hasattr(a, "is_cuda") and a.is_cuda for a in arrs if a is not None]
+        if any(dev) and not all(dev):
+            raise ValueError("all buffers of one call must live in the same memory space")
+        return ZKP_F_DEVICE_PTRS if dev and dev[0] else 0
+
+    def modexp(self, mod_bits, exp_bits, count, base, exp, exp_stride, mod, mod_stride, out):
+        self.check(self.lib.zkp_modexp_batch(self.h, mod_bits, exp_bits, count, ptr(base), ptr(exp), exp_stride,
+                                             ptr(mod), mod_stride, ptr(out), self._flags(base, exp, mod, out)))
+
+    def modmul(self, mod_bits, count, a, b, mod, mod_stride, out):
+        self.check(self.lib.zkp_modmul_batch(self.h, mod_bits, count, ptr(a), ptr(b), ptr(mod), mod_stride, ptr(out),
+                                             self._flags(a, b, mod, out)))
+
+    def paillier_enc(self, n_bits, count, n, n_stride, m, r, out_c):
+        self.check(self.lib.zkp_paillier_enc_batch(self.h, n_bits, count, ptr(n), n_stride, ptr(m), ptr(r), ptr(out_c),
+                                                   self._flags(n, m, r, out_c)))
+
+    def range_ni_prove(self, proofs: RangeNiProofs, wit: RangeNiWitness, out_e, out_e_len, out_status, device: bool):
+        self.check(self.lib.zkp_range_ni_prove_batch(self.h, C.byref(proofs), C.byref(wit), ptr(out_e), ptr(out_e_len),
+                                                     ptr(out_status), ZKP_F_DEVICE_PTRS if device else 0))
+
+    def range_ni_verify(self, proofs: RangeNiProofs, out_verdict, device: bool):
+        self.check(self.lib.zkp_range_ni_verify_batch(self.h, C.byref(proofs), ptr(out_verdict),
+                                                      ZKP_F_DEVICE_PTRS if device else 0))
+
+    def correct_key_ni_verify(self, n_bits, batch, n, sigma, salt: bytes, out_verdict):
+        sb = (C.c_uint8 * len(salt)).from_buffer_copy(salt) if salt else None
+        self.check(self.lib.zkp_correct_key_ni_verify_batch(self.h, n_bits, batch, ptr(n), ptr(sigma),
+                                                            C.cast(sb, C.c_void_p) if sb else None, len(salt),
+                                                            ptr(out_verdict), self._flags(n, sigma, out_verdict)))
+
+    def dlog_prove(self, n_bits, y_bits, batch, N, g, ni, secret, r, out_x, out_y):
+        self.check(self.lib.zkp_dlog_prove_batch(self.h, n_bits, y_bits, batch, ptr(N), ptr(g), ptr(ni), ptr(secret),
+                                                 ptr(r), ptr(out_x), ptr(out_y), self._flags(N, g, ni, out_x)))
+
+    def dlog_verify(self, n_bits, y_bits, batch, N, g, ni, x, y, out_verdict):
+        self.check(self.lib.zkp_dlog_verify_batch(self.h, n_bits, y_bits, batch, ptr(N), ptr(g), ptr(ni), ptr(x),
+                                                  ptr(y), ptr(out_verdict), self._flags(N, g, ni, x, y, out_verdict)))
