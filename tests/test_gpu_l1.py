@@ -1,0 +1,101 @@
+"""GPU parity tests for the L1 boundary (modexp / modmul / Paillier Enc) through the C ABI,
+bit-exact against the C/GMP oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import pm, L
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_limbs(d, count, nlimbs, bits=None):
+    bits = bits or 32 * nlimbs
+    return L.ints_to_limbs([d.bits(bits) for _ in range(count)], nlimbs)
+
+
+@pytest.mark.parametrize("mod_bits,count", [(2048, 37), (4096, 21), (8192, 13)])
+def test_modexp_per_item_moduli(ctx, oracle, mod_bits, count):
+    d = pm.Drbg(b"gpu-modexp-%d" % mod_bits)
+    nl = mod_bits // 32
+    mods = [d.bits(mod_bits) | 1 | (1 << (mod_bits - 1)) for _ in range(count)]
+    mods[1] = (1 << mod_bits) - 1                      # all-ones modulus
+    mods[2] = (1 << (mod_bits - 1)) + 1                # top limb 0x80000000, sparse
+    mods[3] = d.bits(mod_bits // 2) | 1                # half-width modulus, zero padded
+    mods[4] = 3
+    bases = [d.below(m) for m in mods]
+    bases[0] = 0; bases[5] = 1; bases[6] = mods[6] - 1
+    bases[7] = d.bits(mod_bits)                        # base >= modulus is legal for mpz_powm
+    exps = [d.bits(mod_bits) for _ in range(count)]
+    exps[8] = 0; exps[9] = 1; exps[10] = (1 << mod_bits) - 1; exps[11] = 1 << (mod_bits - 1)
+    b, e, m = (L.ints_to_limbs(v, nl) for v in (bases, exps, mods))
+    out = np.zeros_like(b)
+    ctx.modexp(mod_bits, mod_bits, count, b, e, nl, m, nl, out)
+    ref = oracle.modexp(mod_bits, mod_bits, b, e, nl, m, nl)
+    assert np.array_equal(out, ref)
+
+
+def test_modexp_shared_modulus_short_exponent(ctx, oracle):
+    d = pm.Drbg(b"gpu-modexp-shared")
+    nl, count = 64, 300
+    mod = d.bits(2048) | 1 | (1 << 2047)
+    b = L.ints_to_limbs([d.below(mod) for _ in range(count)], nl)
+    e = rand_limbs(d, count, 8)                           # 256-bit exponents (DLog ni^e shape)
+    m = L.ints_to_limbs([mod], nl)
+    out = np.zeros_like(b)
+    ctx.modexp(2048, 256, count, b, e, 8, m, 0, out)
+    assert np.array_equal(out, oracle.modexp(2048, 256, b, e, 8, m, 0))
+    # shared exponent too (the sigma^n mod n shape with one key)
+    e1 = rand_limbs(d, 1, 64)
+    ctx.modexp(2048, 2048, count, b, e1, 0, m, 0, out)
+    assert np.array_equal(out, oracle.modexp(2048, 2048, b, e1, 0, m, 0))
+
+
+def test_even_modulus_is_refused(ctx, zkp):
+    b = np.ones((2, 64), np.uint32); e = np.ones((2, 64), np.uint32)
+    m = np.zeros((2, 64), np.uint32); m[0, 0] = 7; m[1, 0] = 8
+    out = np.zeros_like(b)
+    with pytest.raises(zkp.ZkpError):
+        ctx.modexp(2048, 2048, 2, b, e, 64, m, 64, out)
+
+
+@pytest.mark.parametrize("mod_bits", [2048, 4096])
+def test_modmul(ctx, oracle, mod_bits):
+    d = pm.Drbg(b"gpu-modmul-%d" % mod_bits)
+    nl, count = mod_bits // 32, 50
+    mods = [d.bits(mod_bits) | 1 | (1 << (mod_bits - 1)) for _ in range(count)]
+    a = rand_limbs(d, count, nl); b = rand_limbs(d, count, nl)     # operands may exceed the modulus
+    a[0] = 0; b[1] = 0; a[2] = L.int_to_limbs(mods[2] - 1, nl); b[2] = a[2]
+    m = L.ints_to_limbs(mods, nl)
+    out = np.zeros_like(a)
+    ctx.modmul(mod_bits, count, a, b, m, nl, out)
+    assert np.array_equal(out, oracle.modmul(mod_bits, a, b, m, nl))
+
+
+def test_paillier_enc_fixture_key(ctx, oracle):
+    _, _, n = H.fixture_key()
+    d = pm.Drbg(b"gpu-enc")
+    count, kw = 70, 64
+    ms = [d.bits(256) for _ in range(count)]
+    rs = [d.below(n) for _ in range(count)]
+    ms[0] = 0; ms[1] = 1; ms[2] = n - 1; ms[3] = (1 << 2048) - 1      # m >= n: (1+m*n) mod n^2 semantics
+    rs[4] = 0; rs[5] = 1; rs[6] = n - 1; rs[7] = (1 << 2048) - 1      # r >= n is legal input to mpz_powm
+    nl, m, r = L.ints_to_limbs([n], kw), L.ints_to_limbs(ms, kw), L.ints_to_limbs(rs, kw)
+    out = np.zeros((count, 2 * kw), np.uint32)
+    ctx.paillier_enc(2048, count, nl, 0, m, r, out)
+    ref = oracle.paillier_enc(2048, nl, 0, m, r)
+    assert np.array_equal(out, ref)
+    assert L.limbs_to_int(out[8]) == pm.enc(n, ms[8], rs[8])
+
+
+def test_paillier_enc_per_item_keys_and_widths(ctx, oracle):
+    for n_bits, count in ((1024, 9), (2048, 6), (4096, 3)):
+        kw = n_bits // 32
+        d = pm.Drbg(b"gpu-enc-keys-%d" % n_bits)
+        ns = [d.bits(n_bits) | 1 | (1 << (n_bits - 1)) for _ in range(count)]    # odd pseudo-moduli suffice for Enc parity
+        ns[0] = H.test_key(512)[2]                                               # short key, zero padded
+        nl = L.ints_to_limbs(ns, kw)
+        m = rand_limbs(d, count, kw, 256); r = L.ints_to_limbs([d.below(v) for v in ns], kw)
+        out = np.zeros((count, 2 * kw), np.uint32)
+        ctx.paillier_enc(n_bits, count, nl, kw, m, r, out)
+        assert np.array_equal(out, oracle.paillier_enc(n_bits, nl, kw, m, r))

@@ -1,0 +1,244 @@
+// bigint29.hpp — wave-cooperative fixed-width big-integer arithmetic for gfx950 (MI355X).
+//
+// Representation (chosen from measurements, see DESIGN.md §3 and profiles/valu_rates_r01.jsonl):
+//   * radix 2^29 limbs held in 32-bit registers.  On gfx950 v_mad_u64_u32 issues at ~4.9
+//     cycles per wave64 but every carry-flag instruction (v_addc_co_u32) costs ~4.3 cycles
+//     too, so a full-radix 2^32 multiply-accumulate with explicit carries is ~2x slower than
+//     a carry-free one.  With 29-bit limbs a 64-bit column accumulator absorbs 64 products
+//     before it can overflow, so the inner loops are pure v_mad_u64_u32 chains.
+//   * one big integer is spread over a group of G lanes of a wavefront, W = 9 limbs per lane:
+//       G = 8  -> 72 limbs  = 2088 bits (moduli up to 2048 bits: n, N of the DLog proof)
+//       G = 16 -> 144 limbs = 4176 bits (moduli up to 4096 bits: n^2 for a 2048-bit n)
+//       G = 32 -> 288 limbs = 8352 bits (moduli up to 8192 bits: n^2 for a 4096-bit n)
+//     so a 64-lane wavefront works on 8 / 4 / 2 independent modular exponentiations.
+//   * Montgomery radix R = 2^(29*G*W) exceeds the modulus by >= 40 bits, hence every
+//     Montgomery product of operands < 2M is again < 2M and no conditional subtraction is
+//     needed inside an exponentiation (one exact canonicalisation at the very end).
+//
+// Montgomery multiplication is a block-CIOS with block radix beta = 2^(29*9): in step s
+// every lane multiplies its block A_j by block B_s (broadcast from LDS) and its modulus
+// block N_j by the quotient block q_s (computed from lane 0's low block, broadcast with
+// ds_swizzle); the low block of each lane's window is then handed to lane j-1 (DPP), so the
+// partial sum for one output position travels down the lanes while it is completed.
+//
+// This file replaces what the reference reaches through curv::BigInt -> GMP
+// (mpz_powm / mpz_mul / mpz_tdiv_r); see include/zkp_hip.h for the call sites.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zkp {
+
+constexpr int LB = 29;                      // bits per limb
+constexpr int W = 9;                        // limbs per lane
+constexpr uint32_t LMASK = (1u << LB) - 1;
+constexpr int BLK = 12;                     // LDS words per 9-limb block (48 B: keeps ds_read_b128 aligned)
+
+template <int G> struct Geo {
+  static constexpr int L = G * W;           // 29-bit limbs per integer
+  static constexpr int CAPBITS = L * LB;    // log2(R)
+  static constexpr int LDS_B = G * BLK;     // words of the B-operand staging area
+};
+
+// ---------------------------------------------------------------- cross-lane primitives
+// value held by lane 0 of the group -> every lane of the group (ds_swizzle, bit-mask mode:
+// lane' = lane & and_mask inside each 32-lane half)
+template <int G> __device__ __forceinline__ uint32_t bcast0(uint32_t v) {
+  static_assert(G == 8 || G == 16 || G == 32, "group size");
+  if constexpr (G == 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0000);
+  else if constexpr (G == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0010);
+  else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0018);
+}
+
+// lane j receives the value of lane j+1 of its group; the top lane receives 0
+template <int G> __device__ __forceinline__ uint32_t from_next(uint32_t v, int gl) {
+  if constexpr (G == 16) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
+  } else if constexpr (G == 8) {
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);
+    return gl == G - 1 ? 0u : t;
+  } else {
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+    return gl == G - 1 ? 0u : t;
+  }
+}
+
+// lane j receives the value of lane j-1 of its group; lane 0 receives 0
+template <int G> __device__ __forceinline__ uint32_t from_prev(uint32_t v, int gl) {
+  if constexpr (G == 16) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+  } else if constexpr (G == 8) {
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    return gl == 0 ? 0u : t;
+  } else {
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+    return gl == 0 ? 0u : t;
+  }
+}
+
+// LDS traffic between lanes of ONE wavefront needs no s_barrier (the LDS queue of a wave is
+// in order); this only stops the compiler from moving LDS accesses across the hand-off.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------- block load/store (9 limbs)
+__device__ __forceinline__ void lds_load_block(uint32_t (&v)[W], const uint32_t* p) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  const uint4 b = *reinterpret_cast<const uint4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; v[8] = p[8];
+}
+__device__ __forceinline__ void lds_store_block(uint32_t* p, const uint32_t (&v)[W]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<uint4*>(p + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+  p[8] = v[8];
+}
+
+// ---------------------------------------------------------------- Montgomery multiplication
+// R = A * B / 2^(29*G*W) mod M, with A in registers (block gl of A), B staged in LDS as G
+// blocks of BLK words, N = block gl of the modulus, NI = -M^-1 mod 2^261 (same on every lane).
+// Operand limbs may be "almost normalised" (< 2^29 + 2^8); operand values < 2M.
+// Result: limbs 1..8 < 2^29, limb 0 < 2^29 + 16; value < 2M.
+template <int G>
+__device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W], const uint32_t* ldsB,
+                                        const uint32_t (&N)[W], const uint32_t (&NI)[W], int gl) {
+  uint64_t acc[2 * W];
+#pragma unroll
+  for (int k = 0; k < 2 * W; k++) acc[k] = 0;
+
+#pragma unroll 1
+  for (int s = 0; s < G; s++) {
+    uint32_t Bs[W];
+    lds_load_block(Bs, ldsB + s * BLK);
+    // acc += A_j * B_s : 81 carry-free v_mad_u64_u32
+#pragma unroll
+    for (int i = 0; i < W; i++)
+#pragma unroll
+      for (int k = 0; k < W; k++) acc[i + k] += (uint64_t)A[i] * Bs[k];
+
+    // exact carry chain through the low block
+    uint32_t lo[W];
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      uint64_t t = acc[k] + c;
+      lo[k] = (uint32_t)t & LMASK;
+      c = t >> LB;
+    }
+    acc[W] += c;
+
+    // q = lo * NI mod beta (only the value computed by lane 0 of the group is used)
+    uint64_t qc[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) qc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++)
+#pragma unroll
+      for (int k = 0; k + i < W; k++) qc[i + k] += (uint64_t)lo[i] * NI[k];
+    uint32_t q[W];
+    c = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      uint64_t t = qc[k] + c;
+      q[k] = (uint32_t)t & LMASK;
+      c = t >> LB;
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) q[k] = bcast0<G>(q[k]);
+
+    // acc += N_j * q
+#pragma unroll
+    for (int k = 0; k < W; k++) acc[k] = lo[k];
+#pragma unroll
+    for (int i = 0; i < W; i++)
+#pragma unroll
+      for (int k = 0; k < W; k++) acc[i + k] += (uint64_t)N[i] * q[k];
+
+    // exact chain again: on lane 0 the low block is now zero, on lane j>0 it is the finished
+    // contribution of this lane to output position j+s and goes to lane j-1
+    uint32_t l2[W];
+    c = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      uint64_t t = acc[k] + c;
+      l2[k] = (uint32_t)t & LMASK;
+      c = t >> LB;
+    }
+    acc[W] += c;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      acc[k] = acc[W + k] + (uint64_t)from_next<G>(l2[k], gl);
+      acc[W + k] = 0;
+    }
+  }
+
+  // lane-local exact chain; the (tiny) carry out of each block lands on limb 0 of the next lane
+  uint64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    uint64_t t = acc[k] + c;
+    R[k] = (uint32_t)t & LMASK;
+    c = t >> LB;
+  }
+  R[0] += from_prev<G>((uint32_t)c, gl);
+}
+
+// ---------------------------------------------------------------- representation changes
+// 32-bit words (LDS, `nwords` valid, zero padded up to at least nwords+2) -> this lane's 9 limbs
+__device__ __forceinline__ void limbs_from_words(uint32_t (&v)[W], const uint32_t* words, int gl) {
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const int bit = (gl * W + k) * LB;
+    const int w0 = bit >> 5, off = bit & 31;
+    const uint64_t x = (uint64_t)words[w0] | ((uint64_t)words[w0 + 1] << 32);
+    v[k] = (uint32_t)(x >> off) & LMASK;
+  }
+}
+
+// Exact normalisation of a redundant value (limbs < 2^32) across the group: afterwards
+// every limb is < 2^29.  Ripples are rare (limb == 2^29-1 with carry-in), the loop is
+// wave-uniform (ballot) and runs at most G+1 times.
+template <int G> __device__ __forceinline__ void normalize_exact(uint32_t (&v)[W], int gl) {
+  for (;;) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      uint32_t t = v[k] + c;
+      v[k] = t & LMASK;
+      c = t >> LB;
+    }
+    uint32_t cin = from_prev<G>(c, gl);
+    v[0] += cin;
+    if (!__any(cin != 0)) break;
+  }
+  // v[0] may still equal 2^29 exactly only if cin was added in the last round, which the loop excludes
+}
+
+// exact limbs (this lane's block) -> LDS as 29-bit limb array [L] (+3 zero words of padding by the caller)
+// then each lane assembles out words [gl*WPL, gl*WPL+WPL) of the 32-bit representation.
+template <int G, int NWORDS>
+__device__ __forceinline__ void words_from_limbs(uint32_t* out_words /*LDS, NWORDS*/, uint32_t* scratch /*LDS, L+3*/,
+                                                 const uint32_t (&v)[W], int gl) {
+  constexpr int L = Geo<G>::L;
+#pragma unroll
+  for (int k = 0; k < W; k++) scratch[gl * W + k] = v[k];
+  if (gl == 0) { scratch[L] = 0; scratch[L + 1] = 0; scratch[L + 2] = 0; }
+  wave_lds_fence();
+  constexpr int WPL = (NWORDS + G - 1) / G;
+#pragma unroll
+  for (int t = 0; t < WPL; t++) {
+    const int w = gl * WPL + t;
+    if (w < NWORDS) {
+      const int bit = w * 32;
+      const int i0 = bit / LB, off = bit - i0 * LB;
+      uint64_t x = (uint64_t)scratch[i0] | ((uint64_t)scratch[i0 + 1] << LB);
+      uint32_t word = (uint32_t)(x >> off);
+      if (off > 2 * LB - 32) word |= scratch[i0 + 2] << (2 * LB - off);   // third limb needed when off > 26
+      out_words[w] = word;
+    }
+  }
+  wave_lds_fence();
+}
+
+}  // namespace zkp

@@ -1,0 +1,549 @@
+// kernels_modexp.hpp — device side of the L1 boundary: per-modulus Montgomery set-up,
+// fixed-window modular exponentiation, Paillier Enc and the fused Enc-and-compare used by
+// RangeProofNi verification.  One modular exponentiation per group of G lanes (see
+// bigint29.hpp); 256-thread workgroups = 4 wavefronts = 256/G exponentiations in flight.
+#pragma once
+#include "bigint29.hpp"
+
+namespace zkp {
+
+constexpr int WIN = 5;                 // fixed window width (table of 32 Montgomery powers in HBM/L2)
+constexpr int TAB = 1 << WIN;
+
+// ---- per-modulus constants in global memory (uint32 words):
+//   N29[L] | R2[L] | R1[L] | NR[L] | NI[BLK] | status[4]
+template <int G> struct ConstLayout {
+  static constexpr int L = Geo<G>::L;
+  static constexpr int OFF_N = 0, OFF_R2 = L, OFF_R1 = 2 * L, OFF_NR = 3 * L, OFF_NI = 4 * L, OFF_ST = 4 * L + BLK;
+  static constexpr int WORDS = 4 * L + BLK + 4;
+};
+
+// ---- per-group LDS carve-up (uint32 words)
+template <int G> struct LdsLayout {
+  static constexpr int L = Geo<G>::L;
+  static constexpr int NW = G * 8;                       // 32-bit words of the modulus width (2048/4096/8192 bits)
+  static constexpr int OFF_B = 0;                        // B operand blocks           [G*BLK]
+  static constexpr int OFF_WORDS = OFF_B + G * BLK;       // 32-bit word staging        [NW+8]
+  static constexpr int OFF_SCR = OFF_WORDS + NW + 8;      // 29-bit limb scratch        [L+8]
+  static constexpr int OFF_EXP = OFF_SCR + L + 8;         // exponent words             [NW+8]
+  static constexpr int WORDS = ((OFF_EXP + NW + 8 + 3) / 4) * 4;   // 16-byte multiple
+  static constexpr int GROUPS_PER_BLOCK = 256 / G;
+  static constexpr int BYTES_PER_BLOCK = WORDS * 4 * GROUPS_PER_BLOCK;
+};
+
+template <int G> struct Grp {
+  uint32_t N[W], NI[W];
+  int gl;            // lane inside the group
+  uint32_t* lds;     // group's LDS base
+  __device__ __forceinline__ uint32_t* B() const { return lds + LdsLayout<G>::OFF_B; }
+  __device__ __forceinline__ uint32_t* words() const { return lds + LdsLayout<G>::OFF_WORDS; }
+  __device__ __forceinline__ uint32_t* scr() const { return lds + LdsLayout<G>::OFF_SCR; }
+  __device__ __forceinline__ uint32_t* expw() const { return lds + LdsLayout<G>::OFF_EXP; }
+};
+
+template <int G> __device__ __forceinline__ void grp_init(Grp<G>& g, uint32_t* lds_base) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  g.gl = lane & (G - 1);
+  const int gib = wave * (64 / G) + lane / G;   // group in block
+  g.lds = lds_base + gib * LdsLayout<G>::WORDS;
+}
+
+template <int G> __device__ __forceinline__ void load_limbs_global(uint32_t (&v)[W], const uint32_t* p, int gl) {
+#pragma unroll
+  for (int k = 0; k < W; k++) v[k] = p[gl * W + k];
+}
+template <int G> __device__ __forceinline__ void store_limbs_global(uint32_t* p, const uint32_t (&v)[W], int gl) {
+#pragma unroll
+  for (int k = 0; k < W; k++) p[gl * W + k] = v[k];
+}
+
+template <int G> __device__ __forceinline__ void load_modulus_consts(Grp<G>& g, const uint32_t* cst) {
+  using CL = ConstLayout<G>;
+  load_limbs_global<G>(g.N, cst + CL::OFF_N, g.gl);
+#pragma unroll
+  for (int k = 0; k < W; k++) g.NI[k] = cst[CL::OFF_NI + k];
+}
+
+// stage the B operand (this lane's block) into LDS
+template <int G> __device__ __forceinline__ void stageB(const Grp<G>& g, const uint32_t (&v)[W]) {
+  wave_lds_fence();
+  lds_store_block(g.B() + g.gl * BLK, v);
+  wave_lds_fence();
+}
+
+template <int G> __device__ __forceinline__ void mm(const Grp<G>& g, uint32_t (&R)[W], const uint32_t (&A)[W]) {
+  montmul<G>(R, A, g.B(), g.N, g.NI, g.gl);
+}
+
+// cooperative copy of `nwords` 32-bit words global -> LDS words area, zero padded to NW+8
+template <int G> __device__ __forceinline__ void fetch_words(const Grp<G>& g, uint32_t* dst, const uint32_t* src, int nwords) {
+  constexpr int NW = LdsLayout<G>::NW;
+  wave_lds_fence();
+  for (int w = g.gl; w < NW + 8; w += G) dst[w] = (w < nwords) ? src[w] : 0u;
+  wave_lds_fence();
+}
+
+// value (32-bit words in global memory) -> this lane's limbs
+template <int G> __device__ __forceinline__ void load_value(const Grp<G>& g, uint32_t (&v)[W], const uint32_t* src, int nwords) {
+  fetch_words<G>(g, g.words(), src, nwords);
+  limbs_from_words(v, g.words(), g.gl);
+}
+
+// Exact canonical residue of a Montgomery-domain-free value x <= M (limbs almost normalised):
+// normalise exactly, convert to NW words in LDS words(), and map x == M to 0.
+// Afterwards words()[0..NW) holds the canonical value (visible to the whole group).
+template <int G> __device__ __forceinline__ void canonical_words(const Grp<G>& g, uint32_t (&x)[W], const uint32_t* cstN /*global N29*/) {
+  constexpr int NW = LdsLayout<G>::NW;
+  normalize_exact<G>(x, g.gl);
+  // x == M ?  (x <= M is guaranteed by the caller: x = montmul(., 1))
+  bool eq = true;
+#pragma unroll
+  for (int k = 0; k < W; k++) eq = eq && (x[k] == g.N[k]);
+  // all lanes of the group must agree
+  const unsigned long long m = __ballot(eq);
+  const int lane = threadIdx.x & 63;
+  const unsigned long long gm = (G == 64) ? ~0ull : (((1ull << G) - 1) << (lane & ~(G - 1)));
+  if ((m & gm) == gm) {
+#pragma unroll
+    for (int k = 0; k < W; k++) x[k] = 0;
+  }
+  words_from_limbs<G, NW>(g.words(), g.scr(), x, g.gl);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fixed-window exponentiation.  In: X = base in Montgomery form (regs), exponent words in
+// g.expw() (exp_words valid + 2 zero words).  Out: X = base^exp in Montgomery form, also
+// staged in B().  tab: this group's 32*L-word table in global memory.
+template <int G>
+__device__ __forceinline__ void powm_window(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cstR1) {
+  constexpr int L = Geo<G>::L;
+  uint32_t T[W], R[W];
+  // table: T[0] = R mod M (Montgomery one), T[1] = X, T[k] = T[k-1]*X
+  load_limbs_global<G>(T, cstR1, g.gl);
+  store_limbs_global<G>(tab, T, g.gl);
+  store_limbs_global<G>(tab + L, X, g.gl);
+  stageB<G>(g, X);
+#pragma unroll
+  for (int k = 0; k < W; k++) T[k] = X[k];
+#pragma unroll 1
+  for (int e = 2; e < TAB; e++) {
+    mm<G>(g, R, T);
+#pragma unroll
+    for (int k = 0; k < W; k++) T[k] = R[k];
+    store_limbs_global<G>(tab + e * L, T, g.gl);
+  }
+  const uint32_t* ew = g.expw();
+  const int nwin = (exp_bits + WIN - 1) / WIN;
+  auto window = [&](int wi) -> int {
+    const int bit = wi * WIN;
+    const int w0 = bit >> 5, off = bit & 31;
+    const uint64_t x = (uint64_t)ew[w0] | ((uint64_t)ew[w0 + 1] << 32);
+    return (int)((x >> off) & (TAB - 1));
+  };
+  // the table stores of this lane are re-read by this lane only: program order suffices
+  load_limbs_global<G>(X, tab + window(nwin - 1) * L, g.gl);
+  stageB<G>(g, X);
+#pragma unroll 1
+  for (int wi = nwin - 2; wi >= 0; wi--) {
+#pragma unroll 1
+    for (int sq = 0; sq < WIN; sq++) {
+      mm<G>(g, R, X);
+#pragma unroll
+      for (int k = 0; k < W; k++) X[k] = R[k];
+      stageB<G>(g, X);
+    }
+    load_limbs_global<G>(T, tab + window(wi) * L, g.gl);
+    mm<G>(g, R, T);
+#pragma unroll
+    for (int k = 0; k < W; k++) X[k] = R[k];
+    stageB<G>(g, X);
+  }
+}
+
+// B() := the integer 1
+template <int G> __device__ __forceinline__ void stage_one(const Grp<G>& g) {
+  uint32_t one[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) one[k] = 0;
+  if (g.gl == 0) one[0] = 1;
+  stageB<G>(g, one);
+}
+
+// ------------------------------------------------------------------------------------------
+// Set-up: one group per modulus.  src: modulus words (src_words each, stride src_stride words);
+// square != 0: the modulus is src^2 (Paillier n -> n^2; src_words = NW/2).
+template <int G>
+__global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src, uint64_t src_stride, int src_words, int square,
+                                               uint64_t count, uint32_t* __restrict__ consts) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  constexpr int L = Geo<G>::L, NW = LL::NW, CAP = Geo<G>::CAPBITS;
+  extern __shared__ __align__(16) uint32_t lds_raw[];
+  Grp<G> g;
+  grp_init<G>(g, lds_raw);
+  const uint64_t gid = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
+  const uint64_t item = gid < count ? gid : count - 1;   // idle groups redo the last modulus (keeps wave ops uniform)
+  const uint32_t* ms = src + item * src_stride;
+  uint32_t* cst = consts + item * CL::WORDS;
+  uint32_t* mw = g.words();     // modulus words [NW+8]
+  uint32_t* rw = g.expw();      // r words [NW+8]  (exponent area is free during set-up)
+  uint32_t* sw = g.scr();       // source words when squaring / m2 words later [>= NW/2+..]; L+4 >= NW/2 and >= NW? no: L+4 = 148 >= 128 ok for all G
+
+  wave_lds_fence();
+  for (int w = g.gl; w < NW + 8; w += G) { mw[w] = 0; rw[w] = 0; }
+  for (int w = g.gl; w < L + 8; w += G) sw[w] = 0;
+  wave_lds_fence();
+  int status = 0;
+  if (g.gl == 0) {
+    if (square) {
+      for (int i = 0; i < src_words; i++) sw[i] = ms[i];   // (overwritten by R mod M below; words above NW stay zero)
+      for (int i = 0; i < src_words; i++) {
+        uint64_t carry = 0;
+        const uint64_t a = sw[i];
+        for (int j = 0; j < src_words; j++) {
+          const uint64_t t = a * sw[j] + mw[i + j] + carry;
+          mw[i + j] = (uint32_t)t;
+          carry = t >> 32;
+        }
+        mw[i + src_words] = (uint32_t)carry;
+      }
+    } else {
+      for (int i = 0; i < src_words; i++) mw[i] = ms[i];
+    }
+    // bit length
+    int top = NW - 1;
+    while (top > 0 && mw[top] == 0) top--;
+    const int bl = mw[top] ? top * 32 + (32 - __clz(mw[top])) : 0;
+    if (bl < 2 || (mw[0] & 1) == 0) {
+      status = 2;   // even or trivial modulus: Montgomery arithmetic undefined
+    } else {
+      const int nw = top + 2;               // words carried for r (< 2M)
+      rw[(bl - 1) >> 5] = 1u << ((bl - 1) & 31);   // r = 2^(bl-1) < M
+      const int doublings = CAP - (bl - 1);
+      for (int it = 0; it <= doublings; it++) {
+        if (it == doublings) {               // r == R mod M here: publish R1, then one more doubling gives 2R mod M
+          for (int w = 0; w < NW; w++) sw[w] = rw[w];
+        }
+        uint32_t carry = 0;
+        for (int w = 0; w < nw; w++) { const uint32_t t = rw[w]; rw[w] = (t << 1) | carry; carry = t >> 31; }
+        int ge = 1;
+        for (int w = nw - 1; w >= 0; w--) {
+          if (rw[w] != mw[w]) { ge = rw[w] > mw[w]; break; }
+        }
+        if (ge) {
+          uint32_t borrow = 0;
+          for (int w = 0; w < nw; w++) {
+            const uint64_t t = (uint64_t)rw[w] - mw[w] - borrow;
+            rw[w] = (uint32_t)t;
+            borrow = (uint32_t)(t >> 63);
+          }
+        }
+      }
+    }
+  }
+  wave_lds_fence();
+  status = (int)bcast0<G>((uint32_t)status);
+  // sw = R mod M (words), rw = 2R mod M (words), mw = M (words)
+  uint32_t M2[W], R1[W];
+  limbs_from_words(g.N, mw, g.gl);
+  limbs_from_words(R1, sw, g.gl);
+  limbs_from_words(M2, rw, g.gl);
+  // NI = -M^-1 mod 2^261: every lane derives it redundantly from the low 9 limbs of M
+  {
+    uint32_t Ml[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      const int bit = k * LB;
+      const int w0 = bit >> 5, off = bit & 31;
+      const uint64_t x = (uint64_t)mw[w0] | ((uint64_t)mw[w0 + 1] << 32);
+      Ml[k] = (uint32_t)(x >> off) & LMASK;
+    }
+    uint32_t y = Ml[0];                       // inverse of M mod 2^3 (odd M)
+#pragma unroll
+    for (int it = 0; it < 5; it++) y *= 2u - Ml[0] * y;   // Newton: 3 -> 6 -> 12 -> 24 -> 48 -> 96 bits
+    const uint32_t m0inv = (0u - y) & LMASK;  // -M^-1 mod 2^29
+    uint64_t T[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) T[k] = 0;
+    T[0] = 1;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      const uint32_t u = (((uint32_t)T[i] & LMASK) * m0inv) & LMASK;
+      g.NI[i] = u;
+#pragma unroll
+      for (int k = 0; k + i < W; k++) T[i + k] += (uint64_t)u * Ml[k];
+      if (i + 1 < W) T[i + 1] += T[i] >> LB;
+    }
+  }
+  // R2 = (2R)^(CAP) * R^-(CAP-1) = 2^CAP * R = R^2 (mod M): square-and-multiply in the Montgomery domain
+  uint32_t X[W], R[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) X[k] = M2[k];
+  stageB<G>(g, X);
+  int msb = 31 - __clz(CAP);
+#pragma unroll 1
+  for (int b = msb - 1; b >= 0; b--) {
+    mm<G>(g, R, X);
+#pragma unroll
+    for (int k = 0; k < W; k++) X[k] = R[k];
+    stageB<G>(g, X);
+    if ((CAP >> b) & 1) {
+      mm<G>(g, R, M2);
+#pragma unroll
+      for (int k = 0; k < W; k++) X[k] = R[k];
+      stageB<G>(g, X);
+    }
+  }
+  // X = R^2 mod M (Montgomery form of R).  NR = src * R mod M (Montgomery form of n) for Paillier contexts.
+  uint32_t NR[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) NR[k] = 0;
+  if (square) {
+    uint32_t nl[W];
+    load_value<G>(g, nl, ms, src_words);     // overwrites words(): modulus words no longer needed
+    mm<G>(g, NR, nl);                        // B() holds R2
+  }
+  if (gid < count) {
+    store_limbs_global<G>(cst + CL::OFF_N, g.N, g.gl);
+    store_limbs_global<G>(cst + CL::OFF_R2, X, g.gl);
+    store_limbs_global<G>(cst + CL::OFF_R1, R1, g.gl);
+    store_limbs_global<G>(cst + CL::OFF_NR, NR, g.gl);
+    if (g.gl == 0) {
+#pragma unroll
+      for (int k = 0; k < W; k++) cst[CL::OFF_NI + k] = g.NI[k];
+      cst[CL::OFF_ST] = (uint32_t)status;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Plain modular exponentiation: out[i] = base[i]^exp[i] mod M[i]
+struct ModexpArgs {
+  const uint32_t* base;     // [count][NW]
+  const uint32_t* exp;      // [count or 1][exp_words]
+  uint64_t exp_stride;      // words
+  const uint32_t* consts;   // per-modulus constants
+  uint64_t const_stride;    // 0 = shared modulus, else ConstLayout::WORDS
+  uint32_t* out;            // [count][NW]
+  uint32_t* table;          // [resident groups][32*L]
+  uint64_t count;
+  int exp_bits;
+};
+
+template <int G>
+__global__ void __launch_bounds__(256) k_modexp(ModexpArgs a) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  constexpr int L = Geo<G>::L, NW = LL::NW;
+  extern __shared__ __align__(16) uint32_t lds_raw[];
+  Grp<G> g;
+  grp_init<G>(g, lds_raw);
+  const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
+  const uint64_t ngrp = (uint64_t)gridDim.x * LL::GROUPS_PER_BLOCK;
+  uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
+  const int exp_words = a.exp_bits / 32;
+  // every wave iterates the same number of times; surplus groups recompute the last item and skip the store
+  const uint64_t rounds = (a.count + ngrp - 1) / ngrp;
+  for (uint64_t rd = 0; rd < rounds; rd++) {
+    const uint64_t idx = rd * ngrp + ggrp;
+    const bool live = idx < a.count;
+    const uint64_t item = live ? idx : a.count - 1;
+    const uint32_t* cst = a.consts + item * a.const_stride;
+    load_modulus_consts<G>(g, cst);
+    uint32_t X[W], R[W], T[W];
+    // exponent words -> LDS
+    fetch_words<G>(g, g.expw(), a.exp + item * a.exp_stride, exp_words);
+    // base -> Montgomery form: X = base * R2 / R
+    load_value<G>(g, T, a.base + item * NW, NW);
+    load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
+    stageB<G>(g, X);
+    mm<G>(g, X, T);
+    powm_window<G>(g, X, a.exp_bits, tab, cst + CL::OFF_R1);
+    // leave the Montgomery domain: montmul(X, 1) <= M
+    stage_one<G>(g);
+    mm<G>(g, R, X);
+    canonical_words<G>(g, R, cst + CL::OFF_N);
+    if (live && cst[CL::OFF_ST] == 0) {
+      for (int w = g.gl; w < NW; w += G) a.out[item * NW + w] = g.words()[w];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Modular multiplication out = a*b mod M (same machinery, two Montgomery products)
+struct ModmulArgs {
+  const uint32_t* a; const uint32_t* b; const uint32_t* consts; uint64_t const_stride; uint32_t* out; uint64_t count;
+};
+template <int G>
+__global__ void __launch_bounds__(256) k_modmul(ModmulArgs a) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  constexpr int NW = LL::NW;
+  extern __shared__ __align__(16) uint32_t lds_raw[];
+  Grp<G> g;
+  grp_init<G>(g, lds_raw);
+  const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
+  const bool live = ggrp < a.count;
+  const uint64_t item = live ? ggrp : a.count - 1;
+  const uint32_t* cst = a.consts + item * a.const_stride;
+  load_modulus_consts<G>(g, cst);
+  uint32_t X[W], Y[W], R[W];
+  load_value<G>(g, X, a.a + item * NW, NW);
+  load_limbs_global<G>(Y, cst + CL::OFF_R2, g.gl);
+  stageB<G>(g, Y);
+  mm<G>(g, R, X);                         // a*R
+  load_value<G>(g, Y, a.b + item * NW, NW);
+  stageB<G>(g, Y);
+  mm<G>(g, X, R);                         // a*b  (< M + eps, value may equal a multiple? a*b*R/R reduced: <= M)
+  // X < 2M possible when b >= M: force through montmul(.,1) after re-entering the domain is overkill;
+  // instead reduce once more: X*R2/R then *1/R
+  load_limbs_global<G>(Y, cst + CL::OFF_R2, g.gl);
+  stageB<G>(g, Y);
+  mm<G>(g, R, X);
+  stage_one<G>(g);
+  mm<G>(g, X, R);
+  canonical_words<G>(g, X, cst + CL::OFF_N);
+  if (live && cst[CL::OFF_ST] == 0) {
+    for (int w = g.gl; w < NW; w += G) a.out[item * NW + w] = g.words()[w];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Paillier Enc: c = (1 + m*n) * r^n mod n^2.   (kzen-paillier EncryptWithChosenRandomness;
+// call sites range_proof.rs:165-169,179-183,280-291,330-334.)
+// The modulus context is n^2 (G lanes); n itself is kw = NW/2 words and doubles as the exponent.
+//   rn  = r^n * R                     (fixed-window ladder in the Montgomery domain)
+//   mn  = montmul(m, NR) = m*n mod n^2          (NR = n*R mod n^2, from set-up)
+//   c   = montmul(mn + 1, rn) = (1 + m*n) * r^n mod n^2, then exact canonicalisation.
+// mode 0: store c.  mode 1 (verify work items): compare with an expected ciphertext, optionally
+// expected = cj * cipher_x mod n^2 (Mask rows, range_proof.rs:324-328), and write one ok byte.
+struct EncArgs {
+  const uint32_t* n;         // [keys][kw]
+  uint64_t n_stride;         // words between keys (0 = shared)
+  const uint32_t* consts;    // per key
+  uint64_t const_stride;
+  uint32_t* table;
+  uint64_t count;            // work items
+  int n_bits;
+  int mode;
+  // mode 0: item i -> m[i], r[i], out[i]; key index = i / items_per_key
+  const uint32_t* m; const uint32_t* r; uint32_t* out; uint64_t items_per_key;
+  // mode 1: item list
+  const uint32_t* item_proof;   // [count] proof index b
+  const uint32_t* item_row;     // [count] (row << 1) | which   (which: 0 -> (w1,r1,c1), 1 -> (w2,r2,c2))
+  const uint32_t* resp_w1; const uint32_t* resp_r1; const uint32_t* resp_w2; const uint32_t* resp_r2;
+  const uint8_t* resp_kind; const uint8_t* resp_j;
+  const uint32_t* c1; const uint32_t* c2; const uint32_t* cipher_x;
+  uint8_t* item_ok;             // [count]
+  uint32_t ef;
+};
+
+template <int G>
+__global__ void __launch_bounds__(256) k_enc(EncArgs a) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  constexpr int L = Geo<G>::L, NW = LL::NW, KW = NW / 2;
+  extern __shared__ __align__(16) uint32_t lds_raw[];
+  Grp<G> g;
+  grp_init<G>(g, lds_raw);
+  const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
+  const uint64_t ngrp = (uint64_t)gridDim.x * LL::GROUPS_PER_BLOCK;
+  uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
+  const int kw = a.n_bits / 32;             // <= KW
+  const uint64_t rounds = (a.count + ngrp - 1) / ngrp;
+  for (uint64_t rd = 0; rd < rounds; rd++) {
+    const uint64_t idx = rd * ngrp + ggrp;
+    const bool live = idx < a.count;
+    const uint64_t item = live ? idx : a.count - 1;
+    uint64_t key;
+    const uint32_t *pm, *pr;
+    const uint32_t* pexp = nullptr;       // expected ciphertext (mode 1)
+    bool mask_row = false;
+    uint64_t b = 0;
+    if (a.mode == 0) {
+      key = item / a.items_per_key;
+      pm = a.m + item * kw;
+      pr = a.r + item * kw;
+    } else {
+      b = a.item_proof[item];
+      const uint32_t rw = a.item_row[item];
+      const uint64_t row = b * a.ef + (rw >> 1);
+      key = b;
+      mask_row = a.resp_kind[row] != 0;
+      const bool second = (rw & 1) != 0;
+      pm = (second ? a.resp_w2 : a.resp_w1) + row * kw;
+      pr = (second ? a.resp_r2 : a.resp_r1) + row * kw;
+      const bool use_c1 = mask_row ? (a.resp_j[row] == 1) : !second;
+      pexp = (use_c1 ? a.c1 : a.c2) + row * 2 * kw;
+    }
+    const uint32_t* cst = a.consts + key * a.const_stride;
+    const uint32_t* pn = a.n + key * a.n_stride;
+    load_modulus_consts<G>(g, cst);
+    uint32_t X[W], R[W], T[W];
+    fetch_words<G>(g, g.expw(), pn, kw);                  // exponent = n
+    load_value<G>(g, T, pr, kw);                          // r (kw words, < 2^n_bits <= n^2)
+    load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
+    stageB<G>(g, X);
+    mm<G>(g, X, T);                                       // r * R
+    powm_window<G>(g, X, a.n_bits, tab, cst + CL::OFF_R1);   // X = r^n * R, staged in B()
+    // mn = m * n mod n^2 : montmul(m, NR); B() must hold NR
+    load_limbs_global<G>(T, cst + CL::OFF_NR, g.gl);
+    stageB<G>(g, T);
+    load_value<G>(g, T, pm, kw);
+    mm<G>(g, R, T);                                       // m*n (plain, < 2M)
+    if (g.gl == 0) R[0] += 1;                             // gm = 1 + m*n  (limb 0 stays < 2^29 + 17)
+    stageB<G>(g, X);                                      // B() = r^n * R
+    mm<G>(g, T, R);                                       // gm * r^n  (plain, < 2M)
+    // exact residue: one more pass through the domain (T*R2/R then *1/R) gives a value <= M
+    load_limbs_global<G>(R, cst + CL::OFF_R2, g.gl);
+    stageB<G>(g, R);
+    mm<G>(g, X, T);
+    stage_one<G>(g);
+    mm<G>(g, R, X);
+    canonical_words<G>(g, R, cst + CL::OFF_N);            // words()[0..NW) = c
+    const bool valid = cst[CL::OFF_ST] == 0;
+    if (a.mode == 0) {
+      if (live) {
+        for (int w = g.gl; w < 2 * kw; w += G) a.out[item * 2 * kw + w] = valid ? g.words()[w] : 0u;
+      }
+    } else {
+      // keep c as limbs for the comparison
+      uint32_t C[W];
+      limbs_from_words(C, g.words(), g.gl);
+      uint32_t E[W];
+      load_value<G>(g, E, pexp, 2 * kw);                  // expected c_j[i]  (may be >= n^2 for a forged proof)
+      // bring the expected value to its canonical residue: (cj [* cipher_x]) mod n^2
+      load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
+      stageB<G>(g, T);
+      mm<G>(g, R, E);                                     // cj * R
+      if (mask_row) {
+        load_value<G>(g, T, a.cipher_x + b * 2 * kw, 2 * kw);
+        stageB<G>(g, T);
+        mm<G>(g, E, R);                                   // cj * cipher_x  (< 2M)
+        load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
+        stageB<G>(g, T);
+        mm<G>(g, R, E);                                   // * R
+      }
+      stage_one<G>(g);
+      mm<G>(g, E, R);
+      canonical_words<G>(g, E, cst + CL::OFF_N);
+      // NOTE: the reference compares c with c_j[i] itself on Open rows (no reduction of c_j):
+      // a non-canonical c_j >= n^2 can never equal a residue, so it must not match here either.
+      bool same = true;
+#pragma unroll
+      for (int k = 0; k < W; k++) same = same && (C[k] == E[k]);
+      if (!mask_row) {
+        // Open rows: expected must be canonical already: compare raw words of c_j with the residue words
+        const uint32_t* ww = g.words();                   // canonical residue of c_j
+        for (int w = g.gl; w < 2 * kw; w += G) same = same && (ww[w] == pexp[w]);
+      }
+      const unsigned long long mk = __ballot(same);
+      const int lane = threadIdx.x & 63;
+      const unsigned long long gm = ((G == 64) ? ~0ull : ((1ull << G) - 1)) << (lane & ~(G - 1));
+      if (live && g.gl == 0) a.item_ok[item] = (valid && (mk & gm) == gm) ? 1 : 0;
+    }
+  }
+}
+
+}  // namespace zkp

@@ -1,0 +1,351 @@
+// zkp_api.hip — host side of libzkp_hip.so: the C ABI of include/zkp_hip.h.
+// One ctx = one GPU + one HIP stream; all device scratch (Montgomery constants, window
+// tables, work lists) is owned by the ctx and grown on demand.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/zkp_hip.h"
+#include "kernels_modexp.hpp"
+#include "kernels_proofs.hpp"
+
+using namespace zkp;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct zkp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int cus = 0;
+  std::string err;
+  DevBuf consts, consts2, table, scratch[16];
+  // timing of the dominant kernels
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t ev_used = 0;
+  uint64_t timed_launches = 0, timed_modexps = 0;
+  std::vector<void*> tmp;   // per-call device staging of host buffers
+};
+
+#define HIPCHK(ctx, call)                                                                         \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                             \
+      return e_ == hipErrorOutOfMemory ? ZKP_ENOMEM : ZKP_EDEVICE;                                \
+    }                                                                                             \
+  } while (0)
+
+static int32_t ensure(zkp_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.cap >= bytes) return ZKP_OK;
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr; b.cap = 0;
+  HIPCHK(c, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return ZKP_OK;
+}
+
+// ---- staging of host buffers --------------------------------------------------------------
+struct Stage {
+  zkp_ctx* c;
+  bool dev;
+  std::vector<void*> owned;
+  struct Out { void* d; void* h; size_t n; };
+  std::vector<Out> outs;
+  int32_t st = ZKP_OK;
+  Stage(zkp_ctx* c_, uint32_t flags) : c(c_), dev((flags & ZKP_F_DEVICE_PTRS) != 0) {}
+  template <class T> const T* in(const T* p, size_t count) {
+    if (dev || !p || st) return p;
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(count * sizeof(T), 16)) != hipSuccess) { st = ZKP_ENOMEM; c->err = "hipMalloc (stage in)"; return nullptr; }
+    owned.push_back(d);
+    if (hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) { st = ZKP_EDEVICE; c->err = "H2D copy"; }
+    return (const T*)d;
+  }
+  template <class T> T* out(T* p, size_t count, bool copy_in = false) {
+    if (dev || !p || st) return p;
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(count * sizeof(T), 16)) != hipSuccess) { st = ZKP_ENOMEM; c->err = "hipMalloc (stage out)"; return nullptr; }
+    owned.push_back(d);
+    if (copy_in) { if (hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) { st = ZKP_EDEVICE; c->err = "H2D copy"; } }
+    else (void)hipMemsetAsync(d, 0, count * sizeof(T), c->stream);
+    outs.push_back({d, (void*)p, count * sizeof(T)});
+    return (T*)d;
+  }
+  int32_t finish() {
+    for (auto& o : outs)
+      if (!st && hipMemcpyAsync(o.h, o.d, o.n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { st = ZKP_EDEVICE; c->err = "D2H copy"; }
+    if (!dev || st) { if (hipStreamSynchronize(c->stream) != hipSuccess && !st) { st = ZKP_EDEVICE; c->err = "stream sync"; } }
+    for (void* p : owned) (void)hipFree(p);
+    owned.clear(); outs.clear();
+    return st;
+  }
+};
+
+// ---- timing ---------------------------------------------------------------------------------
+struct TimedRegion {
+  zkp_ctx* c; bool on; size_t slot = 0;
+  TimedRegion(zkp_ctx* c_, uint64_t modexps) : c(c_), on(c_->timing) {
+    if (!on) return;
+    if (c->ev_used == c->ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+      c->ev.push_back({a, b});
+    }
+    slot = c->ev_used++;
+    (void)hipEventRecord(c->ev[slot].first, c->stream);
+    c->timed_launches++; c->timed_modexps += modexps;
+  }
+  ~TimedRegion() { if (on) (void)hipEventRecord(c->ev[slot].second, c->stream); }
+};
+
+// ---- geometry helpers -----------------------------------------------------------------------
+static int group_for_bits(uint32_t mod_bits) { return mod_bits <= 2048 ? 8 : mod_bits <= 4096 ? 16 : mod_bits <= 8192 ? 32 : 0; }
+
+template <int G, class K> static int resident_blocks(zkp_ctx* c, K kernel) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, LdsLayout<G>::BYTES_PER_BLOCK) != hipSuccess || per_cu < 1) per_cu = 1;
+  return per_cu * c->cus;
+}
+
+template <int G> static int32_t run_setup(zkp_ctx* c, const uint32_t* src, uint64_t stride, int src_words, int square, uint64_t count, DevBuf& buf) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  int32_t st = ensure(c, buf, count * CL::WORDS * sizeof(uint32_t));
+  if (st) return st;
+  const unsigned blocks = (unsigned)((count + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK);
+  hipLaunchKernelGGL(k_setup<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, src, stride, src_words, square, count, (uint32_t*)buf.p);
+  HIPCHK(c, hipGetLastError());
+  return ZKP_OK;
+}
+
+template <int G> static int32_t check_setup_status(zkp_ctx* c, uint64_t count, DevBuf& buf, bool* any_bad) {
+  using CL = ConstLayout<G>;
+  std::vector<uint32_t> st(count);
+  HIPCHK(c, hipMemcpy2DAsync(st.data(), 4, (const uint32_t*)buf.p + CL::OFF_ST, CL::WORDS * 4, 4, count, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *any_bad = false;
+  for (uint32_t v : st) if (v) *any_bad = true;
+  return ZKP_OK;
+}
+
+template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_t items, unsigned* blocks_out) {
+  using LL = LdsLayout<G>;
+  const uint64_t need = (items + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK;
+  const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)resident_blocks<G>(c, kernel)));
+  *blocks_out = blocks;
+  return ensure(c, c->table, (size_t)blocks * LL::GROUPS_PER_BLOCK * TAB * Geo<G>::L * sizeof(uint32_t));
+}
+
+// ---- ctx ------------------------------------------------------------------------------------
+extern "C" int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out) {
+  if (!out) return ZKP_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return ZKP_EDEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return ZKP_EDEVICE;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device_id) != hipSuccess) return ZKP_EDEVICE;
+  if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) return ZKP_EDEVICE;   // kernels are built for gfx950 only
+  zkp_ctx* c = new zkp_ctx();
+  c->device = device_id;
+  c->cus = p.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKP_EDEVICE; }
+  *out = c;
+  return ZKP_OK;
+}
+
+extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) {
+  if (!c) return ZKP_EINVAL;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->consts, &c->consts2, &c->table}) if (b->p) (void)hipFree(b->p);
+  for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
+  for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return ZKP_OK;
+}
+
+extern "C" const char* zkp_backend_name(void) { return "hip-gfx950"; }
+extern "C" const char* zkp_last_error_string(zkp_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+extern "C" void* zkp_ctx_stream(zkp_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int32_t zkp_ctx_synchronize(zkp_ctx* c) {
+  if (!c) return ZKP_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+}
+
+extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) {
+  if (!c) return ZKP_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->timing = enable != 0;
+  c->ev_used = 0; c->timed_launches = 0; c->timed_modexps = 0;
+  return ZKP_OK;
+}
+
+extern "C" int32_t zkp_timing_get(zkp_ctx* c, double* ms, uint64_t* launches, uint64_t* modexps) {
+  if (!c) return ZKP_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double total = 0;
+  for (size_t i = 0; i < c->ev_used; i++) {
+    float t = 0;
+    HIPCHK(c, hipEventElapsedTime(&t, c->ev[i].first, c->ev[i].second));
+    total += t;
+  }
+  if (ms) *ms = total;
+  if (launches) *launches = c->timed_launches;
+  if (modexps) *modexps = c->timed_modexps;
+  return ZKP_OK;
+}
+
+// ---- L1 primitives --------------------------------------------------------------------------
+template <int G>
+static int32_t modexp_impl(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const uint32_t* base, const uint32_t* exp, uint64_t exp_stride,
+                           const uint32_t* mod, uint64_t mod_stride, uint32_t* out) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  const uint64_t nmod = mod_stride ? count : 1;
+  int32_t st = run_setup<G>(c, mod, mod_stride, LL::NW, 0, nmod, c->consts);
+  if (st) return st;
+  bool bad = false;
+  if ((st = check_setup_status<G>(c, nmod, c->consts, &bad))) return st;
+  unsigned blocks = 0;
+  if ((st = table_for<G>(c, k_modexp<G>, count, &blocks))) return st;
+  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, mod_stride ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits};
+  {
+    TimedRegion tr(c, count);
+    hipLaunchKernelGGL(k_modexp<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+  }
+  HIPCHK(c, hipGetLastError());
+  if (bad) { c->err = "even or trivial modulus in batch (outputs of those items are untouched)"; return ZKP_ENONCANONICAL; }
+  return ZKP_OK;
+}
+
+extern "C" int32_t zkp_modexp_batch(zkp_ctx* c, uint32_t mod_bits, uint32_t exp_bits, uint64_t count, const uint32_t* base,
+                                    const uint32_t* exp, uint64_t exp_stride, const uint32_t* mod, uint64_t mod_stride, uint32_t* out,
+                                    uint32_t flags) {
+  if (!c) return ZKP_EINVAL;
+  if (count == 0) return ZKP_OK;
+  if (!base || !exp || !mod || !out || (mod_bits != 2048 && mod_bits != 4096 && mod_bits != 8192) || exp_bits == 0 || exp_bits % 32 ||
+      exp_bits > mod_bits || count > (1ull << 40)) { c->err = "zkp_modexp_batch: invalid argument"; return ZKP_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t L = mod_bits / 32, E = exp_bits / 32;
+  Stage s(c, flags);
+  const uint32_t* dbase = s.in(base, count * L);
+  const uint32_t* dexp = s.in(exp, exp_stride ? count * exp_stride : E);
+  const uint32_t* dmod = s.in(mod, mod_stride ? count * mod_stride : L);
+  uint32_t* dout = s.out(out, count * L);
+  int32_t st = s.st;
+  if (!st) {
+    switch (group_for_bits(mod_bits)) {
+      case 8: st = modexp_impl<8>(c, exp_bits, count, dbase, dexp, exp_stride, dmod, mod_stride, dout); break;
+      case 16: st = modexp_impl<16>(c, exp_bits, count, dbase, dexp, exp_stride, dmod, mod_stride, dout); break;
+      default: st = modexp_impl<32>(c, exp_bits, count, dbase, dexp, exp_stride, dmod, mod_stride, dout); break;
+    }
+  }
+  const int32_t fin = s.finish();
+  return st ? st : fin;
+}
+
+template <int G>
+static int32_t modmul_impl(zkp_ctx* c, uint64_t count, const uint32_t* a, const uint32_t* b, const uint32_t* mod, uint64_t mod_stride, uint32_t* out) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  const uint64_t nmod = mod_stride ? count : 1;
+  int32_t st = run_setup<G>(c, mod, mod_stride, LL::NW, 0, nmod, c->consts);
+  if (st) return st;
+  bool bad = false;
+  if ((st = check_setup_status<G>(c, nmod, c->consts, &bad))) return st;
+  ModmulArgs args{a, b, (const uint32_t*)c->consts.p, mod_stride ? (uint64_t)CL::WORDS : 0, out, count};
+  const unsigned blocks = (unsigned)((count + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK);
+  hipLaunchKernelGGL(k_modmul<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, args);
+  HIPCHK(c, hipGetLastError());
+  if (bad) { c->err = "even or trivial modulus in batch"; return ZKP_ENONCANONICAL; }
+  return ZKP_OK;
+}
+
+extern "C" int32_t zkp_modmul_batch(zkp_ctx* c, uint32_t mod_bits, uint64_t count, const uint32_t* a, const uint32_t* b, const uint32_t* mod,
+                                    uint64_t mod_stride, uint32_t* out, uint32_t flags) {
+  if (!c) return ZKP_EINVAL;
+  if (count == 0) return ZKP_OK;
+  if (!a || !b || !mod || !out || (mod_bits != 2048 && mod_bits != 4096 && mod_bits != 8192) || count > (1ull << 31)) { c->err = "zkp_modmul_batch: invalid argument"; return ZKP_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t L = mod_bits / 32;
+  Stage s(c, flags);
+  const uint32_t* da = s.in(a, count * L);
+  const uint32_t* db = s.in(b, count * L);
+  const uint32_t* dm = s.in(mod, mod_stride ? count * mod_stride : L);
+  uint32_t* dout = s.out(out, count * L);
+  int32_t st = s.st;
+  if (!st) {
+    switch (group_for_bits(mod_bits)) {
+      case 8: st = modmul_impl<8>(c, count, da, db, dm, mod_stride, dout); break;
+      case 16: st = modmul_impl<16>(c, count, da, db, dm, mod_stride, dout); break;
+      default: st = modmul_impl<32>(c, count, da, db, dm, mod_stride, dout); break;
+    }
+  }
+  const int32_t fin = s.finish();
+  return st ? st : fin;
+}
+
+// Paillier contexts: modulus n^2, group size from 2*n_bits
+template <int G>
+static int32_t enc_setup(zkp_ctx* c, uint32_t n_bits, const uint32_t* n, uint64_t n_stride, uint64_t nkeys) {
+  return run_setup<G>(c, n, n_stride, (int)(n_bits / 32), 1, nkeys, c->consts);
+}
+
+template <int G>
+static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m, const uint32_t* r,
+                        uint32_t* out) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  const uint64_t nkeys = n_stride ? count : 1;
+  int32_t st = enc_setup<G>(c, n_bits, n, n_stride, nkeys);
+  if (st) return st;
+  unsigned blocks = 0;
+  if ((st = table_for<G>(c, k_enc<G>, count, &blocks))) return st;
+  EncArgs a{};
+  a.n = n; a.n_stride = n_stride; a.consts = (const uint32_t*)c->consts.p; a.const_stride = n_stride ? (uint64_t)CL::WORDS : 0;
+  a.table = (uint32_t*)c->table.p; a.count = count; a.n_bits = (int)n_bits; a.mode = 0;
+  a.m = m; a.r = r; a.out = out; a.items_per_key = n_stride ? 1 : count;
+  {
+    TimedRegion tr(c, count);
+    hipLaunchKernelGGL(k_enc<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+  }
+  HIPCHK(c, hipGetLastError());
+  return ZKP_OK;
+}
+
+extern "C" int32_t zkp_paillier_enc_batch(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m,
+                                          const uint32_t* r, uint32_t* out_c, uint32_t flags) {
+  if (!c) return ZKP_EINVAL;
+  if (count == 0) return ZKP_OK;
+  if (!n || !m || !r || !out_c || (n_bits != 1024 && n_bits != 2048 && n_bits != 4096) || count > (1ull << 40)) { c->err = "zkp_paillier_enc_batch: invalid argument"; return ZKP_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t kw = n_bits / 32;
+  Stage s(c, flags);
+  const uint32_t* dn = s.in(n, n_stride ? count * n_stride : kw);
+  const uint32_t* dm = s.in(m, count * kw);
+  const uint32_t* dr = s.in(r, count * kw);
+  uint32_t* dout = s.out(out_c, count * 2 * kw);
+  int32_t st = s.st;
+  if (!st) {
+    switch (group_for_bits(2 * n_bits)) {
+      case 8: st = enc_impl<8>(c, n_bits, count, dn, n_stride, dm, dr, dout); break;
+      case 16: st = enc_impl<16>(c, n_bits, count, dn, n_stride, dm, dr, dout); break;
+      default: st = enc_impl<32>(c, n_bits, count, dn, n_stride, dm, dr, dout); break;
+    }
+  }
+  const int32_t fin = s.finish();
+  return st ? st : fin;
+}
+
+#include "zkp_api_proofs.inc"
