@@ -75,6 +75,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)")
+        # torch wheels bundle their own libamdhip64 under the same SONAME as /opt/rocm's: whichever is
+        # loaded first serves the whole process, and torch refuses to find GPUs behind a foreign one.
+        # So when torch is installed, let it load its runtime first (the C ABI itself does not need torch).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported

@@ -3,6 +3,7 @@
 // RangeProofNi verification.  One modular exponentiation per group of G lanes (see
 // bigint29.hpp); 256-thread workgroups = 4 wavefronts = 256/G exponentiations in flight.
 #pragma once
+#include "../../include/zkp_hip.h"
 #include "bigint29.hpp"
 
 namespace zkp {
@@ -435,7 +436,8 @@ struct EncArgs {
   const uint32_t* resp_w1; const uint32_t* resp_r1; const uint32_t* resp_w2; const uint32_t* resp_r2;
   const uint8_t* resp_kind; const uint8_t* resp_j;
   const uint32_t* c1; const uint32_t* c2; const uint32_t* cipher_x;
-  uint8_t* item_ok;             // [count]
+  uint8_t* verdict;             // [B] a failing item clears its proof's verdict
+  const unsigned long long* count_ptr;   // mode 1: device-resident item count (overrides `count`)
   uint32_t ef;
 };
 
@@ -451,11 +453,12 @@ __global__ void __launch_bounds__(256) k_enc(EncArgs a) {
   const uint64_t ngrp = (uint64_t)gridDim.x * LL::GROUPS_PER_BLOCK;
   uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
   const int kw = a.n_bits / 32;             // <= KW
-  const uint64_t rounds = (a.count + ngrp - 1) / ngrp;
+  const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
+  const uint64_t rounds = (count + ngrp - 1) / ngrp;
   for (uint64_t rd = 0; rd < rounds; rd++) {
     const uint64_t idx = rd * ngrp + ggrp;
-    const bool live = idx < a.count;
-    const uint64_t item = live ? idx : a.count - 1;
+    const bool live = idx < count;
+    const uint64_t item = live ? idx : count - 1;
     uint64_t key;
     const uint32_t *pm, *pr;
     const uint32_t* pexp = nullptr;       // expected ciphertext (mode 1)
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(256) k_enc(EncArgs a) {
       const unsigned long long mk = __ballot(same);
       const int lane = threadIdx.x & 63;
       const unsigned long long gm = ((G == 64) ? ~0ull : ((1ull << G) - 1)) << (lane & ~(G - 1));
-      if (live && g.gl == 0) a.item_ok[item] = (valid && (mk & gm) == gm) ? 1 : 0;
+      if (live && g.gl == 0 && !(valid && (mk & gm) == gm)) a.verdict[b] = ZKP_VERDICT_REJECT;
     }
   }
 }

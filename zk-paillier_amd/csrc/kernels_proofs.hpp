@@ -1,2 +1,375 @@
+// kernels_proofs.hpp — proof-level device code around the L1 kernels: Fiat-Shamir transcript
+// hashing, challenge-bit driven response selection (prove) and work-list planning (verify)
+// for RangeProofNi, plus the NiCorrectKeyProof and CompositeDLogProof checks.
 #pragma once
 #include "kernels_modexp.hpp"
+#include "sha256_dev.hpp"
+
+namespace zkp {
+
+// ---- small word-array helpers (per thread, little-endian words in global memory) ------------
+__device__ __forceinline__ int cmp_words(const uint32_t* a, const uint32_t* b, int n) {
+  for (int i = n - 1; i >= 0; i--) {
+    const uint32_t x = a[i], y = b[i];
+    if (x != y) return x > y ? 1 : -1;
+  }
+  return 0;
+}
+
+// bit_vec::BitVec::from_bytes indexing (range_proof.rs:221,225,267,272): MSB first
+__device__ __forceinline__ int challenge_bit(const uint8_t* e, uint32_t i) { return (e[i >> 3] >> (7 - (i & 7))) & 1; }
+
+// ------------------------------------------------------------------------------------------
+// Fiat-Shamir challenge of RangeProofNi (range_proof_ni.rs:58-61 / 89-92 / 110-113):
+//   e = to_bytes(from_bytes(SHA256(to_bytes(n) || to_bytes(c1[0..EF)) || to_bytes(c2[0..EF)))))
+// one thread per proof.  Also derives T = floor(range/3) and 2T (range_proof.rs:219-220, 264-265).
+struct RangeHashArgs {
+  const uint32_t* n; uint64_t n_stride;
+  const uint32_t* c1; const uint32_t* c2; const uint32_t* range;
+  uint32_t kw, ef; uint64_t batch;
+  uint8_t* e;          // [B][32] left aligned
+  uint8_t* e_len;      // [B]
+  uint32_t* third;     // [B][kw]
+  uint32_t* two_thirds;// [B][kw]
+  uint8_t* verdict;    // [B] verify: ACCEPT or MALFORMED to start with; prove: status 0 / MALFORMED
+  uint8_t ok_value;    // value written when the challenge is long enough
+};
+
+__global__ void __launch_bounds__(256) k_range_hash(RangeHashArgs a) {
+  __shared__ uint32_t shabuf[16 * 256];
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.batch) return;
+  Sha256 s;
+  s.init(shabuf + threadIdx.x, 256);
+  s.put_bigint(a.n + b * a.n_stride, (int)a.kw);
+  const uint32_t* c1 = a.c1 + b * a.ef * 2 * a.kw;
+  const uint32_t* c2 = a.c2 + b * a.ef * 2 * a.kw;
+  for (uint32_t i = 0; i < a.ef; i++) s.put_bigint(c1 + (uint64_t)i * 2 * a.kw, 2 * (int)a.kw);
+  for (uint32_t i = 0; i < a.ef; i++) s.put_bigint(c2 + (uint64_t)i * 2 * a.kw, 2 * (int)a.kw);
+  uint32_t d[8];
+  s.finish(d);
+  uint8_t db[32];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { db[4 * i] = d[i] >> 24; db[4 * i + 1] = d[i] >> 16; db[4 * i + 2] = d[i] >> 8; db[4 * i + 3] = d[i]; }
+  int lead = 0;
+  while (lead < 31 && db[lead] == 0) lead++;      // BigInt round trip drops leading zero bytes; zero -> "00"
+  uint8_t* e = a.e + b * 32;
+  for (int i = 0; i < 32; i++) e[i] = (i + lead < 32) ? db[i + lead] : 0;
+  const int elen = 32 - lead;
+  a.e_len[b] = (uint8_t)elen;
+  // bits_of_e[i] for i < EF must exist, otherwise the reference panics (index out of bounds)
+  a.verdict[b] = ((uint32_t)elen * 8 >= a.ef) ? a.ok_value : (uint8_t)ZKP_VERDICT_MALFORMED;
+  // T = range div_floor 3, 2T
+  const uint32_t* rg = a.range + b * a.kw;
+  uint32_t* t1 = a.third + b * a.kw;
+  uint32_t* t2 = a.two_thirds + b * a.kw;
+  uint64_t rem = 0;
+  for (int w = (int)a.kw - 1; w >= 0; w--) {
+    const uint64_t cur = (rem << 32) | rg[w];
+    t1[w] = (uint32_t)(cur / 3);
+    rem = cur % 3;
+  }
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < a.kw; w++) { const uint32_t v = t1[w]; t2[w] = (v << 1) | carry; carry = v >> 31; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Verify planning: one thread per (proof, row).  Applies the kind/bit match and the range
+// predicates of verifier_output (range_proof.rs:270-348) and appends the Enc checks the row
+// needs to the work list: Open -> (w1,r1)->c1[i] and (w2,r2)->c2[i]; Mask -> (masked_x,masked_r).
+struct VerifyPlanArgs {
+  const uint8_t* e; const uint8_t* resp_kind;
+  const uint32_t* resp_w1; const uint32_t* resp_w2;
+  const uint32_t* third; const uint32_t* two_thirds;
+  uint32_t kw, ef; uint64_t batch;
+  uint8_t* verdict;
+  uint32_t* item_proof; uint32_t* item_row; unsigned long long* counter;
+};
+
+__global__ void __launch_bounds__(256) k_verify_plan(VerifyPlanArgs a) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool in = t < a.batch * a.ef;
+  uint32_t nitems = 0;
+  uint64_t b = 0; uint32_t i = 0;
+  if (in) {
+    b = t / a.ef; i = (uint32_t)(t % a.ef);
+    if (a.verdict[b] != ZKP_VERDICT_MALFORMED) {
+      const int ei = challenge_bit(a.e + b * 32, i);
+      const int kind = a.resp_kind[t];
+      const uint32_t* T1 = a.third + b * a.kw;
+      const uint32_t* T2 = a.two_thirds + b * a.kw;
+      const uint32_t* w1 = a.resp_w1 + t * a.kw;
+      if (!ei && kind == ZKP_RESP_OPEN) {
+        const uint32_t* w2 = a.resp_w2 + t * a.kw;
+        const int w1_T1 = cmp_words(w1, T1, a.kw), w2_T1 = cmp_words(w2, T1, a.kw);
+        const bool flag = (w2_T1 < 0 && w1_T1 > 0 && cmp_words(w1, T2, a.kw) < 0) ||
+                          (w1_T1 < 0 && w2_T1 > 0 && cmp_words(w2, T2, a.kw) < 0);      // range_proof.rs:300-305
+        if (!flag) a.verdict[b] = ZKP_VERDICT_REJECT;
+        nitems = 2;
+      } else if (ei && kind == ZKP_RESP_MASK) {
+        if (cmp_words(w1, T1, a.kw) < 0 || cmp_words(w1, T2, a.kw) > 0) a.verdict[b] = ZKP_VERDICT_REJECT;   // :338
+        nitems = 1;
+      } else {
+        a.verdict[b] = ZKP_VERDICT_REJECT;                                              // :345
+      }
+    }
+  }
+  // wave-aggregated append
+  const unsigned long long m2 = __ballot(nitems == 2), m1 = __ballot(nitems == 1);
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1;
+  const uint32_t before = 2 * __popcll(m2 & lt) + __popcll(m1 & lt);
+  const uint32_t total = 2 * __popcll(m2) + __popcll(m1);
+  unsigned long long base = 0;
+  if (lane == 0 && total) base = atomicAdd(a.counter, (unsigned long long)total);
+  base = __shfl(base, 0);
+  for (uint32_t k = 0; k < nitems; k++) {
+    a.item_proof[base + before + k] = (uint32_t)b;
+    a.item_row[base + before + k] = (i << 1) | k;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Prove: generate_proof (range_proof.rs:210-252), one group (n context) per (proof, row).
+struct ResponseArgs {
+  const uint32_t* consts; uint64_t const_stride;     // modulus n
+  const uint32_t* x; const uint32_t* r;              // [B][kw]
+  const uint32_t* w1; const uint32_t* w2; const uint32_t* r1; const uint32_t* r2;   // [B][EF][kw]
+  const uint8_t* e; const uint32_t* third; const uint32_t* two_thirds;
+  uint8_t* resp_kind; uint8_t* resp_j; uint32_t* resp_w1; uint32_t* resp_r1; uint32_t* resp_w2; uint32_t* resp_r2;
+  uint8_t* status;
+  uint32_t kw, ef; uint64_t batch;
+};
+
+template <int G>
+__global__ void __launch_bounds__(256) k_range_responses(ResponseArgs a) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  extern __shared__ __align__(16) uint32_t lds_raw[];
+  Grp<G> g;
+  grp_init<G>(g, lds_raw);
+  const uint64_t rows = a.batch * a.ef;
+  const uint64_t gid = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
+  const bool live = gid < rows;
+  const uint64_t t = live ? gid : rows - 1;
+  const uint64_t b = t / a.ef;
+  const uint32_t i = (uint32_t)(t % a.ef);
+  const int kw = (int)a.kw;
+  const uint32_t* cst = a.consts + b * a.const_stride;
+  load_modulus_consts<G>(g, cst);
+  const bool malformed = a.status[b] == ZKP_VERDICT_MALFORMED;
+  const int ei = malformed ? 0 : challenge_bit(a.e + b * 32, i);
+  // lane 0: masked_x = x + w1 (or x + w2), decision T < x+w1 < 2T (both strict, range_proof.rs:233-234)
+  uint32_t* sum = g.expw();   // (scr() is clobbered by canonical_words below; the exponent area is unused here)
+  uint32_t sel = 1, ovf = 0;
+  if (g.gl == 0) {
+    const uint32_t* xs = a.x + b * kw;
+    const uint32_t* ws = a.w1 + t * kw;
+    uint64_t c = 0;
+    for (int w = 0; w < kw; w++) { c += (uint64_t)xs[w] + ws[w]; sum[w] = (uint32_t)c; c >>= 32; }
+    const bool in = c == 0 && cmp_words(sum, a.third + b * kw, kw) > 0 && cmp_words(sum, a.two_thirds + b * kw, kw) < 0;
+    if (!in) {
+      sel = 2;
+      ws = a.w2 + t * kw;
+      c = 0;
+      for (int w = 0; w < kw; w++) { c += (uint64_t)xs[w] + ws[w]; sum[w] = (uint32_t)c; c >>= 32; }
+      ovf = c != 0;     // x + w2 does not fit the fixed-width ABI
+    }
+  }
+  wave_lds_fence();
+  sel = bcast0<G>(sel);
+  ovf = bcast0<G>(ovf);
+  // masked_r = secret_r * r_j % n  (range_proof.rs:239,245)
+  uint32_t X[W], Y[W], R[W];
+  load_value<G>(g, X, a.r + b * kw, kw);
+  load_limbs_global<G>(Y, cst + CL::OFF_R2, g.gl);
+  stageB<G>(g, Y);
+  mm<G>(g, R, X);                                                   // r * R
+  load_value<G>(g, Y, (sel == 1 ? a.r1 : a.r2) + t * kw, kw);
+  stageB<G>(g, Y);
+  mm<G>(g, X, R);                                                   // r * r_j  (< 2M)
+  load_limbs_global<G>(Y, cst + CL::OFF_R2, g.gl);
+  stageB<G>(g, Y);
+  mm<G>(g, R, X);
+  stage_one<G>(g);
+  mm<G>(g, X, R);
+  canonical_words<G>(g, X, cst + CL::OFF_N);                        // words() = masked_r
+  if (!live || malformed) return;
+  uint32_t* ow1 = a.resp_w1 + t * kw; uint32_t* or1 = a.resp_r1 + t * kw;
+  uint32_t* ow2 = a.resp_w2 + t * kw; uint32_t* or2 = a.resp_r2 + t * kw;
+  if (!ei) {                                                        // Open (range_proof.rs:226-232)
+    for (int w = g.gl; w < kw; w += G) {
+      ow1[w] = a.w1[t * kw + w]; or1[w] = a.r1[t * kw + w]; ow2[w] = a.w2[t * kw + w]; or2[w] = a.r2[t * kw + w];
+    }
+    if (g.gl == 0) { a.resp_kind[t] = ZKP_RESP_OPEN; a.resp_j[t] = 0; }
+  } else {                                                          // Mask (:236-246)
+    for (int w = g.gl; w < kw; w += G) { ow1[w] = sum[w]; or1[w] = g.words()[w]; ow2[w] = 0; or2[w] = 0; }
+    if (g.gl == 0) {
+      a.resp_kind[t] = ZKP_RESP_MASK; a.resp_j[t] = (uint8_t)sel;
+      if (ovf || cst[CL::OFF_ST] != 0) a.status[b] = ZKP_VERDICT_MALFORMED;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// NiCorrectKeyProof::verify (correct_key_ni.rs:73-100)
+// (1) one thread per proof: salt_bn, the 11 seeds and the MGF output words (mask_generation,
+//     :105-117: sum_j SHA256(seed || j) << 256 j, j < key_length/256 + 1), and the small-prime
+//     test that is boolean-equivalent to gcd(P, n) == 1 with P = product of primes < 6370.
+struct CkHashArgs {
+  const uint32_t* n; uint32_t kw; uint64_t batch;
+  const uint8_t* salt; uint32_t salt_len;
+  uint32_t* mgf;        // [B][11][kw+8] little-endian words of mask_generation(...)
+  uint8_t* verdict;     // ACCEPT / REJECT (gcd test) to start with
+  const uint32_t* primes; uint32_t nprimes;   // primes < 6370
+};
+
+__device__ __forceinline__ void sha_put_u32_as_bigint(Sha256& s, uint32_t v) { s.put_bigint(&v, 1); }
+
+__global__ void __launch_bounds__(256) k_ck_hash(CkHashArgs a) {
+  __shared__ uint32_t shabuf[16 * 256];
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.batch) return;
+  const uint32_t* n = a.n + b * a.kw;
+  const int kw = (int)a.kw;
+  Sha256 s;
+  // salt_bn = H(to_bytes(from_bytes(salt)))  (:75): leading zero bytes of the salt vanish, empty/zero -> 00
+  uint32_t salt_d[8];
+  {
+    s.init(shabuf + threadIdx.x, 256);
+    uint32_t lead = 0;
+    while (lead < a.salt_len && a.salt[lead] == 0) lead++;
+    if (lead == a.salt_len) s.put_bytes(0, 1);
+    for (uint32_t i = lead; i < a.salt_len; i++) s.put_bytes(a.salt[i], 1);
+    s.finish(salt_d);
+  }
+  // key_length = n.bit_length()
+  int top = kw - 1;
+  while (top > 0 && n[top] == 0) top--;
+  const int key_length = n[top] ? top * 32 + 32 - __clz(n[top]) : 0;
+  const int msklen = key_length / 256 + 1;
+  uint32_t le[8];
+  for (uint32_t i = 0; i < ZKP_CORRECT_KEY_M2; i++) {
+    // seed = H(n || salt_bn || i)  (:79-83)
+    uint32_t seed_d[8];
+    s.init(shabuf + threadIdx.x, 256);
+    s.put_bigint(n, kw);
+#pragma unroll
+    for (int k = 0; k < 8; k++) le[k] = salt_d[7 - k];
+    s.put_bigint(le, 8);
+    sha_put_u32_as_bigint(s, i);
+    s.finish(seed_d);
+    uint32_t seed_le[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) seed_le[k] = seed_d[7 - k];
+    uint32_t* out = a.mgf + (b * ZKP_CORRECT_KEY_M2 + i) * (uint64_t)(kw + 8);
+    for (int w = 0; w < kw + 8; w++) out[w] = 0;
+    for (int j = 0; j < msklen; j++) {
+      uint32_t hj[8];
+      s.init(shabuf + threadIdx.x, 256);
+      s.put_bigint(seed_le, 8);
+      sha_put_u32_as_bigint(s, (uint32_t)j);
+      s.finish(hj);
+      if (8 * j + 8 <= kw + 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) out[8 * j + k] = hj[7 - k];   // the digests occupy disjoint 256-bit slots
+      }
+    }
+  }
+  // gcd(P, n) == 1  <=>  no prime < 6370 divides n
+  bool coprime = true;
+  for (uint32_t pi = 0; pi < a.nprimes; pi++) {
+    const uint32_t p = a.primes[pi];
+    uint64_t rem = 0;
+    for (int w = kw - 1; w >= 0; w--) rem = ((rem << 32) | n[w]) % p;
+    if (rem == 0) coprime = false;
+  }
+  a.verdict[b] = coprime ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
+}
+
+// (2) one group (n context) per (proof, i): sigma_i^n mod n  ==  mask_generation(..) mod n  (:84,:92,:95)
+struct CkCheckArgs {
+  const uint32_t* n; const uint32_t* sigma; const uint32_t* mgf; const uint32_t* consts;
+  uint32_t* table; uint8_t* verdict; uint64_t count; int n_bits;
+};
+
+template <int G>
+__global__ void __launch_bounds__(256) k_ck_check(CkCheckArgs a) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  constexpr int L = Geo<G>::L, NW = LL::NW;
+  extern __shared__ __align__(16) uint32_t lds_raw[];
+  Grp<G> g;
+  grp_init<G>(g, lds_raw);
+  const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
+  const uint64_t ngrp = (uint64_t)gridDim.x * LL::GROUPS_PER_BLOCK;
+  uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
+  const int kw = a.n_bits / 32;
+  const uint64_t rounds = (a.count + ngrp - 1) / ngrp;
+  for (uint64_t rd = 0; rd < rounds; rd++) {
+    const uint64_t idx = rd * ngrp + ggrp;
+    const bool live = idx < a.count;
+    const uint64_t item = live ? idx : a.count - 1;
+    const uint64_t b = item / ZKP_CORRECT_KEY_M2;
+    const uint32_t* cst = a.consts + b * CL::WORDS;
+    load_modulus_consts<G>(g, cst);
+    uint32_t X[W], R[W], T[W], RHO[W];
+    // rho = (v_lo + v_hi * 2^(32 kw)) mod n with v = MGF output (kw + 8 words)
+    const uint32_t* v = a.mgf + item * (uint64_t)(kw + 8);
+    load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
+    stageB<G>(g, T);                                     // B() = R2
+    load_value<G>(g, X, v, kw);
+    mm<G>(g, RHO, X);                                    // v_lo * R
+    {
+      uint32_t P[W];                                     // P = 2^(32 kw) as limbs
+      const int bit = 32 * kw;
+#pragma unroll
+      for (int k = 0; k < W; k++) P[k] = ((g.gl * W + k) == bit / LB) ? (1u << (bit % LB)) : 0u;
+      mm<G>(g, R, P);                                    // 2^(32kw) * R
+      mm<G>(g, T, R);                                    // 2^(32kw) * R^2   (B() still R2)
+      stageB<G>(g, T);
+      load_value<G>(g, X, v + kw, 8);
+      mm<G>(g, R, X);                                    // v_hi * 2^(32kw) * R
+#pragma unroll
+      for (int k = 0; k < W; k++) RHO[k] += R[k];        // limbs < 2^30 + 32: still a valid operand
+    }
+    stage_one<G>(g);
+    mm<G>(g, R, RHO);                                    // rho mod n  (<= n)
+    normalize_exact<G>(R, g.gl);
+    bool is_m = true;
+#pragma unroll
+    for (int k = 0; k < W; k++) is_m = is_m && (R[k] == g.N[k]);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long gm = ((1ull << G) - 1) << (lane & ~(G - 1));
+    if ((__ballot(is_m) & gm) == gm) {
+#pragma unroll
+      for (int k = 0; k < W; k++) R[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) RHO[k] = R[k];           // canonical rho limbs
+    // sigma^n mod n
+    fetch_words<G>(g, g.expw(), a.n + b * kw, kw);
+    load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
+    stageB<G>(g, T);
+    load_value<G>(g, T, a.sigma + item * kw, kw);
+    mm<G>(g, X, T);
+    powm_window<G>(g, X, a.n_bits, tab, cst + CL::OFF_R1);
+    stage_one<G>(g);
+    mm<G>(g, R, X);
+    normalize_exact<G>(R, g.gl);
+    bool same = true, eqm = true;
+#pragma unroll
+    for (int k = 0; k < W; k++) { same = same && (R[k] == RHO[k]); eqm = eqm && (R[k] == g.N[k]); }
+    // R == n means the residue 0
+    const bool r_is_m = (__ballot(eqm) & gm) == gm;
+    bool rho_zero = true;
+#pragma unroll
+    for (int k = 0; k < W; k++) rho_zero = rho_zero && (RHO[k] == 0);
+    const bool all_same = (__ballot(same) & gm) == gm;
+    const bool all_rho_zero = (__ballot(rho_zero) & gm) == gm;
+    const bool ok = r_is_m ? all_rho_zero : all_same;
+    if (live && g.gl == 0 && (!ok || cst[CL::OFF_ST] != 0)) a.verdict[b] = ZKP_VERDICT_REJECT;
+  }
+}
+
+}  // namespace zkp
