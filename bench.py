@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — RangeProofNi verify (headline) and prove throughput at n=2048, batch=4096 proofs per GPU.
+
+A "step" of the headline metric is one pass of zkp_range_ni_verify_batch over one batch of
+B synthetic proofs already resident in HBM (BASELINE.json configs[1]); the prove leg
+(configs[2]) is timed the same way and reported beside it.  One process per GPU; for N>1 the
+proof indices are sharded by rank (weak scaling: B proofs per rank), no collective on the
+data path, and one RCCL all-gather reassembles the verdict vector (and the ciphertext slabs
+of the prove leg) inside the timed region.
+
+Prints ONE JSON line on rank 0.  See DESIGN.md §6 for the definitions of roofline/cpu_baseline."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# measured on MI355X (profiles/valu_rates_r01.jsonl): v_mad_u64_u32, 8 waves/SIMD, 256 CUs
+PEAK_LIMB_MAC_PER_S = 3.19e13
+HBM_PEAK_GBS = 8000.0
+# algorithmic 32x32->64 limb-MACs of one Enc at n=2048: 1.2*2048 modmuls x (2*128^2+128)
+def enc_limb_macs(n_bits):
+    Lw = 2 * n_bits // 32
+    return 1.2 * n_bits * (2 * Lw * Lw + Lw)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU")
+    ap.add_argument("--n-bits", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=96, help="proofs verified by the CPU baseline (0 = skip)")
+    ap.add_argument("--no-prove-leg", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    zkp = importlib.import_module("zk-paillier_amd")
+    from importlib import import_module
+    synth = import_module("zk-paillier_amd.synth")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    ctx = zkp.Context(local_rank)          # raises if the HIP library / a gfx950 GPU is missing
+
+    B, n_bits, EF = args.batch, args.n_bits, 128
+    kw = n_bits // 32
+    n = synth.BENCH_N
+    assert n_bits == 2048, "the bench key is the reference's 2048-bit fixture"
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    # ---- inputs (untimed): witnesses in HBM, ciphertext = Enc(x, r) by the engine itself
+    pb, wt = synth.synth_range_inputs(n, n_bits, B, seed=1234 + rank, device=dev)
+    sync()
+    ctx.paillier_enc(n_bits, B, pb.n, 0, wt.x, wt.r, pb.ciphertext)
+    sync()
+    pstruct, wstruct = pb.struct(), wt.struct()
+    verdict = torch.zeros(B, dtype=torch.uint8, device=dev)
+    gathered_v = torch.zeros(B * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered_c = None
+    if world > 1 and not args.no_prove_leg:
+        gathered_c = [torch.empty((B * world,) + tuple(pb.c1.shape[1:]), dtype=pb.c1.dtype, device=dev) for _ in range(2)]
+
+    def prove_step():
+        ctx.range_ni_prove(pstruct, wstruct, None, None, None, device=True)
+        if world > 1:
+            ctx.synchronize()
+            dist.all_gather_into_tensor(gathered_c[0], pb.c1)
+            dist.all_gather_into_tensor(gathered_c[1], pb.c2)
+
+    def verify_step():
+        ctx.range_ni_verify(pstruct, verdict, device=True)
+        if world > 1:
+            ctx.synchronize()
+            dist.all_gather_into_tensor(gathered_v, verdict)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        ctx.timing_reset(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        kms, launches, modexps = ctx.timing_get()
+        ctx.timing_reset(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kms, launches, modexps
+
+    # ---- prove leg (also produces the proofs the verify leg consumes)
+    prove = None
+    if args.no_prove_leg:
+        prove_step(); sync()
+    else:
+        dt, kms, launches, modexps = timed(prove_step, args.steps, args.warmup)
+        prove = {"value": B * world * args.steps / dt, "unit": "proofs/s", "ms_per_step": 1e3 * dt / args.steps,
+                 "enc_kernel_ms_per_launch": kms / max(launches, 1), "launches": launches,
+                 "achieved_limb_mac_per_s": modexps * enc_limb_macs(n_bits) / (kms * 1e-3) if kms else None}
+    # tamper every 64th proof (one bit of resp_r1 in row 0): those must be rejected, all others accepted
+    tampered = torch.arange(0, B, 64, device=dev)
+    pb.resp_r1[tampered, 0, 0] ^= 1
+    expect = torch.ones(B, dtype=torch.uint8, device=dev)
+    expect[tampered] = 0
+    sync()
+
+    # ---- verify leg (headline)
+    dt, kms, launches, modexps = timed(verify_step, args.steps, args.warmup)
+    sync()
+    ok = bool(torch.equal(verdict, expect))
+    if world > 1:
+        ok = ok and bool(torch.equal(gathered_v.view(world, B)[rank], expect))
+    value = B * world * args.steps / dt
+    enc_per_launch = modexps / max(launches, 1)
+    ach = modexps * enc_limb_macs(n_bits) / (kms * 1e-3) if kms else 0.0
+    # algorithmic bytes per Enc-check: r, m (kw words each) + expected ciphertext (2kw) + 8 B item
+    bytes_per_enc = 4 * kw * 4 + 8
+    roofline = {"bound": "valu", "achieved": ach / 1e12, "peak": PEAK_LIMB_MAC_PER_S / 1e12, "unit": "Tlimb-MAC/s",
+                "frac": ach / PEAK_LIMB_MAC_PER_S, "traffic": None,
+                "kernel": "k_enc<16> (fused Enc-and-compare)", "kernel_ms_per_launch": kms / max(launches, 1),
+                "modexps_per_launch": enc_per_launch,
+                "hbm": {"achieved": modexps * bytes_per_enc / (kms * 1e-3) / 1e9 if kms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+
+    # ---- CPU baseline: the C/GMP oracle on a bounded sample of the same proofs (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib   # test infrastructure: used here only as the reported CPU baseline / checker
+        oracle = oracle_lib.Oracle()
+        S = min(args.cpu_sample, B)
+        # a sample that contains a tampered proof: proofs 0..S-1 (proof 0 is tampered)
+        host = pb.slice(0, S).to(None)
+        threads = oracle.max_threads()
+        oracle.set_threads(threads)
+        vo = np.zeros(S, np.uint8)
+        t0 = time.perf_counter()
+        oracle.range_ni_verify(host.struct(), vo)
+        t_cpu = time.perf_counter() - t0
+        same = bool(np.array_equal(vo, verdict[:S].cpu().numpy()))
+        ok = ok and same
+        cpu = {"value": S / t_cpu, "unit": "verifies/s", "cores": threads, "kind": "port",
+               "sample": f"oracle (C + GMP 6.2.1 mpz_powm, OpenMP over (proof,row)) verifying proofs 0..{S-1} of the same batch in {t_cpu:.2f}s; verdicts equal to GPU: {same}"}
+
+    if rank == 0:
+        out = {"metric": "RangeProofNi verifies/sec, n=2048, batch=4096 per GPU", "value": value, "unit": "verifies/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs, u64 accumulate)",
+               "data": "synthetic", "verdicts_ok": ok,
+               "config": {"workload": f"BASELINE.json configs[1]: batch={B} RangeProofNi verify per GPU, n={n_bits} (reference fixture key), "
+                                      f"128 rows/proof, 1/64 of the proofs tampered; prove leg = configs[2]",
+                          "parallelism": f"proof-index sharding x{world}, all-gather of verdicts" if world > 1 else "single GPU"},
+               "prove": prove, "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

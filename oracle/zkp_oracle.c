@@ -239,29 +239,35 @@ static int challenge_bit(const uint8_t* e, uint32_t i) { return (e[i / 8] >> (7 
 int32_t oracle_range_ni_prove_batch(const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w, uint8_t* out_e,
                                     uint8_t* out_e_len, uint8_t* out_status) {
   const size_t kw = p->n_bits / 32, EF = ZKP_SECURITY_PARAMETER;
+  /* generate_encrypted_pairs, range_proof.rs:161-187 (randomness injected, :136-159); the pool runs over the
+   * flattened (proof, c1|c2, row) list */
+#pragma omp parallel num_threads(n_threads)
+  {
+    mpz_t zn, znn, zm, zr, zc, t;
+    mpz_inits(zn, znn, zm, zr, zc, t, NULL);
+    int64_t cur = -1;
+#pragma omp for schedule(dynamic, 8)
+    for (int64_t it = 0; it < (int64_t)(p->batch * 2 * EF); it++) {
+      const int64_t b = it / (int64_t)(2 * EF), i = it % (int64_t)(2 * EF);
+      if (b != cur) {
+        cur = b;
+        limbs_to_mpz(zn, p->n + b * p->n_stride, kw);
+        mpz_mul(znn, zn, zn);
+      }
+      size_t row = (size_t)i % EF;
+      const uint32_t* wm = (i < (int64_t)EF ? w->w1 : w->w2) + (b * EF + row) * kw;
+      const uint32_t* wr = (i < (int64_t)EF ? w->r1 : w->r2) + (b * EF + row) * kw;
+      limbs_to_mpz(zm, wm, kw);
+      limbs_to_mpz(zr, wr, kw);
+      enc_mpz(zc, zn, znn, zm, zr, t);
+      mpz_to_limbs((i < (int64_t)EF ? p->c1 : p->c2) + (b * EF + row) * 2 * kw, 2 * kw, zc);
+    }
+    mpz_clears(zn, znn, zm, zr, zc, t, NULL);
+  }
   for (uint64_t b = 0; b < p->batch; b++) {
     const uint32_t* nl = p->n + b * p->n_stride;
     uint32_t* c1 = p->c1 + b * EF * 2 * kw;
     uint32_t* c2 = p->c2 + b * EF * 2 * kw;
-    /* generate_encrypted_pairs, range_proof.rs:161-187 (randomness injected, :136-159) */
-#pragma omp parallel num_threads(n_threads)
-    {
-      mpz_t zn, znn, zm, zr, zc, t;
-      mpz_inits(zn, znn, zm, zr, zc, t, NULL);
-      limbs_to_mpz(zn, nl, kw);
-      mpz_mul(znn, zn, zn);
-#pragma omp for schedule(dynamic, 1)
-      for (int64_t i = 0; i < (int64_t)(2 * EF); i++) {
-        size_t row = (size_t)i % EF;
-        const uint32_t* wm = (i < (int64_t)EF ? w->w1 : w->w2) + (b * EF + row) * kw;
-        const uint32_t* wr = (i < (int64_t)EF ? w->r1 : w->r2) + (b * EF + row) * kw;
-        limbs_to_mpz(zm, wm, kw);
-        limbs_to_mpz(zr, wr, kw);
-        enc_mpz(zc, zn, znn, zm, zr, t);
-        mpz_to_limbs((i < (int64_t)EF ? c1 : c2) + row * 2 * kw, 2 * kw, zc);
-      }
-      mpz_clears(zn, znn, zm, zr, zc, t, NULL);
-    }
     mpz_t zn, x, r, third, two_thirds, t, u, wv, rv;
     mpz_inits(zn, x, r, third, two_thirds, t, u, wv, rv, NULL);
     limbs_to_mpz(zn, nl, kw);
@@ -314,72 +320,78 @@ int32_t oracle_range_ni_prove_batch(const zkp_range_ni_proofs* p, const zkp_rang
 
 int32_t oracle_range_ni_verify_batch(const zkp_range_ni_proofs* p, uint8_t* out_verdict) {
   const size_t kw = p->n_bits / 32, EF = p->error_factor;
-  for (uint64_t b = 0; b < p->batch; b++) {
-    const uint32_t* nl = p->n + b * p->n_stride;
-    const uint32_t* c1 = p->c1 + b * EF * 2 * kw;
-    const uint32_t* c2 = p->c2 + b * EF * 2 * kw;
-    mpz_t zn, znn, cx, third, two_thirds, t;
-    mpz_inits(zn, znn, cx, third, two_thirds, t, NULL);
-    limbs_to_mpz(zn, nl, kw);
-    mpz_mul(znn, zn, zn);
-    limbs_to_mpz(cx, p->ciphertext + b * 2 * kw, 2 * kw);
-    limbs_to_mpz(t, p->range + b * kw, kw);
-    mpz_fdiv_q_ui(third, t, 3);       /* range_proof.rs:264 */
-    mpz_mul_ui(two_thirds, third, 2); /* :265 */
-    uint8_t e[32];
-    uint32_t elen = fs_challenge(zn, c1, c2, (uint32_t)EF, kw, e); /* range_proof_ni.rs:89-92 */
-    if ((size_t)elen * 8 < EF) { /* bits_of_e[i] index panic */
-      out_verdict[b] = ZKP_VERDICT_MALFORMED;
-      mpz_clears(zn, znn, cx, third, two_thirds, t, NULL);
-      continue;
-    }
-    int all_ok = 1;
-    /* range_proof.rs:270-348: every row is evaluated, no early exit */
-#pragma omp parallel num_threads(n_threads)
-    {
-      mpz_t w1, r1, w2, r2, c, ex, u;
-      mpz_inits(w1, r1, w2, r2, c, ex, u, NULL);
-      int ok_local = 1;
-#pragma omp for schedule(dynamic, 1)
-      for (int64_t i = 0; i < (int64_t)EF; i++) {
-        size_t o = b * EF + (size_t)i;
-        int ei = challenge_bit(e, (uint32_t)i);
-        int res = 1;
-        limbs_to_mpz(w1, p->resp_w1 + o * kw, kw);
-        limbs_to_mpz(r1, p->resp_r1 + o * kw, kw);
-        if (!ei && p->resp_kind[o] == ZKP_RESP_OPEN) { /* :277-313 */
-          limbs_to_mpz(w2, p->resp_w2 + o * kw, kw);
-          limbs_to_mpz(r2, p->resp_r2 + o * kw, kw);
-          enc_mpz(c, zn, znn, w1, r1, u);
-          limbs_to_mpz(ex, c1 + (size_t)i * 2 * kw, 2 * kw);
-          if (mpz_cmp(c, ex) != 0) res = 0;
-          enc_mpz(c, zn, znn, w2, r2, u);
-          limbs_to_mpz(ex, c2 + (size_t)i * 2 * kw, 2 * kw);
-          if (mpz_cmp(c, ex) != 0) res = 0;
-          int flag = (mpz_cmp(w2, third) < 0 && mpz_cmp(w1, third) > 0 && mpz_cmp(w1, two_thirds) < 0) ||
-                     (mpz_cmp(w1, third) < 0 && mpz_cmp(w2, third) > 0 && mpz_cmp(w2, two_thirds) < 0); /* :300-305 */
-          if (!flag) res = 0;
-        } else if (ei && p->resp_kind[o] == ZKP_RESP_MASK) { /* :315-343 */
-          limbs_to_mpz(ex, (p->resp_j[o] == 1 ? c1 : c2) + (size_t)i * 2 * kw, 2 * kw); /* any j != 1 selects c2 :324-328 */
-          mpz_mul(ex, ex, cx);
-          mpz_tdiv_r(ex, ex, znn);
-          enc_mpz(c, zn, znn, w1, r1, u); /* Enc(masked_x, masked_r) :330-334 */
-          if (mpz_cmp(c, ex) != 0) res = 0;
-          if (mpz_cmp(w1, third) < 0 || mpz_cmp(w1, two_thirds) > 0) res = 0; /* :338 */
-        } else {
-          res = 0; /* :345 */
-        }
-        if (!res) ok_local = 0;
-      }
-      if (!ok_local) {
-#pragma omp atomic write
-        all_ok = 0;
-      }
-      mpz_clears(w1, r1, w2, r2, c, ex, u, NULL);
-    }
-    out_verdict[b] = all_ok ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
-    mpz_clears(zn, znn, cx, third, two_thirds, t, NULL);
+  const int64_t B = (int64_t)p->batch;
+  uint8_t* e_all = (uint8_t*)calloc((size_t)B + 1, 32);
+  /* phase 1: Fiat-Shamir challenge per proof (range_proof_ni.rs:89-92) */
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int64_t b = 0; b < B; b++) {
+    mpz_t zn;
+    mpz_init(zn);
+    limbs_to_mpz(zn, p->n + b * p->n_stride, kw);
+    uint32_t elen = fs_challenge(zn, p->c1 + b * EF * 2 * kw, p->c2 + b * EF * 2 * kw, (uint32_t)EF, kw, e_all + b * 32);
+    /* bits_of_e[i] index panic when the challenge is shorter than error_factor bits */
+    out_verdict[b] = ((size_t)elen * 8 < EF) ? ZKP_VERDICT_MALFORMED : ZKP_VERDICT_ACCEPT;
+    mpz_clear(zn);
   }
+  /* phase 2: range_proof.rs:270-348 — every row of every proof is evaluated (no early exit); rows are
+   * independent, so the pool runs over the flattened (proof,row) list (the reference's rayon par_iter runs
+   * over the rows of one proof; a caller with many proofs would parallelise over proofs as well) */
+#pragma omp parallel num_threads(n_threads)
+  {
+    mpz_t zn, znn, cx, third, two_thirds, t, w1, r1, w2, r2, c, ex, u;
+    mpz_inits(zn, znn, cx, third, two_thirds, t, w1, r1, w2, r2, c, ex, u, NULL);
+    int64_t cur = -1;
+#pragma omp for schedule(dynamic, 8)
+    for (int64_t row = 0; row < B * (int64_t)EF; row++) {
+      const int64_t b = row / (int64_t)EF;
+      const size_t i = (size_t)(row % (int64_t)EF);
+      if (out_verdict[b] == ZKP_VERDICT_MALFORMED) continue;
+      if (b != cur) {
+        cur = b;
+        limbs_to_mpz(zn, p->n + b * p->n_stride, kw);
+        mpz_mul(znn, zn, zn);
+        limbs_to_mpz(cx, p->ciphertext + b * 2 * kw, 2 * kw);
+        limbs_to_mpz(t, p->range + b * kw, kw);
+        mpz_fdiv_q_ui(third, t, 3);       /* range_proof.rs:264 */
+        mpz_mul_ui(two_thirds, third, 2); /* :265 */
+      }
+      const uint32_t* c1 = p->c1 + b * EF * 2 * kw;
+      const uint32_t* c2 = p->c2 + b * EF * 2 * kw;
+      const size_t o = (size_t)row;
+      int ei = challenge_bit(e_all + b * 32, (uint32_t)i);
+      int res = 1;
+      limbs_to_mpz(w1, p->resp_w1 + o * kw, kw);
+      limbs_to_mpz(r1, p->resp_r1 + o * kw, kw);
+      if (!ei && p->resp_kind[o] == ZKP_RESP_OPEN) { /* :277-313 */
+        limbs_to_mpz(w2, p->resp_w2 + o * kw, kw);
+        limbs_to_mpz(r2, p->resp_r2 + o * kw, kw);
+        enc_mpz(c, zn, znn, w1, r1, u);
+        limbs_to_mpz(ex, c1 + i * 2 * kw, 2 * kw);
+        if (mpz_cmp(c, ex) != 0) res = 0;
+        enc_mpz(c, zn, znn, w2, r2, u);
+        limbs_to_mpz(ex, c2 + i * 2 * kw, 2 * kw);
+        if (mpz_cmp(c, ex) != 0) res = 0;
+        int flag = (mpz_cmp(w2, third) < 0 && mpz_cmp(w1, third) > 0 && mpz_cmp(w1, two_thirds) < 0) ||
+                   (mpz_cmp(w1, third) < 0 && mpz_cmp(w2, third) > 0 && mpz_cmp(w2, two_thirds) < 0); /* :300-305 */
+        if (!flag) res = 0;
+      } else if (ei && p->resp_kind[o] == ZKP_RESP_MASK) { /* :315-343 */
+        limbs_to_mpz(ex, (p->resp_j[o] == 1 ? c1 : c2) + i * 2 * kw, 2 * kw); /* any j != 1 selects c2 :324-328 */
+        mpz_mul(ex, ex, cx);
+        mpz_tdiv_r(ex, ex, znn);
+        enc_mpz(c, zn, znn, w1, r1, u); /* Enc(masked_x, masked_r) :330-334 */
+        if (mpz_cmp(c, ex) != 0) res = 0;
+        if (mpz_cmp(w1, third) < 0 || mpz_cmp(w1, two_thirds) > 0) res = 0; /* :338 */
+      } else {
+        res = 0; /* :345 */
+      }
+      if (!res) {
+#pragma omp atomic write
+        out_verdict[b] = ZKP_VERDICT_REJECT;
+      }
+    }
+    mpz_clears(zn, znn, cx, third, two_thirds, t, w1, r1, w2, r2, c, ex, u, NULL);
+  }
+  free(e_all);
   return 0;
 }
 
