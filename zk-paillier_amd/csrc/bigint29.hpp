@@ -6,20 +6,17 @@
 //     too, so a full-radix 2^32 multiply-accumulate with explicit carries is ~2x slower than
 //     a carry-free one.  With 29-bit limbs a 64-bit column accumulator absorbs 64 products
 //     before it can overflow, so the inner loops are pure v_mad_u64_u32 chains.
-//   * one big integer is spread over a group of G lanes of a wavefront, W = 9 limbs per lane:
-//       G = 8  -> 72 limbs  = 2088 bits (moduli up to 2048 bits: n, N of the DLog proof)
-//       G = 16 -> 144 limbs = 4176 bits (moduli up to 4096 bits: n^2 for a 2048-bit n)
-//       G = 32 -> 288 limbs = 8352 bits (moduli up to 8192 bits: n^2 for a 4096-bit n)
-//     so a 64-lane wavefront works on 8 / 4 / 2 independent modular exponentiations.
+//   * one big integer is spread over a group of G lanes of a wavefront, W limbs per lane
+//     (W = 9 or 18, compile-time ZKP_W); G*W = 72 limbs = 2088 bits (moduli up to 2048 bits:
+//     n, N of the DLog proof), 144 limbs = 4176 bits (n^2 for a 2048-bit n), 288 limbs =
+//     8352 bits (n^2 for a 4096-bit n); a 64-lane wavefront works on 64/G independent
+//     modular exponentiations.
 //   * Montgomery radix R = 2^(29*G*W) exceeds the modulus by >= 40 bits, hence every
 //     Montgomery product of operands < 2M is again < 2M and no conditional subtraction is
 //     needed inside an exponentiation (one exact canonicalisation at the very end).
 //
-// Montgomery multiplication is a block-CIOS with block radix beta = 2^(29*9): in step s
-// every lane multiplies its block A_j by block B_s (broadcast from LDS) and its modulus
-// block N_j by the quotient block q_s (computed from lane 0's low block, broadcast with
-// ds_swizzle); the low block of each lane's window is then handed to lane j-1 (DPP), so the
-// partial sum for one output position travels down the lanes while it is completed.
+// Montgomery multiplication is a word-level CIOS on a systolic lane array (see montmul below):
+// the partial sum for one output position travels down the lanes while it is completed.
 //
 // This file replaces what the reference reaches through curv::BigInt -> GMP
 // (mpz_powm / mpz_mul / mpz_tdiv_r); see include/zkp_hip.h for the call sites.
@@ -29,10 +26,14 @@
 
 namespace zkp {
 
+#ifndef ZKP_W
+#define ZKP_W 9
+#endif
 constexpr int LB = 29;                      // bits per limb
-constexpr int W = 9;                        // limbs per lane
+constexpr int W = ZKP_W;                    // limbs per lane (9 or 18)
 constexpr uint32_t LMASK = (1u << LB) - 1;
-constexpr int BLK = 12;                     // LDS words per 9-limb block (48 B: keeps ds_read_b128 aligned)
+constexpr int BLK = (W + 3) & ~3;           // LDS words per W-limb block (16-B multiple: keeps ds_read_b128 aligned)
+static_assert(W == 9 || W == 18, "limbs per lane");
 
 template <int G> struct Geo {
   static constexpr int L = G * W;           // 29-bit limbs per integer
@@ -44,17 +45,18 @@ template <int G> struct Geo {
 // value held by lane 0 of the group -> every lane of the group (ds_swizzle, bit-mask mode:
 // lane' = lane & and_mask inside each 32-lane half)
 template <int G> __device__ __forceinline__ uint32_t bcast0(uint32_t v) {
-  static_assert(G == 8 || G == 16 || G == 32, "group size");
+  static_assert(G == 4 || G == 8 || G == 16 || G == 32, "group size");
   if constexpr (G == 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0000);
   else if constexpr (G == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0010);
-  else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0018);
+  else if constexpr (G == 8) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0018);
+  else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x001C);
 }
 
 // lane j receives the value of lane j+1 of its group; the top lane receives 0
 template <int G> __device__ __forceinline__ uint32_t from_next(uint32_t v, int gl) {
   if constexpr (G == 16) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
-  } else if constexpr (G == 8) {
+  } else if constexpr (G == 8 || G == 4) {
     uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);
     return gl == G - 1 ? 0u : t;
   } else {
@@ -67,7 +69,7 @@ template <int G> __device__ __forceinline__ uint32_t from_next(uint32_t v, int g
 template <int G> __device__ __forceinline__ uint32_t from_prev(uint32_t v, int gl) {
   if constexpr (G == 16) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
-  } else if constexpr (G == 8) {
+  } else if constexpr (G == 8 || G == 4) {
     uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
     return gl == 0 ? 0u : t;
   } else {
@@ -83,105 +85,78 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// ---------------------------------------------------------------- block load/store (9 limbs)
+// ---------------------------------------------------------------- block load/store (W limbs)
 __device__ __forceinline__ void lds_load_block(uint32_t (&v)[W], const uint32_t* p) {
-  const uint4 a = *reinterpret_cast<const uint4*>(p);
-  const uint4 b = *reinterpret_cast<const uint4*>(p + 4);
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; v[8] = p[8];
+#pragma unroll
+  for (int i = 0; i + 4 <= W; i += 4) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p + i);
+    v[i] = a.x; v[i + 1] = a.y; v[i + 2] = a.z; v[i + 3] = a.w;
+  }
+  if constexpr (W % 4 == 1) {
+    v[W - 1] = p[W - 1];
+  } else if constexpr (W % 4 == 2) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p + W - 2);
+    v[W - 2] = a.x; v[W - 1] = a.y;
+  }
 }
 __device__ __forceinline__ void lds_store_block(uint32_t* p, const uint32_t (&v)[W]) {
-  *reinterpret_cast<uint4*>(p) = make_uint4(v[0], v[1], v[2], v[3]);
-  *reinterpret_cast<uint4*>(p + 4) = make_uint4(v[4], v[5], v[6], v[7]);
-  p[8] = v[8];
+#pragma unroll
+  for (int i = 0; i + 4 <= W; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  if constexpr (W % 4 == 1) {
+    p[W - 1] = v[W - 1];
+  } else if constexpr (W % 4 == 2) {
+    *reinterpret_cast<uint2*>(p + W - 2) = make_uint2(v[W - 2], v[W - 1]);
+  }
 }
 
 // ---------------------------------------------------------------- Montgomery multiplication
-// R = A * B / 2^(29*G*W) mod M, with A in registers (block gl of A), B staged in LDS as G
-// blocks of BLK words, N = block gl of the modulus, NI = -M^-1 mod 2^261 (same on every lane).
+// R = A * B / 2^(29*G*W) mod M.  A: this lane's block of A (registers); B: staged in LDS as G
+// blocks of BLK words; N: this lane's block of the modulus; n1 = -M^-1 mod 2^29.
 // Operand limbs may be "almost normalised" (< 2^29 + 2^8); operand values < 2M.
-// Result: limbs 1..8 < 2^29, limb 0 < 2^29 + 16; value < 2M.
+// Result: limbs 1.. < 2^29, limb 0 < 2^29 + 16; value < 2M (<= M when B == 1).
+//
+// Word-level CIOS over a sliding window of W 64-bit column accumulators per lane.  Sub-step
+// (s,t) handles limb b = B[s*W+t]: every lane adds A_j*b to its W columns, lane 0's bottom
+// column fixes the quotient digit q = (c0 * n1) mod 2^29 (one ds_swizzle broadcast), every
+// lane adds N_j*q, then the bottom column is finished: its low 29 bits go to lane j-1 (one DPP
+// move) where they open a fresh top column, its high bits carry into the next column.  Only
+// ONE column is normalised per sub-step and no carry flag is ever used: 2W v_mad_u64_u32 per
+// ~9 other VALU instructions.  The window is a circular register file: after W sub-steps
+// (fully unrolled) the register assignment repeats, so the loop over blocks stays rolled.
 template <int G>
 __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W], const uint32_t* ldsB,
-                                        const uint32_t (&N)[W], const uint32_t (&NI)[W], int gl) {
-  uint64_t acc[2 * W];
+                                        const uint32_t (&N)[W], uint32_t n1, int gl) {
+  uint64_t c[W];
 #pragma unroll
-  for (int k = 0; k < 2 * W; k++) acc[k] = 0;
+  for (int k = 0; k < W; k++) c[k] = 0;
 
 #pragma unroll 1
   for (int s = 0; s < G; s++) {
     uint32_t Bs[W];
     lds_load_block(Bs, ldsB + s * BLK);
-    // acc += A_j * B_s : 81 carry-free v_mad_u64_u32
 #pragma unroll
-    for (int i = 0; i < W; i++)
+    for (int t = 0; t < W; t++) {
+      const uint32_t b = Bs[t];
 #pragma unroll
-      for (int k = 0; k < W; k++) acc[i + k] += (uint64_t)A[i] * Bs[k];
-
-    // exact carry chain through the low block
-    uint32_t lo[W];
-    uint64_t c = 0;
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)A[k] * b;
+      const uint32_t q = bcast0<G>(((uint32_t)c[t] * n1) & LMASK);
 #pragma unroll
-    for (int k = 0; k < W; k++) {
-      uint64_t t = acc[k] + c;
-      lo[k] = (uint32_t)t & LMASK;
-      c = t >> LB;
-    }
-    acc[W] += c;
-
-    // q = lo * NI mod beta (only the value computed by lane 0 of the group is used)
-    uint64_t qc[W];
-#pragma unroll
-    for (int k = 0; k < W; k++) qc[k] = 0;
-#pragma unroll
-    for (int i = 0; i < W; i++)
-#pragma unroll
-      for (int k = 0; k + i < W; k++) qc[i + k] += (uint64_t)lo[i] * NI[k];
-    uint32_t q[W];
-    c = 0;
-#pragma unroll
-    for (int k = 0; k < W; k++) {
-      uint64_t t = qc[k] + c;
-      q[k] = (uint32_t)t & LMASK;
-      c = t >> LB;
-    }
-#pragma unroll
-    for (int k = 0; k < W; k++) q[k] = bcast0<G>(q[k]);
-
-    // acc += N_j * q
-#pragma unroll
-    for (int k = 0; k < W; k++) acc[k] = lo[k];
-#pragma unroll
-    for (int i = 0; i < W; i++)
-#pragma unroll
-      for (int k = 0; k < W; k++) acc[i + k] += (uint64_t)N[i] * q[k];
-
-    // exact chain again: on lane 0 the low block is now zero, on lane j>0 it is the finished
-    // contribution of this lane to output position j+s and goes to lane j-1
-    uint32_t l2[W];
-    c = 0;
-#pragma unroll
-    for (int k = 0; k < W; k++) {
-      uint64_t t = acc[k] + c;
-      l2[k] = (uint32_t)t & LMASK;
-      c = t >> LB;
-    }
-    acc[W] += c;
-#pragma unroll
-    for (int k = 0; k < W; k++) {
-      acc[k] = acc[W + k] + (uint64_t)from_next<G>(l2[k], gl);
-      acc[W + k] = 0;
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q;
+      const uint64_t v = c[t];
+      c[(t + 1) % W] += v >> LB;
+      c[t] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
     }
   }
 
   // lane-local exact chain; the (tiny) carry out of each block lands on limb 0 of the next lane
-  uint64_t c = 0;
+  uint64_t cy = 0;
 #pragma unroll
   for (int k = 0; k < W; k++) {
-    uint64_t t = acc[k] + c;
+    const uint64_t t = c[k] + cy;
     R[k] = (uint32_t)t & LMASK;
-    c = t >> LB;
+    cy = t >> LB;
   }
-  R[0] += from_prev<G>((uint32_t)c, gl);
+  R[0] += from_prev<G>((uint32_t)cy, gl);
 }
 
 // ---------------------------------------------------------------- representation changes

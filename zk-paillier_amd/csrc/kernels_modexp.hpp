@@ -15,14 +15,14 @@ constexpr int TAB = 1 << WIN;
 //   N29[L] | R2[L] | R1[L] | NR[L] | NI[BLK] | status[4]
 template <int G> struct ConstLayout {
   static constexpr int L = Geo<G>::L;
-  static constexpr int OFF_N = 0, OFF_R2 = L, OFF_R1 = 2 * L, OFF_NR = 3 * L, OFF_NI = 4 * L, OFF_ST = 4 * L + BLK;
-  static constexpr int WORDS = 4 * L + BLK + 4;
+  static constexpr int OFF_N = 0, OFF_R2 = L, OFF_R1 = 2 * L, OFF_NR = 3 * L, OFF_NI = 4 * L, OFF_ST = 4 * L + 12;
+  static constexpr int WORDS = 4 * L + 12 + 4;
 };
 
 // ---- per-group LDS carve-up (uint32 words)
 template <int G> struct LdsLayout {
   static constexpr int L = Geo<G>::L;
-  static constexpr int NW = G * 8;                       // 32-bit words of the modulus width (2048/4096/8192 bits)
+  static constexpr int NW = (L / 72) * 64;               // 32-bit words of the modulus width (2048/4096/8192 bits)
   static constexpr int OFF_B = 0;                        // B operand blocks           [G*BLK]
   static constexpr int OFF_WORDS = OFF_B + G * BLK;       // 32-bit word staging        [NW+8]
   static constexpr int OFF_SCR = OFF_WORDS + NW + 8;      // 29-bit limb scratch        [L+8]
@@ -33,7 +33,8 @@ template <int G> struct LdsLayout {
 };
 
 template <int G> struct Grp {
-  uint32_t N[W], NI[W];
+  uint32_t N[W];
+  uint32_t n1;       // -M^-1 mod 2^29
   int gl;            // lane inside the group
   uint32_t* lds;     // group's LDS base
   __device__ __forceinline__ uint32_t* B() const { return lds + LdsLayout<G>::OFF_B; }
@@ -62,8 +63,7 @@ template <int G> __device__ __forceinline__ void store_limbs_global(uint32_t* p,
 template <int G> __device__ __forceinline__ void load_modulus_consts(Grp<G>& g, const uint32_t* cst) {
   using CL = ConstLayout<G>;
   load_limbs_global<G>(g.N, cst + CL::OFF_N, g.gl);
-#pragma unroll
-  for (int k = 0; k < W; k++) g.NI[k] = cst[CL::OFF_NI + k];
+  g.n1 = cst[CL::OFF_NI];
 }
 
 // stage the B operand (this lane's block) into LDS
@@ -74,7 +74,7 @@ template <int G> __device__ __forceinline__ void stageB(const Grp<G>& g, const u
 }
 
 template <int G> __device__ __forceinline__ void mm(const Grp<G>& g, uint32_t (&R)[W], const uint32_t (&A)[W]) {
-  montmul<G>(R, A, g.B(), g.N, g.NI, g.gl);
+  montmul<G>(R, A, g.B(), g.N, g.n1, g.gl);
 }
 
 // cooperative copy of `nwords` 32-bit words global -> LDS words area, zero padded to NW+8
@@ -250,32 +250,13 @@ __global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src,
   limbs_from_words(g.N, mw, g.gl);
   limbs_from_words(R1, sw, g.gl);
   limbs_from_words(M2, rw, g.gl);
-  // NI = -M^-1 mod 2^261: every lane derives it redundantly from the low 9 limbs of M
+  // n1 = -M^-1 mod 2^29 (Newton on the low word; every lane computes it redundantly)
   {
-    uint32_t Ml[W];
+    const uint32_t m0 = mw[0];
+    uint32_t y = m0;                          // inverse of M mod 2^3 (odd M)
 #pragma unroll
-    for (int k = 0; k < W; k++) {
-      const int bit = k * LB;
-      const int w0 = bit >> 5, off = bit & 31;
-      const uint64_t x = (uint64_t)mw[w0] | ((uint64_t)mw[w0 + 1] << 32);
-      Ml[k] = (uint32_t)(x >> off) & LMASK;
-    }
-    uint32_t y = Ml[0];                       // inverse of M mod 2^3 (odd M)
-#pragma unroll
-    for (int it = 0; it < 5; it++) y *= 2u - Ml[0] * y;   // Newton: 3 -> 6 -> 12 -> 24 -> 48 -> 96 bits
-    const uint32_t m0inv = (0u - y) & LMASK;  // -M^-1 mod 2^29
-    uint64_t T[W];
-#pragma unroll
-    for (int k = 0; k < W; k++) T[k] = 0;
-    T[0] = 1;
-#pragma unroll
-    for (int i = 0; i < W; i++) {
-      const uint32_t u = (((uint32_t)T[i] & LMASK) * m0inv) & LMASK;
-      g.NI[i] = u;
-#pragma unroll
-      for (int k = 0; k + i < W; k++) T[i + k] += (uint64_t)u * Ml[k];
-      if (i + 1 < W) T[i + 1] += T[i] >> LB;
-    }
+    for (int it = 0; it < 5; it++) y *= 2u - m0 * y;   // 3 -> 6 -> 12 -> 24 -> 48 -> 96 bits
+    g.n1 = (0u - y) & LMASK;
   }
   // R2 = (2R)^(CAP) * R^-(CAP-1) = 2^CAP * R = R^2 (mod M): square-and-multiply in the Montgomery domain
   uint32_t X[W], R[W];
@@ -311,8 +292,7 @@ __global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src,
     store_limbs_global<G>(cst + CL::OFF_R1, R1, g.gl);
     store_limbs_global<G>(cst + CL::OFF_NR, NR, g.gl);
     if (g.gl == 0) {
-#pragma unroll
-      for (int k = 0; k < W; k++) cst[CL::OFF_NI + k] = g.NI[k];
+      cst[CL::OFF_NI] = g.n1;
       cst[CL::OFF_ST] = (uint32_t)status;
     }
   }

@@ -110,7 +110,9 @@ struct TimedRegion {
 };
 
 // ---- geometry helpers -----------------------------------------------------------------------
-static int group_for_bits(uint32_t mod_bits) { return mod_bits <= 2048 ? 8 : mod_bits <= 4096 ? 16 : mod_bits <= 8192 ? 32 : 0; }
+// lanes per big integer: 72 / 144 / 288 limbs of 29 bits over W limbs per lane
+constexpr int GA = 72 / W, GB = 144 / W, GC = 288 / W;
+static int group_for_bits(uint32_t mod_bits) { return mod_bits <= 2048 ? GA : mod_bits <= 4096 ? GB : mod_bits <= 8192 ? GC : 0; }
 
 template <int G, class K> static int resident_blocks(zkp_ctx* c, K kernel) {
   int per_cu = 0;
@@ -253,9 +255,9 @@ extern "C" int32_t zkp_modexp_batch(zkp_ctx* c, uint32_t mod_bits, uint32_t exp_
   int32_t st = s.st;
   if (!st) {
     switch (group_for_bits(mod_bits)) {
-      case 8: st = modexp_impl<8>(c, exp_bits, count, dbase, dexp, exp_stride, dmod, mod_stride, dout); break;
-      case 16: st = modexp_impl<16>(c, exp_bits, count, dbase, dexp, exp_stride, dmod, mod_stride, dout); break;
-      default: st = modexp_impl<32>(c, exp_bits, count, dbase, dexp, exp_stride, dmod, mod_stride, dout); break;
+      case GA: st = modexp_impl<GA>(c, exp_bits, count, dbase, dexp, exp_stride, dmod, mod_stride, dout); break;
+      case GB: st = modexp_impl<GB>(c, exp_bits, count, dbase, dexp, exp_stride, dmod, mod_stride, dout); break;
+      default: st = modexp_impl<GC>(c, exp_bits, count, dbase, dexp, exp_stride, dmod, mod_stride, dout); break;
     }
   }
   const int32_t fin = s.finish();
@@ -294,9 +296,9 @@ extern "C" int32_t zkp_modmul_batch(zkp_ctx* c, uint32_t mod_bits, uint64_t coun
   int32_t st = s.st;
   if (!st) {
     switch (group_for_bits(mod_bits)) {
-      case 8: st = modmul_impl<8>(c, count, da, db, dm, mod_stride, dout); break;
-      case 16: st = modmul_impl<16>(c, count, da, db, dm, mod_stride, dout); break;
-      default: st = modmul_impl<32>(c, count, da, db, dm, mod_stride, dout); break;
+      case GA: st = modmul_impl<GA>(c, count, da, db, dm, mod_stride, dout); break;
+      case GB: st = modmul_impl<GB>(c, count, da, db, dm, mod_stride, dout); break;
+      default: st = modmul_impl<GC>(c, count, da, db, dm, mod_stride, dout); break;
     }
   }
   const int32_t fin = s.finish();
@@ -346,9 +348,9 @@ extern "C" int32_t zkp_paillier_enc_batch(zkp_ctx* c, uint32_t n_bits, uint64_t 
   int32_t st = s.st;
   if (!st) {
     switch (group_for_bits(2 * n_bits)) {
-      case 8: st = enc_impl<8>(c, n_bits, count, dn, n_stride, dm, dr, dout); break;
-      case 16: st = enc_impl<16>(c, n_bits, count, dn, n_stride, dm, dr, dout); break;
-      default: st = enc_impl<32>(c, n_bits, count, dn, n_stride, dm, dr, dout); break;
+      case GA: st = enc_impl<GA>(c, n_bits, count, dn, n_stride, dm, dr, dout); break;
+      case GB: st = enc_impl<GB>(c, n_bits, count, dn, n_stride, dm, dr, dout); break;
+      default: st = enc_impl<GC>(c, n_bits, count, dn, n_stride, dm, dr, dout); break;
     }
   }
   const int32_t fin = s.finish();

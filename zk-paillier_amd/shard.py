@@ -1,0 +1,39 @@
+"""Multi-GPU plumbing: proofs are independent units, so a batch is cut into
+contiguous blocks of proof indices, one block per rank/GPU; no collective on the data path.
+The only exchange step is ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests)
+that reassembles per-rank output slabs (verdict bytes; ciphertext slabs of a prove batch)."""
+
+
+def shard_range(total: int, world: int, rank: int):
+    """contiguous, balanced block of [0, total) owned by `rank` (first total % world ranks get one more)"""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_slabs(local, world: int, counts=None):
+    """all-gather equally sized slabs along dim 0 -> tensor [world * local.shape[0], ...].
+    With `counts` (rows per rank, unequal) slabs are padded to max(counts) and trimmed after the gather."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local
+    if counts is None:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    m = max(counts)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * m: r * m + counts[r]] for r in range(world)], dim=0)
+
+
+def sharded_verify(verify_fn, batch_total: int, world: int, rank: int, make_local):
+    """Run `verify_fn(local_batch) -> uint8 tensor[local]` on this rank's block and all-gather the verdicts.
+    make_local(lo, hi) builds the rank-local batch view."""
+    lo, hi = shard_range(batch_total, world, rank)
+    local = verify_fn(make_local(lo, hi))
+    counts = [shard_range(batch_total, world, r)[1] - shard_range(batch_total, world, r)[0] for r in range(world)]
+    return all_gather_slabs(local, world, counts if len(set(counts)) > 1 else None)
