@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Mint the golden vectors under tests/golden/ (run from the repo root: python tests/golden/make_golden.py).
+
+The reference (Rust) cannot be executed in this image and holds no known-answer vectors of its own
+(SURVEY.md §4, §8(c)), so these vectors are minted from the repo's two independent restatements:
+every value written here is computed by the C/GMP oracle AND, where a pure-Python computation is
+affordable, asserted equal to oracle/py_model.py before it is written.  Inputs come from the repo's
+SHA-256 counter DRBG (oracle/py_model.Drbg) or are listed literally; big outputs are stored as SHA-256
+digests of their little-endian limb bytes."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import helpers as H  # noqa: E402
+from helpers import pm, L, zkp  # noqa: E402
+import oracle_lib  # noqa: E402
+
+oracle = oracle_lib.Oracle()
+oracle.set_threads(oracle.max_threads())
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def hx(v):
+    return format(v, "x")
+
+
+def modexp_kats():
+    out = []
+    for bits in (2048, 4096, 8192):
+        d = pm.Drbg(b"golden-modexp-%d" % bits)
+        nl = bits // 32
+        cases = []
+        m_rand = d.bits(bits) | 1 | (1 << (bits - 1))
+        cases.append((d.below(m_rand), d.bits(bits), m_rand))                                  # generic
+        cases.append((d.bits(bits), (1 << bits) - 1, (1 << bits) - 1))                          # all-ones modulus/exponent, base >= modulus
+        cases.append((d.below(m_rand), 1 << (bits - 1), (1 << (bits - 1)) + 1))                 # top limb 0x80000000, long zero runs
+        cases.append((0, d.bits(bits), m_rand))                                                 # base 0
+        cases.append((m_rand - 1, d.bits(bits) | 1, m_rand))                                    # base M-1, odd exponent -> M-1
+        cases.append((d.below(m_rand), 0, m_rand))                                              # exponent 0 -> 1
+        b, e, m = (L.ints_to_limbs([c[i] for c in cases], nl) for i in range(3))
+        res = L.limbs_to_ints(oracle.modexp(bits, bits, b, e, nl, m, nl))
+        for (bb, ee, mm), r in zip(cases, res):
+            if bits <= 4096:
+                assert r == pow(bb, ee, mm)
+            out.append(dict(bits=bits, base=hx(bb), exp=hx(ee), mod=hx(mm), out=hx(r)))
+    return out
+
+
+def enc_kats():
+    _, _, n = H.fixture_key()
+    d = pm.Drbg(b"golden-enc")
+    ms = [0, 1, d.bits(256), n - 1, (1 << 2048) - 1]
+    rs = [d.below(n), d.below(n), d.below(n), 1, d.bits(2048)]
+    res = L.limbs_to_ints(oracle.paillier_enc(2048, L.ints_to_limbs([n], 64), 0, L.ints_to_limbs(ms, 64), L.ints_to_limbs(rs, 64)))
+    for m, r, c in zip(ms, rs, res):
+        assert c == pm.enc(n, m, r)
+    return dict(n=hx(n), items=[dict(m=hx(m), r=hx(r), c=hx(c)) for m, r, c in zip(ms, rs, res)])
+
+
+def digest_kats():
+    """compute_digest (utils.rs:9-22): minimal big-endian bytes, zero -> 00, no separators"""
+    d = pm.Drbg(b"golden-digest")
+    lists = [[0], [0, 0, 1], [d.bits(2048), 0x00ff, d.bits(4096)], [d.bits(4088), 1 << 4095], [256, 255, 65536]]
+    out = []
+    for it in lists:
+        out.append(dict(items=[hx(v) for v in it], digest=hx(pm.compute_digest(it))))
+    # Fiat-Shamir challenge with a leading zero digest byte (N2)
+    n = H.test_key(512)[2]
+    ef = 2
+    while True:
+        c1 = [d.bits(64) for _ in range(ef)]; c2 = [d.bits(64) for _ in range(ef)]
+        if hashlib.sha256(b"".join(pm.to_bytes(v) for v in [n] + c1 + c2)).digest()[0] == 0:
+            break
+    e = pm.fs_challenge(n, c1, c2)
+    assert e == oracle.fs_challenge(1024, ef, L.int_to_limbs(n, 32), L.ints_to_limbs(c1, 64), L.ints_to_limbs(c2, 64)) and len(e) < 32
+    return dict(compute_digest=out, leading_zero_challenge=dict(n=hx(n), c1=[hx(v) for v in c1], c2=[hx(v) for v in c2], e=e.hex()))
+
+
+def range_transcripts():
+    _, _, n = H.fixture_key()
+    out = []
+    for seed, honest in ((b"golden-range-1", True), (b"golden-range-2", True), (b"golden-range-bad", False)):
+        cases = H.build_range_case(seed, [n], 2048, 1, honest=honest)
+        pb, wt = H.fill_batch(cases, 2048, True, oracle)
+        e = np.zeros((1, 32), np.uint8); elen = np.zeros(1, np.uint8); st = np.zeros(1, np.uint8)
+        oracle.range_ni_prove(pb.struct(), wt.struct(), e, elen, st)
+        v = np.zeros(1, np.uint8)
+        oracle.range_ni_verify(pb.struct(), v)
+        # spot check of the first rows against the pure-Python model
+        c = cases[0]
+        assert L.limbs_to_int(pb.c1[0, 0]) == pm.enc(n, c["w1"][0], c["r1"][0])
+        assert L.limbs_to_int(pb.c2[0, 127]) == pm.enc(n, c["w2"][127], c["r2"][127])
+        assert bytes(e[0, :elen[0]]) == pm.fs_challenge(n, L.limbs_to_ints(pb.c1[0]), L.limbs_to_ints(pb.c2[0]))
+        resp = pm.generate_proof(n, c["x"], c["r"], bytes(e[0, :elen[0]]), c["range"], c["w1"], c["w2"], c["r1"], c["r2"], 128)
+        assert resp == H.responses_from_batch(pb, 0)
+        out.append(dict(seed=seed.decode(), honest=honest, n_bits=2048, range=hx(c["range"]), x=hx(c["x"]), r=hx(c["r"]),
+                        ciphertext=hx(L.limbs_to_int(pb.ciphertext[0])), e=bytes(e[0, :elen[0]]).hex(),
+                        sha_c1=sha(pb.c1), sha_c2=sha(pb.c2), sha_resp_kind=sha(pb.resp_kind), sha_resp_j=sha(pb.resp_j),
+                        sha_resp_w1=sha(pb.resp_w1), sha_resp_r1=sha(pb.resp_r1), sha_resp_w2=sha(pb.resp_w2), sha_resp_r2=sha(pb.resp_r2),
+                        verdict=int(v[0])))
+    return out
+
+
+def correct_key():
+    p, q, n = H.fixture_key()
+    out = []
+    for salt in (pm.SALT_STRING, bytes([90, 101, 110, 32, 71, 111, 32, 88])):
+        rho = pm.correct_key_rho(n, salt)
+        assert L.limbs_to_ints(oracle.correct_key_rho(2048, L.int_to_limbs(n, 64), salt)) == rho
+        nl, sg = oracle.correct_key_ni_prove(2048, L.int_to_limbs(p, 32), L.int_to_limbs(q, 32), salt)
+        sig = L.limbs_to_ints(sg)
+        assert all(pow(s, n, n) == r for s, r in zip(sig, rho))
+        v_ok = int(oracle.correct_key_ni_verify(2048, nl[None], sg[None], salt)[0])
+        bad = sg.copy(); bad[5, 0] ^= 1
+        v_bad = int(oracle.correct_key_ni_verify(2048, nl[None], bad[None], salt)[0])
+        out.append(dict(salt=salt.hex(), n=hx(n), rho0=hx(rho[0]), sha_rho=sha(L.ints_to_limbs(rho, 64)), sigma0=hx(sig[0]), sha_sigma=sha(sg),
+                        verdict=v_ok, verdict_tampered_sigma5=v_bad))
+    return out
+
+
+def dlog():
+    p, q, N = H.test_key(2048, tag=1)
+    d = pm.Drbg(b"golden-dlog")
+    g = d.range(2, N - 1)
+    s = d.bits(256)
+    out = []
+    for name, ni in (("honest: ni = g^-s", pow(pow(g, -1, N), s, N)), ("bad: ni = g^+s", pow(g, s, N)), ("bad: random ni", d.range(2, N - 1))):
+        r = d.bits(512)
+        x, y = pm.dlog_prove(N, g, ni, s, r)
+        ox, oy = oracle.dlog_prove(2048, 768, *(L.ints_to_limbs([v], 64) for v in (N, g, ni)), L.ints_to_limbs([s], 8), L.ints_to_limbs([r], 16))
+        assert L.limbs_to_int(ox[0]) == x and L.limbs_to_int(oy[0]) == y
+        v = int(oracle.dlog_verify(2048, 768, *(L.ints_to_limbs([v], 64) for v in (N, g, ni)), ox, oy)[0])
+        assert (v == zkp.VERDICT_ACCEPT) == pm.dlog_verify(x, y, N, g, ni)
+        out.append(dict(case=name, N=hx(N), g=hx(g), ni=hx(ni), secret=hx(s), r=hx(r), x=hx(x), y=hx(y), verdict=v))
+    return out
+
+
+def main():
+    files = dict(modexp_kat=modexp_kats(), enc_kat=enc_kats(), digest_kat=digest_kats(), range_ni_transcripts=range_transcripts(),
+                 correct_key_ni=correct_key(), dlog=dlog())
+    for name, obj in files.items():
+        with open(os.path.join(HERE, name + ".json"), "w") as f:
+            json.dump(obj, f, indent=1)
+        print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()

@@ -310,6 +310,7 @@ struct ModexpArgs {
   uint32_t* table;          // [resident groups][32*L]
   uint64_t count;
   int exp_bits;
+  int io_words;             // words per base / out element (<= NW; values are zero-extended)
 };
 
 template <int G>
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(256) k_modexp(ModexpArgs a) {
     // exponent words -> LDS
     fetch_words<G>(g, g.expw(), a.exp + item * a.exp_stride, exp_words);
     // base -> Montgomery form: X = base * R2 / R
-    load_value<G>(g, T, a.base + item * NW, NW);
+    load_value<G>(g, T, a.base + item * a.io_words, a.io_words);
     load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
     stageB<G>(g, X);
     mm<G>(g, X, T);
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(256) k_modexp(ModexpArgs a) {
     mm<G>(g, R, X);
     canonical_words<G>(g, R, cst + CL::OFF_N);
     if (live && cst[CL::OFF_ST] == 0) {
-      for (int w = g.gl; w < NW; w += G) a.out[item * NW + w] = g.words()[w];
+      for (int w = g.gl; w < a.io_words; w += G) a.out[item * a.io_words + w] = g.words()[w];
     }
   }
 }
@@ -355,6 +356,7 @@ __global__ void __launch_bounds__(256) k_modexp(ModexpArgs a) {
 // Modular multiplication out = a*b mod M (same machinery, two Montgomery products)
 struct ModmulArgs {
   const uint32_t* a; const uint32_t* b; const uint32_t* consts; uint64_t const_stride; uint32_t* out; uint64_t count;
+  int io_words;
 };
 template <int G>
 __global__ void __launch_bounds__(256) k_modmul(ModmulArgs a) {
@@ -370,11 +372,11 @@ __global__ void __launch_bounds__(256) k_modmul(ModmulArgs a) {
   const uint32_t* cst = a.consts + item * a.const_stride;
   load_modulus_consts<G>(g, cst);
   uint32_t X[W], Y[W], R[W];
-  load_value<G>(g, X, a.a + item * NW, NW);
+  load_value<G>(g, X, a.a + item * a.io_words, a.io_words);
   load_limbs_global<G>(Y, cst + CL::OFF_R2, g.gl);
   stageB<G>(g, Y);
   mm<G>(g, R, X);                         // a*R
-  load_value<G>(g, Y, a.b + item * NW, NW);
+  load_value<G>(g, Y, a.b + item * a.io_words, a.io_words);
   stageB<G>(g, Y);
   mm<G>(g, X, R);                         // a*b  (< M + eps, value may equal a multiple? a*b*R/R reduced: <= M)
   // X < 2M possible when b >= M: force through montmul(.,1) after re-entering the domain is overkill;
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(256) k_modmul(ModmulArgs a) {
   mm<G>(g, X, R);
   canonical_words<G>(g, X, cst + CL::OFF_N);
   if (live && cst[CL::OFF_ST] == 0) {
-    for (int w = g.gl; w < NW; w += G) a.out[item * NW + w] = g.words()[w];
+    for (int w = g.gl; w < a.io_words; w += G) a.out[item * a.io_words + w] = g.words()[w];
   }
 }
 

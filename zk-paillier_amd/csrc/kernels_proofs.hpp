@@ -372,4 +372,118 @@ __global__ void __launch_bounds__(256) k_ck_check(CkCheckArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// CompositeDLogProof (wi_dlog_proof.rs:46-91), one thread per proof for the byte/word-level parts.
+
+// gcd(a, N) == 1 for odd N: binary GCD on kw-word integers kept in thread-interleaved global scratch
+// (word w of thread t at base[w * stride + t]: coalesced).
+__device__ bool coprime_to_odd(const uint32_t* a, const uint32_t* N, int kw, uint32_t* u, uint32_t* v, uint64_t stride) {
+  bool uz = true;
+  for (int w = 0; w < kw; w++) { const uint32_t x = a[w]; u[w * stride] = x; v[w * stride] = N[w]; uz = uz && x == 0; }
+  if (uz) {                         // gcd(0, N) = N
+    bool one = N[0] == 1;
+    for (int w = 1; w < kw; w++) one = one && N[w] == 0;
+    return one;
+  }
+  for (;;) {
+    // make u odd
+    for (;;) {
+      if (u[0] & 1) break;
+      uint32_t carry = 0;
+      for (int w = kw - 1; w >= 0; w--) { const uint32_t x = u[w * stride]; u[w * stride] = (x >> 1) | (carry << 31); carry = x & 1; }
+    }
+    // compare
+    int cmp = 0;
+    for (int w = kw - 1; w >= 0; w--) {
+      const uint32_t x = u[w * stride], y = v[w * stride];
+      if (x != y) { cmp = x > y ? 1 : -1; break; }
+    }
+    if (cmp == 0) break;            // gcd = u = v
+    if (cmp < 0) { uint32_t* t = u; u = v; v = t; }
+    uint32_t borrow = 0;            // u -= v  (both odd -> u even, non-zero)
+    for (int w = 0; w < kw; w++) {
+      const uint64_t d = (uint64_t)u[w * stride] - v[w * stride] - borrow;
+      u[w * stride] = (uint32_t)d;
+      borrow = (uint32_t)(d >> 63);
+    }
+  }
+  bool one = v[0] == 1;
+  for (int w = 1; w < kw; w++) one = one && v[w * stride] == 0;
+  return one;
+}
+
+struct DlogHashArgs {
+  const uint32_t* N; const uint32_t* g; const uint32_t* ni; const uint32_t* x;   // [B][kw]
+  uint32_t kw; uint64_t batch;
+  uint32_t* e;            // [B][8] little-endian words of e = H(x || g || N || ni)
+  // verify only
+  uint8_t* verdict;       // ACCEPT / MALFORMED to start with (nullable in prove)
+  uint32_t* gcd_scratch;  // [2][2*kw][B]
+  // prove only: y = r + e * secret  (wi_dlog_proof.rs:62)
+  const uint32_t* secret; const uint32_t* r; uint32_t* y; uint32_t yw;
+};
+
+__global__ void __launch_bounds__(256) k_dlog_hash(DlogHashArgs a) {
+  __shared__ uint32_t shabuf[16 * 256];
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.batch) return;
+  const int kw = (int)a.kw;
+  const uint32_t *N = a.N + b * kw, *g = a.g + b * kw, *ni = a.ni + b * kw, *x = a.x + b * kw;
+  Sha256 s;
+  s.init(shabuf + threadIdx.x, 256);
+  s.put_bigint(x, kw); s.put_bigint(g, kw); s.put_bigint(N, kw); s.put_bigint(ni, kw);   // :56-61 / :75-80
+  uint32_t d[8], e[8];
+  s.finish(d);
+#pragma unroll
+  for (int k = 0; k < 8; k++) { e[k] = d[7 - k]; a.e[b * 8 + k] = e[k]; }
+  if (a.verdict) {
+    // assert!(N > 2^128) :69 ; gcd(g, N) == 1 :72 ; gcd(ni, N) == 1 :73  (panics in the reference)
+    bool big = false;
+    for (int w = 5; w < kw; w++) big = big || N[w] != 0;
+    big = big || N[4] > 1 || (N[4] == 1 && (N[0] | N[1] | N[2] | N[3]) != 0);
+    bool ok = big && (N[0] & 1);    // even N: Montgomery path undefined -> reported as malformed (documented deviation)
+    if (ok) {
+      uint32_t* u = a.gcd_scratch + b;
+      uint32_t* v = a.gcd_scratch + (uint64_t)kw * a.batch + b;
+      ok = coprime_to_odd(g, N, kw, u, v, a.batch) && coprime_to_odd(ni, N, kw, u, v, a.batch);
+    }
+    a.verdict[b] = ok ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_MALFORMED;
+  }
+  if (a.y) {
+    const uint32_t* sc = a.secret + b * 8;
+    const uint32_t* r = a.r + b * 16;
+    uint32_t* y = a.y + b * a.yw;
+    uint64_t acc[17];
+    for (int k = 0; k < 17; k++) acc[k] = k < 16 ? r[k] : 0;
+    // e * secret: 8 x 8 words
+    uint32_t prod[16];
+    for (int k = 0; k < 16; k++) prod[k] = 0;
+    for (int i = 0; i < 8; i++) {
+      uint64_t carry = 0;
+      for (int j = 0; j < 8; j++) {
+        const uint64_t t = (uint64_t)e[i] * sc[j] + prod[i + j] + carry;
+        prod[i + j] = (uint32_t)t; carry = t >> 32;
+      }
+      prod[i + 8] = (uint32_t)carry;
+    }
+    uint64_t c = 0;
+    for (uint32_t k = 0; k < a.yw; k++) {
+      c += (k < 17 ? acc[k] : 0) + (k < 16 ? prod[k] : 0);
+      y[k] = (uint32_t)c; c >>= 32;
+    }
+  }
+}
+
+// final comparison x ==? g^y * ni^e mod N (:83-90): plain word compare, only ACCEPT can be downgraded
+struct DlogCmpArgs { const uint32_t* x; const uint32_t* t; const uint32_t* consts; uint64_t const_stride; int st_off; uint32_t kw; uint64_t batch; uint8_t* verdict; };
+__global__ void __launch_bounds__(256) k_dlog_compare(DlogCmpArgs a) {
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.batch) return;
+  if (a.verdict[b] != ZKP_VERDICT_ACCEPT) return;
+  bool same = true;
+  for (uint32_t w = 0; w < a.kw; w++) same = same && a.x[b * a.kw + w] == a.t[b * a.kw + w];
+  if (a.consts[b * a.const_stride + a.st_off] != 0) { a.verdict[b] = ZKP_VERDICT_MALFORMED; return; }
+  if (!same) a.verdict[b] = ZKP_VERDICT_REJECT;
+}
+
 }  // namespace zkp

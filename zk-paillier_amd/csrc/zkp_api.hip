@@ -216,24 +216,34 @@ extern "C" int32_t zkp_timing_get(zkp_ctx* c, double* ms, uint64_t* launches, ui
 }
 
 // ---- L1 primitives --------------------------------------------------------------------------
+// modexp over constants that are already set up in c->consts (per-item when const_stride != 0)
+template <int G>
+static int32_t modexp_core(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const uint32_t* base, const uint32_t* exp, uint64_t exp_stride,
+                           bool per_item_mod, uint32_t* out, int io_words) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  unsigned blocks = 0;
+  int32_t st;
+  if ((st = table_for<G>(c, k_modexp<G>, count, &blocks))) return st;
+  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words};
+  {
+    TimedRegion tr(c, count);
+    hipLaunchKernelGGL(k_modexp<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+  }
+  HIPCHK(c, hipGetLastError());
+  return ZKP_OK;
+}
+
 template <int G>
 static int32_t modexp_impl(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const uint32_t* base, const uint32_t* exp, uint64_t exp_stride,
                            const uint32_t* mod, uint64_t mod_stride, uint32_t* out) {
-  using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
   const uint64_t nmod = mod_stride ? count : 1;
   int32_t st = run_setup<G>(c, mod, mod_stride, LL::NW, 0, nmod, c->consts);
   if (st) return st;
   bool bad = false;
   if ((st = check_setup_status<G>(c, nmod, c->consts, &bad))) return st;
-  unsigned blocks = 0;
-  if ((st = table_for<G>(c, k_modexp<G>, count, &blocks))) return st;
-  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, mod_stride ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits};
-  {
-    TimedRegion tr(c, count);
-    hipLaunchKernelGGL(k_modexp<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
-  }
-  HIPCHK(c, hipGetLastError());
+  if ((st = modexp_core<G>(c, exp_bits, count, base, exp, exp_stride, mod_stride != 0, out, LL::NW))) return st;
   if (bad) { c->err = "even or trivial modulus in batch (outputs of those items are untouched)"; return ZKP_ENONCANONICAL; }
   return ZKP_OK;
 }
@@ -273,7 +283,7 @@ static int32_t modmul_impl(zkp_ctx* c, uint64_t count, const uint32_t* a, const 
   if (st) return st;
   bool bad = false;
   if ((st = check_setup_status<G>(c, nmod, c->consts, &bad))) return st;
-  ModmulArgs args{a, b, (const uint32_t*)c->consts.p, mod_stride ? (uint64_t)CL::WORDS : 0, out, count};
+  ModmulArgs args{a, b, (const uint32_t*)c->consts.p, mod_stride ? (uint64_t)CL::WORDS : 0, out, count, LL::NW};
   const unsigned blocks = (unsigned)((count + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK);
   hipLaunchKernelGGL(k_modmul<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, args);
   HIPCHK(c, hipGetLastError());
