@@ -28,6 +28,18 @@ def enc_limb_macs(n_bits):
     return 1.2 * n_bits * (2 * Lw * Lw + Lw)
 
 
+def usable_cores(omp_max):
+    """host cores this process may really use: min(affinity, cgroup cpu quota, OpenMP max)"""
+    n = min(omp_max, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +170,7 @@ def main():
         S = min(args.cpu_sample, B)
         # a sample that contains a tampered proof: proofs 0..S-1 (proof 0 is tampered)
         host = pb.slice(0, S).to(None)
-        threads = oracle.max_threads()
+        threads = usable_cores(oracle.max_threads())
         oracle.set_threads(threads)
         vo = np.zeros(S, np.uint8)
         t0 = time.perf_counter()
