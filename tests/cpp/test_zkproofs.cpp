@@ -1,0 +1,154 @@
+// C++ mirror of the reference's own unit tests for the hot path, written against
+// zk-paillier_amd/host/zkproofs.hpp (same names and flow as the #[cfg(test)] modules of
+// src/zkproofs/range_proof_ni.rs:131-199, correct_key_ni.rs:120-138, wi_dlog_proof.rs:110-196).
+// Needs a gfx950 GPU (every modexp runs through libzkp_hip.so).  Exit code 0 = all passed.
+#include <cstdio>
+#include <functional>
+#include <string>
+
+#include "../../zk-paillier_amd/host/zkproofs.hpp"
+
+using namespace zkproofs;
+
+static const size_t RANGE_BITS = 256;   // range_proof_ni.rs:133
+
+// range_proof_ni.rs:141-145 (also benches/all.rs:73-77)
+static Keypair test_keypair() {
+  return Keypair{
+      BigInt::from_str_radix10("148677972634832330983979593310074301486537017973460461278300587514468301043894574906886127642530475786889672304776052879927627556769456140664043088700743909632312483413393134504352834240399191134336344285483935856491230340093391784574980688823380828143810804684752914935441384845195613674104960646037368551517"),
+      BigInt::from_str_radix10("158741574437007245654463598139927898730476924736461654463975966787719309357536545869203069369466212089132653564188443272208127277664424448947476335413293018778018615899291704693105620242763173357203898195318179150836424196645745308205164116144020613415407736216097185962171301808761138424668335445923774195463")};
+}
+
+static int failures = 0;
+static void run(const char* name, const std::function<void()>& f, bool should_panic = false) {
+  bool panicked = false;
+  std::string what;
+  try { f(); } catch (const Panic& e) { panicked = true; what = e.what(); }
+  const bool ok = panicked == should_panic;
+  std::printf("%s %s%s%s\n", ok ? "PASS" : "FAIL", name, what.empty() ? "" : "  [panic: ", what.empty() ? "" : (what + "]").c_str());
+  if (!ok) failures++;
+}
+#define ASSERT(c) do { if (!(c)) throw Panic(std::string("assertion failed: ") + #c); } while (0)
+
+// ---- range_proof_ni.rs tests
+static void test_prover() {   // :148-160
+  auto [ek, dk] = test_keypair().keys();
+  BigInt range = BigInt::sample(RANGE_BITS);
+  BigInt secret_r = BigInt::sample_below(ek.n);
+  BigInt secret_x = BigInt::sample_below(range);
+  BigInt ciphertext = Paillier::encrypt_with_chosen_randomness(ek, secret_x, secret_r);
+  RangeProofNi::prove(ek, range, ciphertext, secret_x, secret_r);
+}
+static void test_verifier_for_correct_proof() {   // :163-177
+  auto [ek, dk] = test_keypair().keys();
+  BigInt range = BigInt::sample(RANGE_BITS);
+  BigInt secret_r = BigInt::sample_below(ek.n);
+  BigInt secret_x = BigInt::sample_below(range.div_floor(BigInt(3)));
+  BigInt cipher_x = Paillier::encrypt_with_chosen_randomness(ek, secret_x, secret_r);
+  RangeProofNi range_proof = RangeProofNi::prove(ek, range, cipher_x, secret_x, secret_r);
+  range_proof.verify(ek, cipher_x).expect("range proof error");
+  ASSERT(range_proof.verify_self().is_ok());
+}
+static void test_verifier_for_incorrect_proof() {   // :180-199, #[should_panic]
+  auto [ek, dk] = test_keypair().keys();
+  BigInt range = BigInt::sample(RANGE_BITS);
+  BigInt secret_r = BigInt::sample_below(ek.n);
+  BigInt secret_x = BigInt::sample_range(BigInt(100) * range, BigInt(10000) * range);
+  BigInt cipher_x = Paillier::encrypt_with_chosen_randomness(ek, secret_x, secret_r);
+  RangeProofNi range_proof = RangeProofNi::prove(ek, range, cipher_x, secret_x, secret_r);
+  range_proof.verify(ek, cipher_x).expect("range proof error");
+}
+static void test_verify_asserts_statement() {   // the two assert_eq! of verify (:86,88), #[should_panic]
+  auto [ek, dk] = test_keypair().keys();
+  BigInt range = BigInt::sample(RANGE_BITS);
+  BigInt r = BigInt::sample_below(ek.n), x = BigInt::sample_below(range.div_floor(BigInt(3)));
+  BigInt c = Paillier::encrypt_with_chosen_randomness(ek, x, r);
+  RangeProofNi p = RangeProofNi::prove(ek, range, c, x, r);
+  p.verify(ek, c + BigInt::one());
+}
+static void test_batch_round_trip() {   // many provers, one key: what the GPU is for
+  auto [ek, dk] = test_keypair().keys();
+  std::vector<RangeProofNi::Statement> st;
+  for (int i = 0; i < 6; i++) {
+    BigInt range = BigInt::sample(RANGE_BITS);
+    BigInt r = BigInt::sample_below(ek.n);
+    BigInt x = i == 4 ? BigInt::sample_range(BigInt(100) * range, BigInt(10000) * range) : BigInt::sample_below(range.div_floor(BigInt(3)));
+    st.push_back({range, Paillier::encrypt_with_chosen_randomness(ek, x, r), x, r});
+  }
+  auto proofs = RangeProofNi::prove_batch(ek, st);
+  std::vector<const RangeProofNi*> ptr;
+  for (auto& p : proofs) ptr.push_back(&p);
+  auto res = RangeProofNi::verify_batch(ek, ptr);
+  for (int i = 0; i < 6; i++) ASSERT(res[i].is_ok() == (i != 4));
+}
+
+// ---- correct_key_ni.rs tests (the reference draws a fresh key with Paillier::keypair(); key generation is
+//      not on the hot path, the fixture key is used instead)
+static void test_correct_zk_proof_no_salt_str() {   // :126-130
+  auto [ek, dk] = test_keypair().keys();
+  NiCorrectKeyProof proof = NiCorrectKeyProof::proof(dk);
+  ASSERT(proof.verify(ek, SALT_STRING, 4).is_ok());
+}
+static void test_correct_zk_proof_with_salt_str() {   // :133-138
+  const uint8_t salt_str[8] = {90, 101, 110, 32, 71, 111, 32, 88};
+  auto [ek, dk] = test_keypair().keys();
+  NiCorrectKeyProof proof = NiCorrectKeyProof::proof(dk, salt_str, 8);
+  ASSERT(proof.verify(ek, salt_str, 8).is_ok());
+  ASSERT(proof.verify(ek, SALT_STRING, 4).is_err());          // wrong salt
+  proof.sigma_vec[3] = proof.sigma_vec[3] + BigInt::one();
+  ASSERT(proof.verify(ek, salt_str, 8).is_err());             // tampered root
+}
+
+// ---- wi_dlog_proof.rs tests
+static int legendre_symbol(const BigInt& a, const BigInt& p) {   // :94-107
+  BigInt e = (p - BigInt::one()).div_floor(BigInt(2));
+  return mod_pow(a, e, p) == BigInt::one() ? 1 : -1;
+}
+static const size_t SAMPLE_S = 256;
+static DLogStatement dlog_statement(int variant, BigInt* secret_out) {
+  auto [ek, dk] = test_keypair().keys();
+  BigInt one = BigInt::one();
+  BigInt S = BigInt::pow2(SAMPLE_S);
+  BigInt h1 = BigInt::sample_range(one, ek.n - one);
+  while (legendre_symbol(h1, dk.p) * legendre_symbol(h1, dk.q) != -1) h1 = BigInt::sample_range(one, ek.n - one);   // Jacobi -1, :124-128
+  BigInt secret = BigInt::sample_below(S);
+  BigInt h2;
+  if (variant == 0) h2 = mod_pow(BigInt::mod_inv(h1, ek.n), secret, ek.n);   // :130-131
+  else if (variant == 1) h2 = mod_pow(h1, secret, ek.n);                      // :159 "+secret"
+  else h2 = BigInt::sample_range(one, ek.n - one);                            // :187 random
+  *secret_out = secret;
+  return DLogStatement{ek.n, h1, h2};
+}
+static void test_correct_dlog_proof() {   // :117-141
+  BigInt secret;
+  DLogStatement st = dlog_statement(0, &secret);
+  CompositeDLogProof proof = CompositeDLogProof::prove(st, secret);
+  ASSERT(proof.verify(st).is_ok());
+}
+static void test_bad_dlog_proof() {   // :145-168 #[should_panic]
+  BigInt secret;
+  DLogStatement st = dlog_statement(1, &secret);
+  CompositeDLogProof proof = CompositeDLogProof::prove(st, secret);
+  ASSERT(proof.verify(st).is_ok());
+}
+static void test_bad_dlog_proof_2() {   // :172-196 #[should_panic]
+  BigInt secret;
+  DLogStatement st = dlog_statement(2, &secret);
+  CompositeDLogProof proof = CompositeDLogProof::prove(st, secret);
+  ASSERT(proof.verify(st).is_ok());
+}
+
+int main() {
+  run("range_proof_ni::test_prover", test_prover);
+  run("range_proof_ni::test_verifier_for_correct_proof", test_verifier_for_correct_proof);
+  run("range_proof_ni::test_verifier_for_incorrect_proof", test_verifier_for_incorrect_proof, true);
+  run("range_proof_ni::verify asserts ek/ciphertext", test_verify_asserts_statement, true);
+  run("range_proof_ni::batch round trip", test_batch_round_trip);
+  run("correct_key_ni::test_correct_zk_proof_no_salt_str", test_correct_zk_proof_no_salt_str);
+  run("correct_key_ni::test_correct_zk_proof_with_salt_str", test_correct_zk_proof_with_salt_str);
+  run("wi_dlog_proof::test_correct_dlog_proof", test_correct_dlog_proof);
+  run("wi_dlog_proof::test_bad_dlog_proof", test_bad_dlog_proof, true);
+  run("wi_dlog_proof::test_bad_dlog_proof_2", test_bad_dlog_proof_2, true);
+  std::printf("%d failure(s)\n", failures);
+  return failures ? 1 : 0;
+}

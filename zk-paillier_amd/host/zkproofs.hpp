@@ -1,0 +1,352 @@
+// zkproofs.hpp — C++ host mirror of the reference's proof API for the hot path, on top of the C
+// ABI of include/zkp_hip.h.  (The reference is Rust; there is no Rust toolchain in this image, so
+// the host side above the C ABI is C++ — same type and method names, argument meaning and error
+// behaviour as the reference, so that tests read like the reference's own tests.)
+//
+//   reference                                                      here
+//   zkproofs::RangeProofNi::{prove,verify,verify_self}              RangeProofNi::{prove,verify,verify_self}   (+ *_batch)
+//     src/zkproofs/range_proof_ni.rs:36-128
+//   zkproofs::NiCorrectKeyProof::{proof,verify}                     NiCorrectKeyProof::{proof,verify}
+//     src/zkproofs/correct_key_ni.rs:36-100
+//   zkproofs::{CompositeDLogProof,DLogStatement}::{prove,verify}    same
+//     src/zkproofs/wi_dlog_proof.rs:33-91
+//   paillier::{Keypair,EncryptionKey,DecryptionKey,Paillier}        same names, only what the path needs
+//   zkproofs::IncorrectProof (errors.rs:5-13)                       Result<> with is_ok()/is_err()/expect()
+//
+// Rust panics (assert_eq!, index out of bounds, .expect on Err) become C++ exceptions (Panic).
+// Every modular exponentiation runs on the GPU; this layer only samples, hashes small transcripts
+// (NiCorrectKeyProof::proof's MGF), converts BigInt <-> limbs and flattens proofs into batches.
+#pragma once
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/zkp_hip.h"
+#include "bigint.hpp"
+
+namespace zkproofs {
+
+struct Panic : std::runtime_error { using std::runtime_error::runtime_error; };
+struct IncorrectProof {};   // src/zkproofs/errors.rs:5-13
+
+// Result<(), IncorrectProof>
+class Result {
+  bool ok_;
+ public:
+  explicit Result(bool ok) : ok_(ok) {}
+  bool is_ok() const { return ok_; }
+  bool is_err() const { return !ok_; }
+  void expect(const char* msg) const { if (!ok_) throw Panic(std::string(msg) + ": IncorrectProof"); }
+};
+
+// ------------------------------------------------------------------ engine (one ctx per device)
+class Engine {
+  zkp_ctx* ctx_ = nullptr;
+ public:
+  explicit Engine(int device = 0) {
+    if (zkp_ctx_create(device, &ctx_) != ZKP_OK) throw std::runtime_error("zkp_ctx_create failed: no gfx950 GPU (there is no CPU fallback)");
+  }
+  ~Engine() { if (ctx_) zkp_ctx_destroy(ctx_); }
+  Engine(const Engine&) = delete;
+  zkp_ctx* ctx() const { return ctx_; }
+  void check(int32_t st, const char* what) const {
+    if (st != ZKP_OK) throw std::runtime_error(std::string(what) + " failed (status " + std::to_string(st) + "): " + zkp_last_error_string(ctx_));
+  }
+  static Engine& instance() { static Engine e(0); return e; }
+};
+
+// kernel width (bits) for an n of the given size
+inline uint32_t width_for(const BigInt& n) {
+  const size_t b = n.bit_length();
+  if (b <= 1024) return 1024;
+  if (b <= 2048) return 2048;
+  if (b <= 4096) return 4096;
+  throw std::length_error("modulus wider than 4096 bits");
+}
+
+// ------------------------------------------------------------------ Paillier key types
+struct EncryptionKey {
+  BigInt n, nn;
+  friend bool operator==(const EncryptionKey& a, const EncryptionKey& b) { return a.n == b.n && a.nn == b.nn; }
+};
+struct DecryptionKey { BigInt p, q; };
+struct Keypair {
+  BigInt p, q;
+  // [upstream paillier::Keypair::keys]: ek = {n, nn = n^2}, dk = {p, q}
+  std::pair<EncryptionKey, DecryptionKey> keys() const { BigInt n = p * q; return {EncryptionKey{n, n * n}, DecryptionKey{p, q}}; }
+};
+
+struct Paillier {
+  // [upstream EncryptWithChosenRandomness] c = (1 + m n) r^n mod n^2
+  static BigInt encrypt_with_chosen_randomness(const EncryptionKey& ek, const BigInt& m, const BigInt& r) {
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    std::vector<uint32_t> n(kw), mm(kw), rr(kw), c(2 * kw);
+    ek.n.to_limbs(n.data(), kw); m.to_limbs(mm.data(), kw); r.to_limbs(rr.data(), kw);
+    e.check(zkp_paillier_enc_batch(e.ctx(), nb, 1, n.data(), 0, mm.data(), rr.data(), c.data(), 0), "zkp_paillier_enc_batch");
+    return BigInt::from_limbs(c.data(), 2 * kw);
+  }
+};
+
+inline BigInt mod_pow(const BigInt& base, const BigInt& exp, const BigInt& modulus) {
+  Engine& e = Engine::instance();
+  const size_t b = modulus.bit_length();
+  const uint32_t mb = b <= 2048 ? 2048 : b <= 4096 ? 4096 : 8192, L = mb / 32;
+  if (exp.bit_length() > mb) throw std::length_error("exponent wider than the modulus width");
+  std::vector<uint32_t> bb(L), ee(L), mm(L), out(L);
+  (base % modulus).to_limbs(bb.data(), L); exp.to_limbs(ee.data(), L); modulus.to_limbs(mm.data(), L);
+  e.check(zkp_modexp_batch(e.ctx(), mb, mb, 1, bb.data(), ee.data(), L, mm.data(), L, out.data(), 0), "zkp_modexp_batch");
+  return BigInt::from_limbs(out.data(), L);
+}
+
+// ------------------------------------------------------------------ RangeProofNi
+struct Response {           // src/zkproofs/range_proof.rs:53-78
+  enum Kind { Open, Mask } kind = Open;
+  BigInt w1, r1, w2, r2;    // Open
+  uint8_t j = 0;            // Mask
+  BigInt masked_x, masked_r;
+};
+struct EncryptedPairs { std::vector<BigInt> c1, c2; };   // range_proof.rs:32-39
+struct Proof { std::vector<Response> responses; };       // range_proof.rs:80-81
+
+class RangeProofNi {
+ public:
+  static constexpr size_t SECURITY_PARAMETER = ZKP_SECURITY_PARAMETER;   // range_proof_ni.rs:23
+  EncryptionKey ek;
+  BigInt range, ciphertext;
+  EncryptedPairs encrypted_pairs;
+  Proof proof;
+  size_t error_factor = SECURITY_PARAMETER;
+
+  struct Statement { BigInt range, ciphertext, secret_x, secret_r; };
+
+  // range_proof_ni.rs:47-82 for many provers sharing one key; randomness sampled as range_proof.rs:133-159
+  static std::vector<RangeProofNi> prove_batch(const EncryptionKey& ek, const std::vector<Statement>& st) {
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    const size_t B = st.size(), EF = SECURITY_PARAMETER, rows = B * EF;
+    std::vector<uint32_t> n(kw), range(B * kw), ct(B * 2 * kw), x(B * kw), r(B * kw), w1(rows * kw), w2(rows * kw), r1(rows * kw), r2(rows * kw);
+    ek.n.to_limbs(n.data(), kw);
+    std::random_device rd;
+    for (size_t b = 0; b < B; b++) {
+      st[b].range.to_limbs(&range[b * kw], kw); st[b].ciphertext.to_limbs(&ct[b * 2 * kw], 2 * kw);
+      st[b].secret_x.to_limbs(&x[b * kw], kw); st[b].secret_r.to_limbs(&r[b * kw], kw);
+      const BigInt third = st[b].range.div_floor(BigInt(3)), two_thirds = BigInt(2) * third;   // range_proof.rs:133-134
+      for (size_t i = 0; i < EF; i++) {
+        BigInt a = BigInt::sample_range(third, two_thirds), c = a - third;                      // :136-141
+        if (rd() & 1) std::swap(a, c);                                                           // :144-149
+        a.to_limbs(&w1[(b * EF + i) * kw], kw); c.to_limbs(&w2[(b * EF + i) * kw], kw);
+        BigInt::sample_below(ek.n).to_limbs(&r1[(b * EF + i) * kw], kw);                         // :151-159
+        BigInt::sample_below(ek.n).to_limbs(&r2[(b * EF + i) * kw], kw);
+      }
+    }
+    std::vector<uint32_t> c1(rows * 2 * kw), c2(rows * 2 * kw), rw1(rows * kw), rr1(rows * kw), rw2(rows * kw), rr2(rows * kw);
+    std::vector<uint8_t> kind(rows), jj(rows), status(B);
+    zkp_range_ni_proofs p{nb, (uint32_t)EF, B, 0, n.data(), range.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
+                          rw1.data(), rr1.data(), rw2.data(), rr2.data()};
+    zkp_range_ni_witness w{x.data(), r.data(), w1.data(), w2.data(), r1.data(), r2.data()};
+    e.check(zkp_range_ni_prove_batch(e.ctx(), &p, &w, nullptr, nullptr, status.data(), 0), "zkp_range_ni_prove_batch");
+    std::vector<RangeProofNi> out(B);
+    for (size_t b = 0; b < B; b++) {
+      if (status[b] != 0) throw Panic("RangeProofNi::prove: malformed (the reference would panic)");
+      RangeProofNi& o = out[b];
+      o.ek = ek; o.range = st[b].range; o.ciphertext = st[b].ciphertext; o.error_factor = EF;
+      for (size_t i = 0; i < EF; i++) {
+        const size_t t = b * EF + i;
+        o.encrypted_pairs.c1.push_back(BigInt::from_limbs(&c1[t * 2 * kw], 2 * kw));
+        o.encrypted_pairs.c2.push_back(BigInt::from_limbs(&c2[t * 2 * kw], 2 * kw));
+        Response rs;
+        if (kind[t] == ZKP_RESP_OPEN) {
+          rs.kind = Response::Open;
+          rs.w1 = BigInt::from_limbs(&rw1[t * kw], kw); rs.r1 = BigInt::from_limbs(&rr1[t * kw], kw);
+          rs.w2 = BigInt::from_limbs(&rw2[t * kw], kw); rs.r2 = BigInt::from_limbs(&rr2[t * kw], kw);
+        } else {
+          rs.kind = Response::Mask; rs.j = jj[t];
+          rs.masked_x = BigInt::from_limbs(&rw1[t * kw], kw); rs.masked_r = BigInt::from_limbs(&rr1[t * kw], kw);
+        }
+        o.proof.responses.push_back(std::move(rs));
+      }
+    }
+    return out;
+  }
+
+  static RangeProofNi prove(const EncryptionKey& ek, const BigInt& range, const BigInt& ciphertext, const BigInt& secret_x, const BigInt& secret_r) {
+    return prove_batch(ek, {Statement{range, ciphertext, secret_x, secret_r}})[0];
+  }
+
+  // verify_self for many proofs sharing one key (range_proof_ni.rs:109-128)
+  static std::vector<Result> verify_batch(const EncryptionKey& ek, const std::vector<const RangeProofNi*>& proofs) {
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    const size_t B = proofs.size();
+    if (B == 0) return {};
+    const size_t EF = proofs[0]->error_factor, rows = B * EF;
+    std::vector<uint32_t> n(kw), range(B * kw), ct(B * 2 * kw), c1(rows * 2 * kw), c2(rows * 2 * kw), rw1(rows * kw), rr1(rows * kw), rw2(rows * kw), rr2(rows * kw);
+    std::vector<uint8_t> kind(rows), jj(rows), verdict(B);
+    ek.n.to_limbs(n.data(), kw);
+    for (size_t b = 0; b < B; b++) {
+      const RangeProofNi& p = *proofs[b];
+      if (p.error_factor != EF) throw std::invalid_argument("verify_batch: mixed error factors");
+      // responses[i], c1[i], c2[i] for i < error_factor: out-of-bounds index is a panic in the reference (range_proof.rs:274,293,296)
+      if (p.proof.responses.size() < EF || p.encrypted_pairs.c1.size() < EF || p.encrypted_pairs.c2.size() < EF) throw Panic("index out of bounds");
+      if (p.encrypted_pairs.c1.size() != EF || p.encrypted_pairs.c2.size() != EF)
+        throw std::invalid_argument("verify_batch: the fixed-layout ABI needs len(c1) == len(c2) == error_factor");
+      p.range.to_limbs(&range[b * kw], kw); p.ciphertext.to_limbs(&ct[b * 2 * kw], 2 * kw);
+      for (size_t i = 0; i < EF; i++) {
+        const size_t t = b * EF + i;
+        p.encrypted_pairs.c1[i].to_limbs(&c1[t * 2 * kw], 2 * kw); p.encrypted_pairs.c2[i].to_limbs(&c2[t * 2 * kw], 2 * kw);
+        const Response& rs = p.proof.responses[i];
+        if (rs.kind == Response::Open) {
+          kind[t] = ZKP_RESP_OPEN;
+          rs.w1.to_limbs(&rw1[t * kw], kw); rs.r1.to_limbs(&rr1[t * kw], kw); rs.w2.to_limbs(&rw2[t * kw], kw); rs.r2.to_limbs(&rr2[t * kw], kw);
+        } else {
+          kind[t] = ZKP_RESP_MASK; jj[t] = rs.j;
+          rs.masked_x.to_limbs(&rw1[t * kw], kw); rs.masked_r.to_limbs(&rr1[t * kw], kw);
+        }
+      }
+    }
+    zkp_range_ni_proofs p{nb, (uint32_t)EF, B, 0, n.data(), range.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
+                          rw1.data(), rr1.data(), rw2.data(), rr2.data()};
+    e.check(zkp_range_ni_verify_batch(e.ctx(), &p, verdict.data(), 0), "zkp_range_ni_verify_batch");
+    std::vector<Result> out;
+    for (size_t b = 0; b < B; b++) {
+      if (verdict[b] == ZKP_VERDICT_MALFORMED) throw Panic("RangeProofNi::verify: malformed proof (the reference would panic)");
+      out.emplace_back(verdict[b] == ZKP_VERDICT_ACCEPT);
+    }
+    return out;
+  }
+
+  // range_proof_ni.rs:84-107
+  Result verify(const EncryptionKey& ek_, const BigInt& ciphertext_) const {
+    if (!(ek_ == ek)) throw Panic("assertion failed: `(left == right)` ek");                  // :86
+    if (ciphertext_ != ciphertext) throw Panic("assertion failed: `(left == right)` ciphertext");   // :88
+    return verify_batch(ek, {this})[0];
+  }
+  Result verify_self() const { return verify_batch(ek, {this})[0]; }                          // :109-128
+};
+
+// ------------------------------------------------------------------ host SHA-256 (only for NiCorrectKeyProof::proof's MGF)
+namespace detail {
+struct Sha256 {
+  uint32_t h[8]; uint8_t buf[64]; uint64_t len = 0; size_t fill = 0;
+  static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  Sha256() { static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}; std::memcpy(h, iv, 32); }
+  void block(const uint8_t* p) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) w[i] = w[i - 16] + (ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+      uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const uint8_t* p, size_t n) {
+    len += n;
+    while (n) { size_t k = std::min(n, 64 - fill); std::memcpy(buf + fill, p, k); fill += k; p += k; n -= k; if (fill == 64) { block(buf); fill = 0; } }
+  }
+  void update(const BigInt& v) { auto b = v.to_bytes(); update(b.data(), b.size()); }
+  BigInt finish() {
+    uint64_t bits = len * 8; uint8_t pad = 0x80; update(&pad, 1); pad = 0;
+    while (fill != 56) update(&pad, 1);
+    uint8_t lb[8]; for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+    update(lb, 8);
+    uint8_t out[32]; for (int i = 0; i < 8; i++) { out[4 * i] = h[i] >> 24; out[4 * i + 1] = h[i] >> 16; out[4 * i + 2] = h[i] >> 8; out[4 * i + 3] = h[i]; }
+    return BigInt::from_bytes(out, 32);
+  }
+};
+// src/zkproofs/utils.rs:9-22
+inline BigInt compute_digest(std::initializer_list<const BigInt*> items) { Sha256 s; for (auto* v : items) s.update(*v); return s.finish(); }
+}  // namespace detail
+
+// ------------------------------------------------------------------ NiCorrectKeyProof
+static const uint8_t SALT_STRING[4] = {75, 90, 101, 110};   // correct_key_ni.rs:28
+
+class NiCorrectKeyProof {
+ public:
+  static constexpr size_t M2 = ZKP_CORRECT_KEY_M2, DIGEST_SIZE = 256;   // correct_key_ni.rs:29-30
+  std::vector<BigInt> sigma_vec;
+
+  // correct_key_ni.rs:105-117
+  static BigInt mask_generation(size_t out_length, const BigInt& seed) {
+    const size_t msklen = out_length / DIGEST_SIZE + 1;
+    BigInt acc;
+    for (size_t j = 0; j < msklen; j++) { BigInt jj(j); acc = acc + detail::compute_digest({&seed, &jj}).shl(j * DIGEST_SIZE); }
+    return acc;
+  }
+  // correct_key_ni.rs:42-71 — prover side (needs the secret key).  The n-th roots are
+  // rho^(n^-1 mod phi) mod n ([upstream] extract_nroot), computed by ONE batched GPU modexp.
+  static NiCorrectKeyProof proof(const DecryptionKey& dk, const uint8_t* salt = SALT_STRING, size_t salt_len = 4) {
+    Engine& e = Engine::instance();
+    const BigInt n = dk.p * dk.q;
+    const BigInt phi = (dk.p - BigInt::one()) * (dk.q - BigInt::one());
+    const BigInt d = BigInt::mod_inv(n, phi);
+    const BigInt salt_bn = [&] { BigInt s = BigInt::from_bytes(salt, salt_len); return detail::compute_digest({&s}); }();
+    const uint32_t nb = n.bit_length() <= 2048 ? 2048 : 4096, kw = nb / 32;   // modexp kernel widths
+    std::vector<uint32_t> base(M2 * kw), ex(kw), mod(kw), out(M2 * kw);
+    for (size_t i = 0; i < M2; i++) {
+      BigInt ii(i);
+      BigInt seed = detail::compute_digest({&n, &salt_bn, &ii});
+      (mask_generation(n.bit_length(), seed) % n).to_limbs(&base[i * kw], kw);
+    }
+    d.to_limbs(ex.data(), kw); n.to_limbs(mod.data(), kw);
+    e.check(zkp_modexp_batch(e.ctx(), nb, nb, M2, base.data(), ex.data(), 0, mod.data(), 0, out.data(), 0), "zkp_modexp_batch");
+    NiCorrectKeyProof p;
+    for (size_t i = 0; i < M2; i++) p.sigma_vec.push_back(BigInt::from_limbs(&out[i * kw], kw));
+    return p;
+  }
+  // correct_key_ni.rs:73-100
+  Result verify(const EncryptionKey& ek, const uint8_t* salt = SALT_STRING, size_t salt_len = 4) const {
+    Engine& e = Engine::instance();
+    if (sigma_vec.size() < M2) throw Panic("index out of bounds: sigma_vec");   // self.sigma_vec[i], :92
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    std::vector<uint32_t> n(kw), sg(M2 * kw);
+    ek.n.to_limbs(n.data(), kw);
+    for (size_t i = 0; i < M2; i++) sigma_vec[i].to_limbs(&sg[i * kw], kw);
+    uint8_t v = 9;
+    e.check(zkp_correct_key_ni_verify_batch(e.ctx(), nb, 1, n.data(), sg.data(), salt, (uint32_t)salt_len, &v, 0), "zkp_correct_key_ni_verify_batch");
+    return Result(v == ZKP_VERDICT_ACCEPT);
+  }
+};
+
+// ------------------------------------------------------------------ CompositeDLogProof
+struct DLogStatement { BigInt N, g, ni; };   // wi_dlog_proof.rs:38-43
+
+class CompositeDLogProof {
+ public:
+  static constexpr uint32_t Y_BITS = 768;     // y = r + e*s < 2^513 for honest provers
+  BigInt x, y;
+  // wi_dlog_proof.rs:46-65
+  static CompositeDLogProof prove(const DLogStatement& st, const BigInt& secret) {
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.N), kw = nb / 32;
+    const BigInt r = BigInt::sample_below(BigInt::pow2(512));     // K + K' + SAMPLE_S = 512, :53-54
+    std::vector<uint32_t> N(kw), g(kw), ni(kw), s(8), rr(16), x(kw), y(Y_BITS / 32);
+    st.N.to_limbs(N.data(), kw); st.g.to_limbs(g.data(), kw); st.ni.to_limbs(ni.data(), kw); secret.to_limbs(s.data(), 8); r.to_limbs(rr.data(), 16);
+    e.check(zkp_dlog_prove_batch(e.ctx(), nb, Y_BITS, 1, N.data(), g.data(), ni.data(), s.data(), rr.data(), x.data(), y.data(), 0), "zkp_dlog_prove_batch");
+    return CompositeDLogProof{BigInt::from_limbs(x.data(), kw), BigInt::from_limbs(y.data(), Y_BITS / 32)};
+  }
+  // wi_dlog_proof.rs:67-91
+  Result verify(const DLogStatement& st) const {
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.N), kw = nb / 32;
+    std::vector<uint32_t> N(kw), g(kw), ni(kw), xx(kw), yy(Y_BITS / 32);
+    st.N.to_limbs(N.data(), kw); st.g.to_limbs(g.data(), kw); st.ni.to_limbs(ni.data(), kw); x.to_limbs(xx.data(), kw); y.to_limbs(yy.data(), Y_BITS / 32);
+    uint8_t v = 9;
+    e.check(zkp_dlog_verify_batch(e.ctx(), nb, Y_BITS, 1, N.data(), g.data(), ni.data(), xx.data(), yy.data(), &v, 0), "zkp_dlog_verify_batch");
+    if (v == ZKP_VERDICT_MALFORMED) throw Panic("assertion failed in CompositeDLogProof::verify (N > 2^128, gcd(g,N) = gcd(ni,N) = 1)");   // :69,72,73
+    return Result(v == ZKP_VERDICT_ACCEPT);
+  }
+};
+
+}  // namespace zkproofs
