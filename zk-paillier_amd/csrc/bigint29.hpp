@@ -34,6 +34,11 @@ constexpr int W = ZKP_W;                    // limbs per lane (9 or 18)
 constexpr uint32_t LMASK = (1u << LB) - 1;
 constexpr int BLK = (W + 3) & ~3;           // LDS words per W-limb block (16-B multiple: keeps ds_read_b128 aligned)
 static_assert(W == 9 || W == 18, "limbs per lane");
+// minimum waves per SIMD requested from the register allocator for the modexp-class kernels: the hot
+// loop (montmul) needs ~70 VGPRs at W = 9; values that live across an exponentiation may spill around it
+#ifndef ZKP_WPE
+#define ZKP_WPE (ZKP_W == 9 ? 5 : 3)
+#endif
 
 template <int G> struct Geo {
   static constexpr int L = G * W;           // 29-bit limbs per integer

@@ -314,7 +314,7 @@ struct ModexpArgs {
 };
 
 template <int G>
-__global__ void __launch_bounds__(256) k_modexp(ModexpArgs a) {
+__global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
   constexpr int L = Geo<G>::L, NW = LL::NW;
@@ -359,7 +359,7 @@ struct ModmulArgs {
   int io_words;
 };
 template <int G>
-__global__ void __launch_bounds__(256) k_modmul(ModmulArgs a) {
+__global__ void __launch_bounds__(256, ZKP_WPE) k_modmul(ModmulArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
   constexpr int NW = LL::NW;
@@ -424,7 +424,7 @@ struct EncArgs {
 };
 
 template <int G>
-__global__ void __launch_bounds__(256) k_enc(EncArgs a) {
+__global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
   constexpr int L = Geo<G>::L, NW = LL::NW, KW = NW / 2;

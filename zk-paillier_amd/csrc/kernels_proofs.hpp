@@ -142,7 +142,7 @@ struct ResponseArgs {
 };
 
 template <int G>
-__global__ void __launch_bounds__(256) k_range_responses(ResponseArgs a) {
+__global__ void __launch_bounds__(256, ZKP_WPE) k_range_responses(ResponseArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
   extern __shared__ __align__(16) uint32_t lds_raw[];
@@ -294,7 +294,7 @@ struct CkCheckArgs {
 };
 
 template <int G>
-__global__ void __launch_bounds__(256) k_ck_check(CkCheckArgs a) {
+__global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
   constexpr int L = Geo<G>::L, NW = LL::NW;
