@@ -103,12 +103,14 @@ def main():
             ctx.synchronize()
             dist.all_gather_into_tensor(gathered_c[0], pb.c1)
             dist.all_gather_into_tensor(gathered_c[1], pb.c2)
+            torch.cuda.synchronize()      # the next step overwrites c1/c2 on the engine's own stream
 
     def verify_step():
         ctx.range_ni_verify(pstruct, verdict, device=True)
         if world > 1:
             ctx.synchronize()
             dist.all_gather_into_tensor(gathered_v, verdict)
+            torch.cuda.synchronize()
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):

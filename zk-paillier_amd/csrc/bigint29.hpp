@@ -128,7 +128,11 @@ __device__ __forceinline__ void lds_store_block(uint32_t* p, const uint32_t (&v)
 // ONE column is normalised per sub-step and no carry flag is ever used: 2W v_mad_u64_u32 per
 // ~9 other VALU instructions.  The window is a circular register file: after W sub-steps
 // (fully unrolled) the register assignment repeats, so the loop over blocks stays rolled.
-template <int G>
+//
+// ORUP = true: the caller passes N := M~ = M * n1 (a multiple of M with M~ == -1 mod 2^29, Orup's trick):
+// the quotient digit is then just the low limb of the bottom column, one multiply less per sub-step.  The
+// result is correct modulo M (not reduced below M~): used inside exponentiation ladders only.
+template <int G, bool ORUP = false>
 __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W], const uint32_t* ldsB,
                                         const uint32_t (&N)[W], uint32_t n1, int gl) {
   uint64_t c[W];
@@ -144,7 +148,7 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
       const uint32_t b = Bs[t];
 #pragma unroll
       for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)A[k] * b;
-      const uint32_t q = bcast0<G>(((uint32_t)c[t] * n1) & LMASK);
+      const uint32_t q = bcast0<G>((ORUP ? (uint32_t)c[t] : (uint32_t)c[t] * n1) & LMASK);
 #pragma unroll
       for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q;
       const uint64_t v = c[t];

@@ -12,11 +12,12 @@ constexpr int WIN = 5;                 // fixed window width (table of 32 Montgo
 constexpr int TAB = 1 << WIN;
 
 // ---- per-modulus constants in global memory (uint32 words):
-//   N29[L] | R2[L] | R1[L] | NR[L] | NI[BLK] | status[4]
+//   N29[L] | R2[L] | R1[L] | NR[L] | MT[L] | n1[12] | status[4]
+// (MT = M * n1, the Orup multiple of the modulus used inside the exponentiation ladders)
 template <int G> struct ConstLayout {
   static constexpr int L = Geo<G>::L;
-  static constexpr int OFF_N = 0, OFF_R2 = L, OFF_R1 = 2 * L, OFF_NR = 3 * L, OFF_NI = 4 * L, OFF_ST = 4 * L + 12;
-  static constexpr int WORDS = 4 * L + 12 + 4;
+  static constexpr int OFF_N = 0, OFF_R2 = L, OFF_R1 = 2 * L, OFF_NR = 3 * L, OFF_MT = 4 * L, OFF_NI = 5 * L, OFF_ST = 5 * L + 12;
+  static constexpr int WORDS = 5 * L + 12 + 4;
 };
 
 // ---- per-group LDS carve-up (uint32 words)
@@ -74,7 +75,11 @@ template <int G> __device__ __forceinline__ void stageB(const Grp<G>& g, const u
 }
 
 template <int G> __device__ __forceinline__ void mm(const Grp<G>& g, uint32_t (&R)[W], const uint32_t (&A)[W]) {
-  montmul<G>(R, A, g.B(), g.N, g.n1, g.gl);
+  montmul<G, false>(R, A, g.B(), g.N, g.n1, g.gl);
+}
+// ladder variant: NT = this lane's block of M~ (ConstLayout::OFF_MT)
+template <int G> __device__ __forceinline__ void mmo(const Grp<G>& g, const uint32_t (&NT)[W], uint32_t (&R)[W], const uint32_t (&A)[W]) {
+  montmul<G, true>(R, A, g.B(), NT, 1u, g.gl);
 }
 
 // cooperative copy of `nwords` 32-bit words global -> LDS words area, zero padded to NW+8
@@ -113,15 +118,21 @@ template <int G> __device__ __forceinline__ void canonical_words(const Grp<G>& g
 }
 
 // ------------------------------------------------------------------------------------------
-// Fixed-window exponentiation.  In: X = base in Montgomery form (regs), exponent words in
-// g.expw() (exp_words valid + 2 zero words).  Out: X = base^exp in Montgomery form, also
-// staged in B().  tab: this group's 32*L-word table in global memory.
+// Exponentiation ladders.  In: X = base in Montgomery form (regs), exponent words in g.expw()
+// (valid words + zero padding).  Out: X = base^exp in Montgomery form (value < 2M~), also staged in B().
+// tab: this group's TAB*L-word table in global memory; cst: the modulus' constant record.
+// Both ladders run on M~ (Orup) and keep ONE montmul call site in their main loop.
+
+// (a) per-item exponents (sigma^n mod n with a different n per proof, DLog): fixed 5-bit windows, uniform
+//     control flow whatever the exponents are.  1.2 t + 30 products.
 template <int G>
-__device__ __forceinline__ void powm_window(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cstR1) {
+__device__ __forceinline__ void powm_fixed(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst) {
+  using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
-  uint32_t T[W], R[W];
+  uint32_t NT[W], T[W], R[W];
+  load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
   // table: T[0] = R mod M (Montgomery one), T[1] = X, T[k] = T[k-1]*X
-  load_limbs_global<G>(T, cstR1, g.gl);
+  load_limbs_global<G>(T, cst + CL::OFF_R1, g.gl);
   store_limbs_global<G>(tab, T, g.gl);
   store_limbs_global<G>(tab + L, X, g.gl);
   stageB<G>(g, X);
@@ -129,7 +140,7 @@ __device__ __forceinline__ void powm_window(const Grp<G>& g, uint32_t (&X)[W], i
   for (int k = 0; k < W; k++) T[k] = X[k];
 #pragma unroll 1
   for (int e = 2; e < TAB; e++) {
-    mm<G>(g, R, T);
+    mmo<G>(g, NT, R, T);
 #pragma unroll
     for (int k = 0; k < W; k++) T[k] = R[k];
     store_limbs_global<G>(tab + e * L, T, g.gl);
@@ -145,21 +156,101 @@ __device__ __forceinline__ void powm_window(const Grp<G>& g, uint32_t (&X)[W], i
   // the table stores of this lane are re-read by this lane only: program order suffices
   load_limbs_global<G>(X, tab + window(nwin - 1) * L, g.gl);
   stageB<G>(g, X);
+  // (nwin-1) rounds of [5 squarings, 1 table product] as one loop with one montmul call site
 #pragma unroll 1
-  for (int wi = nwin - 2; wi >= 0; wi--) {
-#pragma unroll 1
-    for (int sq = 0; sq < WIN; sq++) {
-      mm<G>(g, R, X);
+  for (int step = 0; step < (nwin - 1) * (WIN + 1); step++) {
+    const int ph = step % (WIN + 1);
+    if (ph == WIN) {
+      load_limbs_global<G>(T, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
+    } else {
 #pragma unroll
-      for (int k = 0; k < W; k++) X[k] = R[k];
-      stageB<G>(g, X);
+      for (int k = 0; k < W; k++) T[k] = X[k];
     }
-    load_limbs_global<G>(T, tab + window(wi) * L, g.gl);
-    mm<G>(g, R, T);
+    mmo<G>(g, NT, R, T);
 #pragma unroll
     for (int k = 0; k < W; k++) X[k] = R[k];
     stageB<G>(g, X);
   }
+}
+
+// (b) ONE exponent for the whole launch (Paillier Enc under a shared key: exponent n): sliding windows of
+//     up to 6 bits over a table of the 32 odd powers; the schedule depends on the exponent only, so it is
+//     wave-uniform (scalar branches).  ~ t + t/7 + 33 products.
+constexpr int SWIN = 6;
+template <int G>
+__device__ __forceinline__ void powm_sliding(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst) {
+  using CL = ConstLayout<G>;
+  constexpr int L = Geo<G>::L;
+  static_assert((1 << (SWIN - 1)) == TAB, "table size");
+  uint32_t NT[W], T[W], R[W];
+  load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
+  // odd powers: tab[e] = X^(2e+1);  X2 = X^2 staged in B() while the table is built
+  store_limbs_global<G>(tab, X, g.gl);
+  stageB<G>(g, X);
+  mmo<G>(g, NT, R, X);
+  stageB<G>(g, R);
+#pragma unroll
+  for (int k = 0; k < W; k++) T[k] = X[k];
+#pragma unroll 1
+  for (int e = 1; e < TAB; e++) {
+    mmo<G>(g, NT, R, T);
+#pragma unroll
+    for (int k = 0; k < W; k++) T[k] = R[k];
+    store_limbs_global<G>(tab + e * L, T, g.gl);
+  }
+  const uint32_t* ew = g.expw();
+  auto bit = [&](int i) -> int { return (int)((__builtin_amdgcn_readfirstlane(ew[i >> 5]) >> (i & 31)) & 1u); };
+  int i = exp_bits - 1;
+  while (i >= 0 && !bit(i)) i--;
+  if (i < 0) {                                     // exponent 0
+    load_limbs_global<G>(X, cst + CL::OFF_R1, g.gl);
+    stageB<G>(g, X);
+    return;
+  }
+  int nsq = 0, mulval = 0;
+  bool started = false;
+#pragma unroll 1
+  for (;;) {
+    int op;                                        // 0: square, v > 0: multiply by X^v (v odd)
+    if (nsq > 0) { op = 0; nsq--; }
+    else if (mulval) { op = mulval; mulval = 0; }
+    else {
+      if (i < 0) break;
+      if (!bit(i)) { op = 0; i--; }
+      else {
+        int l = i - SWIN + 1; if (l < 0) l = 0;
+        while (!bit(l)) l++;
+        int val = 0;
+        for (int k = i; k >= l; k--) val = (val << 1) | bit(k);
+        const int len = i - l + 1;
+        i = l - 1;
+        if (!started) {                            // first window: X = table entry, no squarings
+          started = true;
+          load_limbs_global<G>(X, tab + (val >> 1) * L, g.gl);
+          stageB<G>(g, X);
+          continue;
+        }
+        nsq = len; mulval = val;
+        continue;
+      }
+    }
+    if (op == 0) {
+#pragma unroll
+      for (int k = 0; k < W; k++) T[k] = X[k];
+    } else {
+      load_limbs_global<G>(T, tab + (op >> 1) * L, g.gl);
+    }
+    mmo<G>(g, NT, R, T);
+#pragma unroll
+    for (int k = 0; k < W; k++) X[k] = R[k];
+    stageB<G>(g, X);
+  }
+}
+
+template <int G>
+__device__ __forceinline__ void powm(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst, bool shared_exponent) {
+  if (shared_exponent) powm_sliding<G>(g, X, exp_bits, tab, cst);
+  else powm_fixed<G>(g, X, exp_bits, tab, cst);
 }
 
 // B() := the integer 1
@@ -277,6 +368,18 @@ __global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src,
       stageB<G>(g, X);
     }
   }
+  // MT = M * n1 (Orup multiple, == -1 mod 2^29): lane 0 multiplies the modulus words by the 29-bit n1
+  uint32_t MT[W];
+  {
+    wave_lds_fence();
+    if (g.gl == 0) {
+      uint64_t carry = 0;
+      for (int w = 0; w < NW + 2; w++) { const uint64_t t = (uint64_t)mw[w] * g.n1 + carry; rw[w] = (uint32_t)t; carry = t >> 32; }
+      for (int w = NW + 2; w < NW + 8; w++) rw[w] = 0;
+    }
+    wave_lds_fence();
+    limbs_from_words(MT, rw, g.gl);
+  }
   // X = R^2 mod M (Montgomery form of R).  NR = src * R mod M (Montgomery form of n) for Paillier contexts.
   uint32_t NR[W];
 #pragma unroll
@@ -291,6 +394,7 @@ __global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src,
     store_limbs_global<G>(cst + CL::OFF_R2, X, g.gl);
     store_limbs_global<G>(cst + CL::OFF_R1, R1, g.gl);
     store_limbs_global<G>(cst + CL::OFF_NR, NR, g.gl);
+    store_limbs_global<G>(cst + CL::OFF_MT, MT, g.gl);
     if (g.gl == 0) {
       cst[CL::OFF_NI] = g.n1;
       cst[CL::OFF_ST] = (uint32_t)status;
@@ -341,7 +445,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
     load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
     stageB<G>(g, X);
     mm<G>(g, X, T);
-    powm_window<G>(g, X, a.exp_bits, tab, cst + CL::OFF_R1);
+    powm<G>(g, X, a.exp_bits, tab, cst, a.exp_stride == 0);
     // leave the Montgomery domain: montmul(X, 1) <= M
     stage_one<G>(g);
     mm<G>(g, R, X);
@@ -471,7 +575,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
     load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
     stageB<G>(g, X);
     mm<G>(g, X, T);                                       // r * R
-    powm_window<G>(g, X, a.n_bits, tab, cst + CL::OFF_R1);   // X = r^n * R, staged in B()
+    powm<G>(g, X, a.n_bits, tab, cst, a.n_stride == 0);      // X = r^n * R (mod M, < 2M~), staged in B()
     // mn = m * n mod n^2 : montmul(m, NR); B() must hold NR
     load_limbs_global<G>(T, cst + CL::OFF_NR, g.gl);
     stageB<G>(g, T);

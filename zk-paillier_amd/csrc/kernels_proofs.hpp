@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
     stageB<G>(g, T);
     load_value<G>(g, T, a.sigma + item * kw, kw);
     mm<G>(g, X, T);
-    powm_window<G>(g, X, a.n_bits, tab, cst + CL::OFF_R1);
+    powm_fixed<G>(g, X, a.n_bits, tab, cst);
     stage_one<G>(g);
     mm<G>(g, R, X);
     normalize_exact<G>(R, g.gl);
