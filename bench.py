@@ -69,6 +69,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     ctx = zkp.Context(local_rank)          # raises if the HIP library / a gfx950 GPU is missing
+    lpl = int(zkp.load().zkp_build_limbs_per_lane())
 
     B, n_bits, EF = args.batch, args.n_bits, 128
     kw = n_bits // 32
@@ -159,7 +160,8 @@ def main():
     bytes_per_enc = 4 * kw * 4 + 8
     roofline = {"bound": "valu", "achieved": ach / 1e12, "peak": PEAK_LIMB_MAC_PER_S / 1e12, "unit": "Tlimb-MAC/s",
                 "frac": ach / PEAK_LIMB_MAC_PER_S, "traffic": None,
-                "kernel": "k_enc<16> (fused Enc-and-compare)", "kernel_ms_per_launch": kms / max(launches, 1),
+                "kernel": f"k_enc<{144 // lpl}> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer)",
+                "kernel_ms_per_launch": kms / max(launches, 1),
                 "modexps_per_launch": enc_per_launch,
                 "hbm": {"achieved": modexps * bytes_per_enc / (kms * 1e-3) / 1e9 if kms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
 

@@ -7,7 +7,7 @@
 //     a carry-free one.  With 29-bit limbs a 64-bit column accumulator absorbs 64 products
 //     before it can overflow, so the inner loops are pure v_mad_u64_u32 chains.
 //   * one big integer is spread over a group of G lanes of a wavefront, W limbs per lane
-//     (W = 9 or 18, compile-time ZKP_W); G*W = 72 limbs = 2088 bits (moduli up to 2048 bits:
+//     (W = 18 by default, 9 with -DZKP_W=9); G*W = 72 limbs = 2088 bits (moduli up to 2048 bits:
 //     n, N of the DLog proof), 144 limbs = 4176 bits (n^2 for a 2048-bit n), 288 limbs =
 //     8352 bits (n^2 for a 4096-bit n); a 64-lane wavefront works on 64/G independent
 //     modular exponentiations.
@@ -27,7 +27,7 @@
 namespace zkp {
 
 #ifndef ZKP_W
-#define ZKP_W 9
+#define ZKP_W 18
 #endif
 constexpr int LB = 29;                      // bits per limb
 constexpr int W = ZKP_W;                    // limbs per lane (9 or 18)
@@ -35,9 +35,11 @@ constexpr uint32_t LMASK = (1u << LB) - 1;
 constexpr int BLK = (W + 3) & ~3;           // LDS words per W-limb block (16-B multiple: keeps ds_read_b128 aligned)
 static_assert(W == 9 || W == 18, "limbs per lane");
 // minimum waves per SIMD requested from the register allocator for the modexp-class kernels: the hot
-// loop (montmul) needs ~70 VGPRs at W = 9; values that live across an exponentiation may spill around it
+// loop (montmul) needs ~70 VGPRs at W = 9 and ~150 at W = 18; values that live across an exponentiation
+// may spill around it.  Measured on MI355X (Enc/s at n = 2048): W=9 @5 waves 251 K, W=18 @2 waves 269 K,
+// W=18 @3 waves 265 K — the larger window halves the per-limb overhead instructions per multiply.
 #ifndef ZKP_WPE
-#define ZKP_WPE (ZKP_W == 9 ? 5 : 3)
+#define ZKP_WPE (ZKP_W == 9 ? 5 : 2)
 #endif
 
 template <int G> struct Geo {

@@ -527,20 +527,39 @@ struct EncArgs {
   uint32_t ef;
 };
 
+// stage a constant (this lane's block of a limb array in global memory) as the B operand
+template <int G> __device__ __forceinline__ void stage_const(const Grp<G>& g, const uint32_t* limbs) {
+  uint32_t t[W];
+  load_limbs_global<G>(t, limbs, g.gl);
+  stageB<G>(g, t);
+}
+
+// The kernel body is a short script of Montgomery products around the ladder, executed by ONE loop with ONE
+// generic montmul call site (every inlined montmul copy costs registers, which is what limits W = 18):
+//   s0  X  = r * R2 / R                      (to the Montgomery domain)
+//   s1  X  = X^n                             (ladder: powm)
+//   s2  Y  = m * NR / R = m*n mod n^2 ; Y += 1
+//   s3  Y  = Y * X / R  = (1 + m n) r^n      (plain, < 2M)
+//   s4  Y  = Y * R2 / R ; s5  Y = Y * 1 / R  -> value <= M -> canonical words = c
+//   mode 1 only (expected ciphertext e = c_j[i], or c_j[i] * cipher_x mod n^2 on Mask rows, range_proof.rs:324-328):
+//   s6  Y  = e * R2 / R ; s7  Y = Y * (mask ? cipher_x : 1) / R ; s8  Y = Y * R2 / R ; s9  Y = Y * 1 / R -> canonical
 template <int G>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
-  constexpr int L = Geo<G>::L, NW = LL::NW, KW = NW / 2;
+  constexpr int L = Geo<G>::L, NW = LL::NW;
   extern __shared__ __align__(16) uint32_t lds_raw[];
   Grp<G> g;
   grp_init<G>(g, lds_raw);
   const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
   const uint64_t ngrp = (uint64_t)gridDim.x * LL::GROUPS_PER_BLOCK;
   uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
-  const int kw = a.n_bits / 32;             // <= KW
+  const int kw = a.n_bits / 32;
   const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
   const uint64_t rounds = (count + ngrp - 1) / ngrp;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long gmask = ((1ull << G) - 1) << (lane & ~(G - 1));
+  const int nsteps = a.mode == 0 ? 6 : 10;
   for (uint64_t rd = 0; rd < rounds; rd++) {
     const uint64_t idx = rd * ngrp + ggrp;
     const bool live = idx < count;
@@ -569,68 +588,67 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
     const uint32_t* cst = a.consts + key * a.const_stride;
     const uint32_t* pn = a.n + key * a.n_stride;
     load_modulus_consts<G>(g, cst);
-    uint32_t X[W], R[W], T[W];
-    fetch_words<G>(g, g.expw(), pn, kw);                  // exponent = n
-    load_value<G>(g, T, pr, kw);                          // r (kw words, < 2^n_bits <= n^2)
-    load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
-    stageB<G>(g, X);
-    mm<G>(g, X, T);                                       // r * R
-    powm<G>(g, X, a.n_bits, tab, cst, a.n_stride == 0);      // X = r^n * R (mod M, < 2M~), staged in B()
-    // mn = m * n mod n^2 : montmul(m, NR); B() must hold NR
-    load_limbs_global<G>(T, cst + CL::OFF_NR, g.gl);
-    stageB<G>(g, T);
-    load_value<G>(g, T, pm, kw);
-    mm<G>(g, R, T);                                       // m*n (plain, < 2M)
-    if (g.gl == 0) R[0] += 1;                             // gm = 1 + m*n  (limb 0 stays < 2^29 + 17)
-    stageB<G>(g, X);                                      // B() = r^n * R
-    mm<G>(g, T, R);                                       // gm * r^n  (plain, < 2M)
-    // exact residue: one more pass through the domain (T*R2/R then *1/R) gives a value <= M
-    load_limbs_global<G>(R, cst + CL::OFF_R2, g.gl);
-    stageB<G>(g, R);
-    mm<G>(g, X, T);
-    stage_one<G>(g);
-    mm<G>(g, R, X);
-    canonical_words<G>(g, R, cst + CL::OFF_N);            // words()[0..NW) = c
     const bool valid = cst[CL::OFF_ST] == 0;
-    if (a.mode == 0) {
-      if (live) {
-        for (int w = g.gl; w < 2 * kw; w += G) a.out[item * 2 * kw + w] = valid ? g.words()[w] : 0u;
-      }
-    } else {
-      // keep c as limbs for the comparison
-      uint32_t C[W];
-      limbs_from_words(C, g.words(), g.gl);
-      uint32_t E[W];
-      load_value<G>(g, E, pexp, 2 * kw);                  // expected c_j[i]  (may be >= n^2 for a forged proof)
-      // bring the expected value to its canonical residue: (cj [* cipher_x]) mod n^2
-      load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
-      stageB<G>(g, T);
-      mm<G>(g, R, E);                                     // cj * R
-      if (mask_row) {
-        load_value<G>(g, T, a.cipher_x + b * 2 * kw, 2 * kw);
-        stageB<G>(g, T);
-        mm<G>(g, E, R);                                   // cj * cipher_x  (< 2M)
-        load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
-        stageB<G>(g, T);
-        mm<G>(g, R, E);                                   // * R
-      }
-      stage_one<G>(g);
-      mm<G>(g, E, R);
-      canonical_words<G>(g, E, cst + CL::OFF_N);
-      // NOTE: the reference compares c with c_j[i] itself on Open rows (no reduction of c_j):
-      // a non-canonical c_j >= n^2 can never equal a residue, so it must not match here either.
-      bool same = true;
+    uint32_t X[W], Y[W], A[W], R[W];
 #pragma unroll
-      for (int k = 0; k < W; k++) same = same && (C[k] == E[k]);
-      if (!mask_row) {
-        // Open rows: expected must be canonical already: compare raw words of c_j with the residue words
-        const uint32_t* ww = g.words();                   // canonical residue of c_j
-        for (int w = g.gl; w < 2 * kw; w += G) same = same && (ww[w] == pexp[w]);
+    for (int k = 0; k < W; k++) { X[k] = 0; Y[k] = 0; }
+#pragma unroll 1
+    for (int s = 0; s < nsteps; s++) {
+      if (s == 1) {
+        fetch_words<G>(g, g.expw(), pn, kw);                         // exponent = n
+        powm<G>(g, X, a.n_bits, tab, cst, a.n_stride == 0);
+        continue;
       }
-      const unsigned long long mk = __ballot(same);
-      const int lane = threadIdx.x & 63;
-      const unsigned long long gm = ((G == 64) ? ~0ull : ((1ull << G) - 1)) << (lane & ~(G - 1));
-      if (live && g.gl == 0 && !(valid && (mk & gm) == gm)) a.verdict[b] = ZKP_VERDICT_REJECT;
+      // ---- operands
+      if (s == 0) { load_value<G>(g, A, pr, kw); stage_const<G>(g, cst + CL::OFF_R2); }
+      else if (s == 2) { load_value<G>(g, A, pm, kw); stage_const<G>(g, cst + CL::OFF_NR); }
+      else if (s == 6) { load_value<G>(g, A, pexp, 2 * kw); stage_const<G>(g, cst + CL::OFF_R2); }
+      else {
+#pragma unroll
+        for (int k = 0; k < W; k++) A[k] = Y[k];
+        if (s == 3) stageB<G>(g, X);
+        else if (s == 4 || s == 8) stage_const<G>(g, cst + CL::OFF_R2);
+        else if (s == 7) {
+          uint32_t t[W];
+          load_value<G>(g, t, a.cipher_x + b * 2 * kw, mask_row ? 2 * kw : 0);   // Open rows: value 0 ...
+          if (!mask_row && g.gl == 0) t[0] = 1;                                    // ... turned into the integer 1
+          stageB<G>(g, t);
+        } else stage_one<G>(g);                                        // s == 5, 9
+      }
+      mm<G>(g, R, A);
+      // ---- results
+      if (s == 0) {
+#pragma unroll
+        for (int k = 0; k < W; k++) X[k] = R[k];
+        continue;
+      }
+#pragma unroll
+      for (int k = 0; k < W; k++) Y[k] = R[k];
+      if (s == 2 && g.gl == 0) Y[0] += 1;                              // gm = 1 + m*n (limb 0 stays < 2^29 + 17)
+      if (s == 5) {
+        canonical_words<G>(g, Y, cst + CL::OFF_N);                     // words()[0..NW) = c
+        if (a.mode == 0) {
+          if (live) for (int w = g.gl; w < 2 * kw; w += G) a.out[item * 2 * kw + w] = valid ? g.words()[w] : 0u;
+        } else {
+          // keep c in the (now free) exponent area for the final comparison
+          wave_lds_fence();
+          for (int w = g.gl; w < NW; w += G) g.expw()[w] = g.words()[w];
+          wave_lds_fence();
+        }
+      }
+      if (s == 9) {
+        canonical_words<G>(g, Y, cst + CL::OFF_N);                     // words() = canonical residue of the expected value
+        // The reference compares c with c_j[i] itself on Open rows (no reduction): a non-canonical c_j >= n^2 can
+        // never equal a residue, so besides residue equality the raw words of c_j must equal their own residue.
+        bool same = true;
+        for (int w = g.gl; w < NW; w += G) {
+          const uint32_t e = g.words()[w];
+          same = same && (e == g.expw()[w]);
+          if (!mask_row && w < 2 * kw) same = same && (e == pexp[w]);
+        }
+        const unsigned long long mk = __ballot(same);
+        if (live && g.gl == 0 && !(valid && (mk & gmask) == gmask)) a.verdict[b] = ZKP_VERDICT_REJECT;
+      }
     }
   }
 }

@@ -182,6 +182,7 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) {
 }
 
 extern "C" const char* zkp_backend_name(void) { return "hip-gfx950"; }
+extern "C" int32_t zkp_build_limbs_per_lane(void) { return W; }
 extern "C" const char* zkp_last_error_string(zkp_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 extern "C" void* zkp_ctx_stream(zkp_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int32_t zkp_ctx_synchronize(zkp_ctx* c) {
