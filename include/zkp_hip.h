@@ -171,6 +171,34 @@ int32_t zkp_dlog_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint32_t y_bits, ui
                               const uint32_t* x, const uint32_t* y, uint8_t* out_verdict,
                               uint32_t flags);
 
+/* ------------------------------------------------------------------ ZeroProof / CiphertextProof
+ * (single-shot sigma proofs composed from the same kernels.)
+ * ZeroProof (src/zkproofs/zero_enc_proof.rs:26-95): c = r^n mod n^2 encrypts zero.
+ *   prove : a = Enc(0, r'), e = H(n || c || a), z = r' * r^e mod n^2           (:44-64)
+ *   verify: Enc(0, z) == c^e * a mod n^2                                        (:66-94)
+ * n: [B or 1][kw]; c, z, a: [B][2kw]; r, r_prime: [B][kw] (r' is sampled by the caller:
+ * BigInt::sample_below(n), :45). */
+int32_t zkp_zero_proof_prove_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride,
+                                   const uint32_t* c, const uint32_t* r, const uint32_t* r_prime, uint32_t* out_z,
+                                   uint32_t* out_a, uint32_t flags);
+int32_t zkp_zero_proof_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride,
+                                    const uint32_t* c, const uint32_t* z, const uint32_t* a, uint8_t* out_verdict,
+                                    uint32_t flags);
+
+/* CiphertextProof (src/zkproofs/correct_ciphertext.rs:23-98): knowledge of (x, r) with c = Enc(x, r).
+ *   prove : c' = Enc(x', r'), e = H(n || c || c'), z1 = x' + x*e (over Z), z2 = r' * r^e mod n^2   (:42-64)
+ *   verify: Enc(z1, z2) == c^e * c' mod n^2                                                          (:66-97)
+ * x, r, x_prime, r_prime: [B][kw]; z1: [B][kw + ZKP_Z1_EXTRA_LIMBS] (x' + x*e < 2^(n_bits+257));
+ * c, z2, c_prime: [B][2kw]. */
+#define ZKP_Z1_EXTRA_LIMBS 16
+int32_t zkp_ciphertext_proof_prove_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride,
+                                         const uint32_t* c, const uint32_t* x, const uint32_t* r, const uint32_t* x_prime,
+                                         const uint32_t* r_prime, uint32_t* out_z1, uint32_t* out_z2, uint32_t* out_c_prime,
+                                         uint32_t flags);
+int32_t zkp_ciphertext_proof_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride,
+                                          const uint32_t* c, const uint32_t* z1, const uint32_t* z2, const uint32_t* c_prime,
+                                          uint8_t* out_verdict, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

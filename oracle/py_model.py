@@ -282,3 +282,36 @@ def dlog_verify(x, y, N, g, ni) -> bool:
 FIXTURE_P = 148677972634832330983979593310074301486537017973460461278300587514468301043894574906886127642530475786889672304776052879927627556769456140664043088700743909632312483413393134504352834240399191134336344285483935856491230340093391784574980688823380828143810804684752914935441384845195613674104960646037368551517
 FIXTURE_Q = 158741574437007245654463598139927898730476924736461654463975966787719309357536545869203069369466212089132653564188443272208127277664424448947476335413293018778018615899291704693105620242763173357203898195318179150836424196645745308205164116144020613415407736216097185962171301808761138424668335445923774195463
 FIXTURE_N = FIXTURE_P * FIXTURE_Q
+
+
+# ----------------------------------------------------------------------------- ZeroProof / CiphertextProof
+
+def zero_proof_prove(n, c, r, r_prime):
+    """zero_enc_proof.rs:44-64 with r' injected (:45 samples it below n)."""
+    nn = n * n
+    a = enc(n, 0, r_prime)
+    e = compute_digest([n, c, a])
+    z = (r_prime * pow(r, e, nn)) % nn
+    return z, a
+
+
+def zero_proof_verify(n, c, z, a) -> bool:
+    """zero_enc_proof.rs:66-94; [upstream] Paillier::mul = c^e mod nn, Paillier::add = product mod nn."""
+    nn = n * n
+    e = compute_digest([n, c, a])
+    return enc(n, 0, z) == (pow(c, e, nn) * a) % nn
+
+
+def ciphertext_proof_prove(n, c, x, r, x_prime, r_prime):
+    """correct_ciphertext.rs:42-64 with (x', r') injected."""
+    nn = n * n
+    c_prime = enc(n, x_prime, r_prime)
+    e = compute_digest([n, c, c_prime])
+    return x_prime + x * e, (r_prime * pow(r, e, nn)) % nn, c_prime
+
+
+def ciphertext_proof_verify(n, c, z1, z2, c_prime) -> bool:
+    """correct_ciphertext.rs:66-97."""
+    nn = n * n
+    e = compute_digest([n, c, c_prime])
+    return enc(n, z1, z2) == (pow(c, e, nn) * c_prime) % nn

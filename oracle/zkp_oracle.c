@@ -579,3 +579,86 @@ int32_t oracle_fs_challenge(uint32_t n_bits, uint32_t ef, const uint32_t* n, con
   mpz_clear(zn);
   return 0;
 }
+
+/* ------------------------------------------------------------------ ZeroProof / CiphertextProof
+ * [upstream kzen-paillier] Paillier::mul(ek, m, c) = c^m mod nn ; Paillier::add(ek, c1, c2) = c1*c2 mod nn. */
+static void sigma_challenge(mpz_t e, const mpz_t n, const mpz_t c, const mpz_t a) {
+  mpz_t it[3];
+  mpz_init_set(it[0], n); mpz_init_set(it[1], c); mpz_init_set(it[2], a);
+  compute_digest(e, (const mpz_t*)it, 3); /* zero_enc_proof.rs:54-58,67-71 ; correct_ciphertext.rs:53-57,67-71 */
+  mpz_clears(it[0], it[1], it[2], NULL);
+}
+
+/* with_x = 0: ZeroProof::prove (zero_enc_proof.rs:44-64); with_x = 1: CiphertextProof::prove (correct_ciphertext.rs:42-64) */
+static int32_t sigma_prove(int with_x, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* c,
+                           const uint32_t* x, const uint32_t* r, const uint32_t* x_prime, const uint32_t* r_prime, uint32_t* out_z1,
+                           uint32_t* out_z, uint32_t* out_commit) {
+  const size_t kw = n_bits / 32, z1w = kw + ZKP_Z1_EXTRA_LIMBS;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int64_t b = 0; b < (int64_t)batch; b++) {
+    mpz_t zn, znn, zc, zr, zrp, zx, zxp, com, e, t, u;
+    mpz_inits(zn, znn, zc, zr, zrp, zx, zxp, com, e, t, u, NULL);
+    limbs_to_mpz(zn, n + b * n_stride, kw);
+    mpz_mul(znn, zn, zn);
+    limbs_to_mpz(zc, c + b * 2 * kw, 2 * kw);
+    limbs_to_mpz(zr, r + b * kw, kw);
+    limbs_to_mpz(zrp, r_prime + b * kw, kw);
+    if (with_x) { limbs_to_mpz(zx, x + b * kw, kw); limbs_to_mpz(zxp, x_prime + b * kw, kw); }
+    enc_mpz(com, zn, znn, zxp, zrp, u);            /* a = Enc(0, r') / c' = Enc(x', r') */
+    sigma_challenge(e, zn, zc, com);
+    if (with_x) {
+      mpz_mul(t, zx, e);
+      mpz_add(t, t, zxp);                          /* z1 = x' + x*e  (correct_ciphertext.rs:59) */
+      mpz_to_limbs(out_z1 + b * z1w, z1w, t);
+    }
+    mpz_powm(t, zr, e, znn);                       /* r^e mod nn */
+    mpz_mul(t, t, zrp);
+    mpz_mod(t, t, znn);                            /* mod_mul(r', r^e, nn) */
+    mpz_to_limbs(out_z + b * 2 * kw, 2 * kw, t);
+    mpz_to_limbs(out_commit + b * 2 * kw, 2 * kw, com);
+    mpz_clears(zn, znn, zc, zr, zrp, zx, zxp, com, e, t, u, NULL);
+  }
+  return 0;
+}
+
+static int32_t sigma_verify(int with_z1, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* c,
+                            const uint32_t* z1, const uint32_t* z, const uint32_t* commit, uint8_t* out_verdict) {
+  const size_t kw = n_bits / 32, z1w = kw + ZKP_Z1_EXTRA_LIMBS;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int64_t b = 0; b < (int64_t)batch; b++) {
+    mpz_t zn, znn, zc, zz1, zz, com, e, cz, t, u;
+    mpz_inits(zn, znn, zc, zz1, zz, com, e, cz, t, u, NULL);
+    limbs_to_mpz(zn, n + b * n_stride, kw);
+    mpz_mul(znn, zn, zn);
+    limbs_to_mpz(zc, c + b * 2 * kw, 2 * kw);
+    if (with_z1) limbs_to_mpz(zz1, z1 + b * z1w, z1w);
+    limbs_to_mpz(zz, z + b * 2 * kw, 2 * kw);
+    limbs_to_mpz(com, commit + b * 2 * kw, 2 * kw);
+    sigma_challenge(e, zn, zc, com);
+    enc_mpz(cz, zn, znn, zz1, zz, u);              /* c_z = Enc(z1 | 0, z) */
+    mpz_powm(t, zc, e, znn);                       /* Paillier::mul: c^e */
+    mpz_mul(t, t, com);
+    mpz_mod(t, t, znn);                            /* Paillier::add: * a */
+    out_verdict[b] = mpz_cmp(cz, t) == 0 ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
+    mpz_clears(zn, znn, zc, zz1, zz, com, e, cz, t, u, NULL);
+  }
+  return 0;
+}
+
+int32_t oracle_zero_proof_prove_batch(uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* c,
+                                      const uint32_t* r, const uint32_t* r_prime, uint32_t* out_z, uint32_t* out_a) {
+  return sigma_prove(0, n_bits, batch, n, n_stride, c, NULL, r, NULL, r_prime, NULL, out_z, out_a);
+}
+int32_t oracle_zero_proof_verify_batch(uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* c,
+                                       const uint32_t* z, const uint32_t* a, uint8_t* out_verdict) {
+  return sigma_verify(0, n_bits, batch, n, n_stride, c, NULL, z, a, out_verdict);
+}
+int32_t oracle_ciphertext_proof_prove_batch(uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* c,
+                                            const uint32_t* x, const uint32_t* r, const uint32_t* x_prime, const uint32_t* r_prime,
+                                            uint32_t* out_z1, uint32_t* out_z2, uint32_t* out_c_prime) {
+  return sigma_prove(1, n_bits, batch, n, n_stride, c, x, r, x_prime, r_prime, out_z1, out_z2, out_c_prime);
+}
+int32_t oracle_ciphertext_proof_verify_batch(uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* c,
+                                             const uint32_t* z1, const uint32_t* z2, const uint32_t* c_prime, uint8_t* out_verdict) {
+  return sigma_verify(1, n_bits, batch, n, n_stride, c, z1, z2, c_prime, out_verdict);
+}

@@ -138,6 +138,36 @@ static void test_bad_dlog_proof_2() {   // :172-196 #[should_panic]
   ASSERT(proof.verify(st).is_ok());
 }
 
+// ---- zero_enc_proof.rs tests (:112-155) and correct_ciphertext.rs tests (:113-162); fixture key instead of keygen
+static void test_zero_proof() {
+  auto [ek, dk] = test_keypair().keys();
+  BigInt r = BigInt::sample_below(ek.n);
+  BigInt c = Paillier::encrypt_with_chosen_randomness(ek, BigInt::zero(), r);
+  ZeroProof proof = ZeroProof::prove(ZeroWitness{r}, ZeroStatement{ek, c});
+  ASSERT(proof.verify(ZeroStatement{ek, c}).is_ok());
+}
+static void test_one_proof() {   // #[should_panic]: c encrypts 1
+  auto [ek, dk] = test_keypair().keys();
+  BigInt r = BigInt::sample_below(ek.n);
+  BigInt c = Paillier::encrypt_with_chosen_randomness(ek, BigInt::one(), r);
+  ZeroProof proof = ZeroProof::prove(ZeroWitness{r}, ZeroStatement{ek, c});
+  ASSERT(proof.verify(ZeroStatement{ek, c}).is_ok());
+}
+static void test_ciphertext_proof() {
+  auto [ek, dk] = test_keypair().keys();
+  BigInt x = BigInt::sample_below(ek.n), r = BigInt::sample_below(ek.n);
+  BigInt c = Paillier::encrypt_with_chosen_randomness(ek, x, r);
+  CiphertextProof proof = CiphertextProof::prove(CiphertextWitness{x, r}, CiphertextStatement{ek, c});
+  ASSERT(proof.verify(CiphertextStatement{ek, c}).is_ok());
+}
+static void test_bad_ciphertext_proof() {   // #[should_panic]: witness r + 1
+  auto [ek, dk] = test_keypair().keys();
+  BigInt x = BigInt::sample_below(ek.n), r = BigInt::sample_below(ek.n);
+  BigInt c = Paillier::encrypt_with_chosen_randomness(ek, x, r);
+  CiphertextProof proof = CiphertextProof::prove(CiphertextWitness{x, r + BigInt::one()}, CiphertextStatement{ek, c});
+  ASSERT(proof.verify(CiphertextStatement{ek, c}).is_ok());
+}
+
 int main() {
   run("range_proof_ni::test_prover", test_prover);
   run("range_proof_ni::test_verifier_for_correct_proof", test_verifier_for_correct_proof);
@@ -149,6 +179,10 @@ int main() {
   run("wi_dlog_proof::test_correct_dlog_proof", test_correct_dlog_proof);
   run("wi_dlog_proof::test_bad_dlog_proof", test_bad_dlog_proof, true);
   run("wi_dlog_proof::test_bad_dlog_proof_2", test_bad_dlog_proof_2, true);
+  run("zero_enc_proof::test_zero_proof", test_zero_proof);
+  run("zero_enc_proof::test_one_proof", test_one_proof, true);
+  run("correct_ciphertext::test_ciphertext_proof", test_ciphertext_proof);
+  run("correct_ciphertext::test_bad_ciphertext_proof", test_bad_ciphertext_proof, true);
   std::printf("%d failure(s)\n", failures);
   return failures ? 1 : 0;
 }

@@ -106,3 +106,29 @@ class Oracle:
         elen = C.c_uint8()
         self.lib.oracle_fs_challenge(C.c_uint32(n_bits), C.c_uint32(ef), p(n), p(c1), p(c2), p(e), C.byref(elen))
         return bytes(e[:elen.value])
+
+    # ---- ZeroProof / CiphertextProof
+    def zero_proof_prove(self, n_bits, n, n_stride, c, r, r_prime):
+        B = c.shape[0]
+        z = np.zeros_like(c); a = np.zeros_like(c)
+        self.lib.oracle_zero_proof_prove_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(c), p(r), p(r_prime), p(z), p(a))
+        return z, a
+
+    def zero_proof_verify(self, n_bits, n, n_stride, c, z, a):
+        B = c.shape[0]
+        v = np.zeros(B, np.uint8)
+        self.lib.oracle_zero_proof_verify_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(c), p(z), p(a), p(v))
+        return v
+
+    def ciphertext_proof_prove(self, n_bits, n, n_stride, c, x, r, x_prime, r_prime):
+        B = c.shape[0]
+        z1 = np.zeros((B, n_bits // 32 + 16), np.uint32); z2 = np.zeros_like(c); cp = np.zeros_like(c)
+        self.lib.oracle_ciphertext_proof_prove_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(c), p(x), p(r), p(x_prime),
+                                                     p(r_prime), p(z1), p(z2), p(cp))
+        return z1, z2, cp
+
+    def ciphertext_proof_verify(self, n_bits, n, n_stride, c, z1, z2, c_prime):
+        B = c.shape[0]
+        v = np.zeros(B, np.uint8)
+        self.lib.oracle_ciphertext_proof_verify_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(c), p(z1), p(z2), p(c_prime), p(v))
+        return v

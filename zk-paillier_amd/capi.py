@@ -64,8 +64,17 @@ EXPORTS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_dlog_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_zero_proof_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_zero_proof_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_uint32]),
+    "zkp_ciphertext_proof_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_ciphertext_proof_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.c_uint32]),
 }
 
+Z1_EXTRA_LIMBS = 16
 _lib = None
 
 
@@ -188,3 +197,19 @@ class Context:
     def dlog_verify(self, n_bits, y_bits, batch, N, g, ni, x, y, out_verdict):
         self.check(self.lib.zkp_dlog_verify_batch(self.h, n_bits, y_bits, batch, ptr(N), ptr(g), ptr(ni), ptr(x),
                                                   ptr(y), ptr(out_verdict), self._flags(N, g, ni, x, y, out_verdict)))
+
+    def zero_proof_prove(self, n_bits, batch, n, n_stride, c, r, r_prime, out_z, out_a):
+        self.check(self.lib.zkp_zero_proof_prove_batch(self.h, n_bits, batch, ptr(n), n_stride, ptr(c), ptr(r), ptr(r_prime), ptr(out_z), ptr(out_a),
+                                                       self._flags(n, c, r, r_prime, out_z, out_a)))
+
+    def zero_proof_verify(self, n_bits, batch, n, n_stride, c, z, a, out_verdict):
+        self.check(self.lib.zkp_zero_proof_verify_batch(self.h, n_bits, batch, ptr(n), n_stride, ptr(c), ptr(z), ptr(a), ptr(out_verdict),
+                                                        self._flags(n, c, z, a, out_verdict)))
+
+    def ciphertext_proof_prove(self, n_bits, batch, n, n_stride, c, x, r, x_prime, r_prime, out_z1, out_z2, out_c_prime):
+        self.check(self.lib.zkp_ciphertext_proof_prove_batch(self.h, n_bits, batch, ptr(n), n_stride, ptr(c), ptr(x), ptr(r), ptr(x_prime), ptr(r_prime),
+                                                             ptr(out_z1), ptr(out_z2), ptr(out_c_prime), self._flags(n, c, x, r, out_z1)))
+
+    def ciphertext_proof_verify(self, n_bits, batch, n, n_stride, c, z1, z2, c_prime, out_verdict):
+        self.check(self.lib.zkp_ciphertext_proof_verify_batch(self.h, n_bits, batch, ptr(n), n_stride, ptr(c), ptr(z1), ptr(z2), ptr(c_prime),
+                                                              ptr(out_verdict), self._flags(n, c, z1, z2, c_prime, out_verdict)))

@@ -414,7 +414,8 @@ struct ModexpArgs {
   uint32_t* table;          // [resident groups][32*L]
   uint64_t count;
   int exp_bits;
-  int io_words;             // words per base / out element (<= NW; values are zero-extended)
+  int io_words;             // words per base element (<= NW; values are zero-extended)
+  int out_words;            // words per out element
 };
 
 template <int G>
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
     mm<G>(g, R, X);
     canonical_words<G>(g, R, cst + CL::OFF_N);
     if (live && cst[CL::OFF_ST] == 0) {
-      for (int w = g.gl; w < a.io_words; w += G) a.out[item * a.io_words + w] = g.words()[w];
+      for (int w = g.gl; w < a.out_words; w += G) a.out[item * a.out_words + w] = g.words()[w];
     }
   }
 }
@@ -460,7 +461,8 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
 // Modular multiplication out = a*b mod M (same machinery, two Montgomery products)
 struct ModmulArgs {
   const uint32_t* a; const uint32_t* b; const uint32_t* consts; uint64_t const_stride; uint32_t* out; uint64_t count;
-  int io_words;
+  int io_words;             // words per out element (and per a / b element unless overridden below)
+  int a_words = 0, b_words = 0;
 };
 template <int G>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_modmul(ModmulArgs a) {
@@ -476,11 +478,12 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modmul(ModmulArgs a) {
   const uint32_t* cst = a.consts + item * a.const_stride;
   load_modulus_consts<G>(g, cst);
   uint32_t X[W], Y[W], R[W];
-  load_value<G>(g, X, a.a + item * a.io_words, a.io_words);
+  const int aw = a.a_words ? a.a_words : a.io_words, bw = a.b_words ? a.b_words : a.io_words;
+  load_value<G>(g, X, a.a + item * aw, aw);
   load_limbs_global<G>(Y, cst + CL::OFF_R2, g.gl);
   stageB<G>(g, Y);
   mm<G>(g, R, X);                         // a*R
-  load_value<G>(g, Y, a.b + item * a.io_words, a.io_words);
+  load_value<G>(g, Y, a.b + item * bw, bw);
   stageB<G>(g, Y);
   mm<G>(g, X, R);                         // a*b  (< M + eps, value may equal a multiple? a*b*R/R reduced: <= M)
   // X < 2M possible when b >= M: force through montmul(.,1) after re-entering the domain is overkill;
@@ -516,6 +519,7 @@ struct EncArgs {
   int mode;
   // mode 0: item i -> m[i], r[i], out[i]; key index = i / items_per_key
   const uint32_t* m; const uint32_t* r; uint32_t* out; uint64_t items_per_key;
+  int m_words, r_words;         // mode 0: words per m / r element (0 = n_bits/32; m may be null when m_words < 0: m = 0)
   // mode 1: item list
   const uint32_t* item_proof;   // [count] proof index b
   const uint32_t* item_row;     // [count] (row << 1) | which   (which: 0 -> (w1,r1,c1), 1 -> (w2,r2,c2))
@@ -569,10 +573,13 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
     const uint32_t* pexp = nullptr;       // expected ciphertext (mode 1)
     bool mask_row = false;
     uint64_t b = 0;
+    int mw = kw, rw_ = kw;
     if (a.mode == 0) {
       key = item / a.items_per_key;
-      pm = a.m + item * kw;
-      pr = a.r + item * kw;
+      mw = a.m_words < 0 ? 0 : (a.m_words ? a.m_words : kw);
+      rw_ = a.r_words ? a.r_words : kw;
+      pm = a.m + item * mw;
+      pr = a.r + item * rw_;
     } else {
       b = a.item_proof[item];
       const uint32_t rw = a.item_row[item];
@@ -600,8 +607,8 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
         continue;
       }
       // ---- operands
-      if (s == 0) { load_value<G>(g, A, pr, kw); stage_const<G>(g, cst + CL::OFF_R2); }
-      else if (s == 2) { load_value<G>(g, A, pm, kw); stage_const<G>(g, cst + CL::OFF_NR); }
+      if (s == 0) { load_value<G>(g, A, pr, rw_); stage_const<G>(g, cst + CL::OFF_R2); }
+      else if (s == 2) { load_value<G>(g, A, pm, mw); stage_const<G>(g, cst + CL::OFF_NR); }
       else if (s == 6) { load_value<G>(g, A, pexp, 2 * kw); stage_const<G>(g, cst + CL::OFF_R2); }
       else {
 #pragma unroll

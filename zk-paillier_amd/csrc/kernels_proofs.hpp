@@ -486,4 +486,58 @@ __global__ void __launch_bounds__(256) k_dlog_compare(DlogCmpArgs a) {
   if (!same) a.verdict[b] = ZKP_VERDICT_REJECT;
 }
 
+// ------------------------------------------------------------------------------------------
+// ZeroProof / CiphertextProof (zero_enc_proof.rs:44-94, correct_ciphertext.rs:42-97):
+// e = H(n || c || a) per proof (a = the commitment: ZeroProof.a / CiphertextProof.c_prime), optionally
+// z1 = x' + x*e over the integers (correct_ciphertext.rs:59).
+struct SigmaHashArgs {
+  const uint32_t* n; uint64_t n_stride; const uint32_t* c; const uint32_t* a;
+  uint32_t kw; uint64_t batch;
+  uint32_t* e;                                   // [B][8]
+  const uint32_t* x; const uint32_t* x_prime; uint32_t* z1; uint32_t z1w;   // nullable
+};
+
+__global__ void __launch_bounds__(256) k_sigma_hash(SigmaHashArgs a) {
+  __shared__ uint32_t shabuf[16 * 256];
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.batch) return;
+  const int kw = (int)a.kw;
+  Sha256 s;
+  s.init(shabuf + threadIdx.x, 256);
+  s.put_bigint(a.n + b * a.n_stride, kw);
+  s.put_bigint(a.c + b * 2 * kw, 2 * kw);
+  s.put_bigint(a.a + b * 2 * kw, 2 * kw);
+  uint32_t d[8], e[8];
+  s.finish(d);
+#pragma unroll
+  for (int k = 0; k < 8; k++) { e[k] = d[7 - k]; a.e[b * 8 + k] = e[k]; }
+  if (a.z1) {
+    // z1 = x' + x * e : (kw x 8)-word product, row by row straight into the output words
+    const uint32_t* x = a.x + b * kw;
+    const uint32_t* xp = a.x_prime + b * kw;
+    uint32_t* z = a.z1 + b * a.z1w;
+    for (uint32_t w = 0; w < a.z1w; w++) z[w] = w < (uint32_t)kw ? xp[w] : 0u;
+    for (int i = 0; i < 8; i++) {
+      uint64_t carry = 0;
+      for (int j = 0; j < kw; j++) {
+        const uint64_t t = (uint64_t)e[i] * x[j] + z[i + j] + carry;
+        z[i + j] = (uint32_t)t; carry = t >> 32;
+      }
+      for (uint32_t w = i + kw; carry && w < a.z1w; w++) { const uint64_t t = (uint64_t)z[w] + carry; z[w] = (uint32_t)t; carry = t >> 32; }
+    }
+  }
+}
+
+// verdict[b] = (lhs[b] == rhs[b]) word for word (`c_z == c_z_test`, zero_enc_proof.rs:90, correct_ciphertext.rs:93)
+struct WordsCmpArgs { const uint32_t* lhs; const uint32_t* rhs; const uint32_t* consts; uint64_t const_stride; int st_off; uint32_t words; uint64_t batch; uint8_t* verdict; };
+__global__ void __launch_bounds__(256) k_words_compare(WordsCmpArgs a) {
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.batch) return;
+  bool same = true;
+  for (uint32_t w = 0; w < a.words; w++) same = same && a.lhs[b * a.words + w] == a.rhs[b * a.words + w];
+  uint8_t v = same ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
+  if (a.consts[b * a.const_stride + a.st_off] != 0) v = ZKP_VERDICT_MALFORMED;   // even key: Montgomery path undefined
+  a.verdict[b] = v;
+}
+
 }  // namespace zkp

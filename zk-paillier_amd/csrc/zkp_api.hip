@@ -220,13 +220,13 @@ extern "C" int32_t zkp_timing_get(zkp_ctx* c, double* ms, uint64_t* launches, ui
 // modexp over constants that are already set up in c->consts (per-item when const_stride != 0)
 template <int G>
 static int32_t modexp_core(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const uint32_t* base, const uint32_t* exp, uint64_t exp_stride,
-                           bool per_item_mod, uint32_t* out, int io_words) {
+                           bool per_item_mod, uint32_t* out, int io_words, int out_words = 0) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
   unsigned blocks = 0;
   int32_t st;
   if ((st = table_for<G>(c, k_modexp<G>, count, &blocks))) return st;
-  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words};
+  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words, out_words ? out_words : io_words};
   {
     TimedRegion tr(c, count);
     hipLaunchKernelGGL(k_modexp<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);

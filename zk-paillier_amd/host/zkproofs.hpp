@@ -10,6 +10,8 @@
 //     src/zkproofs/correct_key_ni.rs:36-100
 //   zkproofs::{CompositeDLogProof,DLogStatement}::{prove,verify}    same
 //     src/zkproofs/wi_dlog_proof.rs:33-91
+//   zkproofs::{ZeroProof,ZeroStatement,ZeroWitness}                 same (zero_enc_proof.rs:26-95)
+//   zkproofs::{CiphertextProof,CiphertextStatement,CiphertextWitness} same (correct_ciphertext.rs:23-98)
 //   paillier::{Keypair,EncryptionKey,DecryptionKey,Paillier}        same names, only what the path needs
 //   zkproofs::IncorrectProof (errors.rs:5-13)                       Result<> with is_ok()/is_err()/expect()
 //
@@ -345,6 +347,60 @@ class CompositeDLogProof {
     uint8_t v = 9;
     e.check(zkp_dlog_verify_batch(e.ctx(), nb, Y_BITS, 1, N.data(), g.data(), ni.data(), xx.data(), yy.data(), &v, 0), "zkp_dlog_verify_batch");
     if (v == ZKP_VERDICT_MALFORMED) throw Panic("assertion failed in CompositeDLogProof::verify (N > 2^128, gcd(g,N) = gcd(ni,N) = 1)");   // :69,72,73
+    return Result(v == ZKP_VERDICT_ACCEPT);
+  }
+};
+
+// ------------------------------------------------------------------ ZeroProof (src/zkproofs/zero_enc_proof.rs:26-95)
+struct ZeroWitness { BigInt r; };
+struct ZeroStatement { EncryptionKey ek; BigInt c; };
+class ZeroProof {
+ public:
+  BigInt z, a;
+  static ZeroProof prove(const ZeroWitness& w, const ZeroStatement& st) {   // :44-64
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.ek.n), kw = nb / 32;
+    const BigInt r_prime = BigInt::sample_below(st.ek.n);                     // :45
+    std::vector<uint32_t> n(kw), c(2 * kw), r(kw), rp(kw), z(2 * kw), a(2 * kw);
+    st.ek.n.to_limbs(n.data(), kw); st.c.to_limbs(c.data(), 2 * kw); (w.r % st.ek.nn).to_limbs(r.data(), kw); r_prime.to_limbs(rp.data(), kw);
+    e.check(zkp_zero_proof_prove_batch(e.ctx(), nb, 1, n.data(), 0, c.data(), r.data(), rp.data(), z.data(), a.data(), 0), "zkp_zero_proof_prove_batch");
+    return ZeroProof{BigInt::from_limbs(z.data(), 2 * kw), BigInt::from_limbs(a.data(), 2 * kw)};
+  }
+  Result verify(const ZeroStatement& st) const {                             // :66-94
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.ek.n), kw = nb / 32;
+    std::vector<uint32_t> n(kw), c(2 * kw), zz(2 * kw), aa(2 * kw);
+    st.ek.n.to_limbs(n.data(), kw); st.c.to_limbs(c.data(), 2 * kw); z.to_limbs(zz.data(), 2 * kw); a.to_limbs(aa.data(), 2 * kw);
+    uint8_t v = 9;
+    e.check(zkp_zero_proof_verify_batch(e.ctx(), nb, 1, n.data(), 0, c.data(), zz.data(), aa.data(), &v, 0), "zkp_zero_proof_verify_batch");
+    return Result(v == ZKP_VERDICT_ACCEPT);
+  }
+};
+
+// ------------------------------------------------------------------ CiphertextProof (src/zkproofs/correct_ciphertext.rs:23-98)
+struct CiphertextWitness { BigInt x, r; };
+struct CiphertextStatement { EncryptionKey ek; BigInt c; };
+class CiphertextProof {
+ public:
+  BigInt z1, z2, c_prime;
+  static CiphertextProof prove(const CiphertextWitness& w, const CiphertextStatement& st) {   // :42-64
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.ek.n), kw = nb / 32, z1w = kw + ZKP_Z1_EXTRA_LIMBS;
+    const BigInt x_prime = BigInt::sample_below(st.ek.n), r_prime = BigInt::sample_below(st.ek.n);   // :43-44
+    std::vector<uint32_t> n(kw), c(2 * kw), x(kw), r(kw), xp(kw), rp(kw), o1(z1w), o2(2 * kw), oc(2 * kw);
+    st.ek.n.to_limbs(n.data(), kw); st.c.to_limbs(c.data(), 2 * kw); w.x.to_limbs(x.data(), kw); w.r.to_limbs(r.data(), kw);
+    x_prime.to_limbs(xp.data(), kw); r_prime.to_limbs(rp.data(), kw);
+    e.check(zkp_ciphertext_proof_prove_batch(e.ctx(), nb, 1, n.data(), 0, c.data(), x.data(), r.data(), xp.data(), rp.data(), o1.data(), o2.data(), oc.data(), 0),
+            "zkp_ciphertext_proof_prove_batch");
+    return CiphertextProof{BigInt::from_limbs(o1.data(), z1w), BigInt::from_limbs(o2.data(), 2 * kw), BigInt::from_limbs(oc.data(), 2 * kw)};
+  }
+  Result verify(const CiphertextStatement& st) const {                                        // :66-97
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.ek.n), kw = nb / 32, z1w = kw + ZKP_Z1_EXTRA_LIMBS;
+    std::vector<uint32_t> n(kw), c(2 * kw), a1(z1w), a2(2 * kw), ac(2 * kw);
+    st.ek.n.to_limbs(n.data(), kw); st.c.to_limbs(c.data(), 2 * kw); z1.to_limbs(a1.data(), z1w); z2.to_limbs(a2.data(), 2 * kw); c_prime.to_limbs(ac.data(), 2 * kw);
+    uint8_t v = 9;
+    e.check(zkp_ciphertext_proof_verify_batch(e.ctx(), nb, 1, n.data(), 0, c.data(), a1.data(), a2.data(), ac.data(), &v, 0), "zkp_ciphertext_proof_verify_batch");
     return Result(v == ZKP_VERDICT_ACCEPT);
   }
 };
