@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--n-bits", type=int, default=2048)
     ap.add_argument("--cpu-sample", type=int, default=96, help="proofs verified by the CPU baseline (0 = skip)")
     ap.add_argument("--no-prove-leg", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs for BASELINE.json configs[3] and configs[4]")
     args = ap.parse_args()
 
     import numpy as np
@@ -190,6 +191,47 @@ def main():
         cpu = {"value": S / t_cpu, "unit": "verifies/s", "cores": threads, "kind": "port",
                "sample": f"oracle (C + GMP 6.2.1 mpz_powm, OpenMP over (proof,row)) verifying proofs 0..{S-1} of the same batch in {t_cpu:.2f}s; verdicts equal to GPU: {same}"}
 
+    # ---- short legs for the other BASELINE.json configurations (rank-local, reported per GPU; not part of `value`)
+    other = None
+    if not args.no_other_configs:
+        other = {}
+        g = torch.Generator(device=dev); g.manual_seed(99 + rank)
+        def rnd(shape):
+            return torch.randint(-2**31, 2**31 - 1, shape, dtype=torch.int32, device=dev, generator=g)
+        # configs[3]: 65536 NiCorrectKeyProof verifies, n = 2048, 65536 distinct (pseudo-)moduli: pure throughput shape,
+        # every record is expected to be rejected (random sigma); accept parity is covered by tests/test_gpu_fullsize.py
+        Bk, kwk = 65536, 64
+        nk = rnd((Bk, kwk)); nk[:, 0] |= 1; nk[:, -1] |= -2**31
+        sg = rnd((Bk, 11, kwk)); sg[:, :, -1] &= 0x3FFFFFFF
+        vk = torch.full((Bk,), 9, dtype=torch.uint8, device=dev)
+        sync()
+        ctx.correct_key_ni_verify(2048, Bk, nk, sg, b"KZen", vk); sync()      # warm-up
+        ctx.timing_reset(True); t0 = time.perf_counter()
+        ctx.correct_key_ni_verify(2048, Bk, nk, sg, b"KZen", vk); sync()
+        dtk = time.perf_counter() - t0
+        kms_k, _, me_k = ctx.timing_get(); ctx.timing_reset(False)
+        other["configs[3] NiCorrectKeyProof verify, n=2048, batch=65536 distinct moduli (per GPU)"] = {
+            "verifies_per_s": Bk / dtk, "modexp_per_s": me_k / (kms_k * 1e-3), "all_rejected_as_expected": bool((vk == 0).all().item()),
+            "achieved_limb_mac_per_s": me_k * 1.2 * 2048 * (2 * 64 * 64 + 64) / (kms_k * 1e-3)}
+        del nk, sg, vk
+        # configs[4]: RangeProofNi prove + verify at n = 4096 (8192-bit n^2); batch reduced to 256 proofs per GPU to stay short
+        B5, nb5 = 256, 4096
+        n5 = (1 << 4095) | int.from_bytes(os.urandom(500), "big") | 1          # odd 4096-bit pseudo-modulus: prove -> verify round trip is key-agnostic
+        pb5, wt5 = synth.synth_range_inputs(n5, nb5, B5, seed=4321 + rank, device=dev)
+        sync()
+        ctx.paillier_enc(nb5, B5, pb5.n, 0, wt5.x, wt5.r, pb5.ciphertext); sync()
+        v5 = torch.full((B5,), 9, dtype=torch.uint8, device=dev)
+        t0 = time.perf_counter()
+        ctx.range_ni_prove(pb5.struct(), wt5.struct(), None, None, None, device=True); sync()
+        t1 = time.perf_counter()
+        ctx.range_ni_verify(pb5.struct(), v5, device=True); sync()
+        t2 = time.perf_counter()
+        ok5 = bool((v5 == 1).all().item())
+        ok = ok and ok5
+        other["configs[4] RangeProofNi prove+verify, n=4096, batch=256 (per GPU, reduced from 4096)"] = {
+            "proofs_per_s": B5 / (t1 - t0), "verifies_per_s": B5 / (t2 - t1), "all_accepted": ok5}
+        del pb5, wt5
+
     if rank == 0:
         out = {"metric": "RangeProofNi verifies/sec, n=2048, batch=4096 per GPU", "value": value, "unit": "verifies/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -198,7 +240,7 @@ def main():
                "config": {"workload": f"BASELINE.json configs[1]: batch={B} RangeProofNi verify per GPU, n={n_bits} (reference fixture key), "
                                       f"128 rows/proof, 1/64 of the proofs tampered; prove leg = configs[2]",
                           "parallelism": f"proof-index sharding x{world}, all-gather of verdicts" if world > 1 else "single GPU"},
-               "prove": prove, "roofline": roofline, "cpu_baseline": cpu}
+               "prove": prove, "roofline": roofline, "cpu_baseline": cpu, "other_configs": other}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
