@@ -168,6 +168,31 @@ static void test_bad_ciphertext_proof() {   // #[should_panic]: witness r + 1
   ASSERT(proof.verify(CiphertextStatement{ek, c}).is_ok());
 }
 
+// ---- correct_key.rs tests (:200-236), interactive protocol
+static void test_correct_zk_proof() {
+  auto [ek, dk] = test_keypair().keys();
+  auto [challenge, verification_aid] = CorrectKey::challenge(ek);
+  auto proof_results = CorrectKey::prove(dk, challenge);
+  ASSERT(proof_results.is_ok());
+  ASSERT(CorrectKey::verify(proof_results.unwrap(), verification_aid).is_ok());
+}
+static void test_incorrect_zk_proof() {
+  auto [ek, dk] = test_keypair().keys();
+  auto [challenge, verification_aid] = CorrectKey::challenge(ek);
+  challenge.e = challenge.e + BigInt::one();
+  auto proof_results = CorrectKey::prove(dk, challenge);
+  ASSERT(proof_results.is_err());   // manipulated challenge
+  ASSERT(proof_results.err == CorrectKeyProveError::EWasntComputedCorrectly);
+}
+static void test_incorrect_zk_proof_2() {
+  auto [ek, dk] = test_keypair().keys();
+  auto [challenge, verification_aid] = CorrectKey::challenge(ek);
+  auto proof_results = CorrectKey::prove(dk, challenge);
+  ASSERT(proof_results.is_ok());
+  verification_aid.s_digest = verification_aid.s_digest + BigInt::one();
+  ASSERT(CorrectKey::verify(proof_results.unwrap(), verification_aid).is_err());   // manipulated aid
+}
+
 int main() {
   run("range_proof_ni::test_prover", test_prover);
   run("range_proof_ni::test_verifier_for_correct_proof", test_verifier_for_correct_proof);
@@ -183,6 +208,9 @@ int main() {
   run("zero_enc_proof::test_one_proof", test_one_proof, true);
   run("correct_ciphertext::test_ciphertext_proof", test_ciphertext_proof);
   run("correct_ciphertext::test_bad_ciphertext_proof", test_bad_ciphertext_proof, true);
+  run("correct_key::test_correct_zk_proof", test_correct_zk_proof);
+  run("correct_key::test_incorrect_zk_proof", test_incorrect_zk_proof);
+  run("correct_key::test_incorrect_zk_proof_2", test_incorrect_zk_proof_2);
   std::printf("%d failure(s)\n", failures);
   return failures ? 1 : 0;
 }

@@ -10,6 +10,7 @@
 //     src/zkproofs/correct_key_ni.rs:36-100
 //   zkproofs::{CompositeDLogProof,DLogStatement}::{prove,verify}    same
 //     src/zkproofs/wi_dlog_proof.rs:33-91
+//   zkproofs::{CorrectKey,Challenge,VerificationAid,CorrectKeyProof} same (interactive, correct_key.rs:28-183)
 //   zkproofs::{ZeroProof,ZeroStatement,ZeroWitness}                 same (zero_enc_proof.rs:26-95)
 //   zkproofs::{CiphertextProof,CiphertextStatement,CiphertextWitness} same (correct_ciphertext.rs:23-98)
 //   paillier::{Keypair,EncryptionKey,DecryptionKey,Paillier}        same names, only what the path needs
@@ -102,6 +103,23 @@ inline BigInt mod_pow(const BigInt& base, const BigInt& exp, const BigInt& modul
   (base % modulus).to_limbs(bb.data(), L); exp.to_limbs(ee.data(), L); modulus.to_limbs(mm.data(), L);
   e.check(zkp_modexp_batch(e.ctx(), mb, mb, 1, bb.data(), ee.data(), L, mm.data(), L, out.data(), 0), "zkp_modexp_batch");
   return BigInt::from_limbs(out.data(), L);
+}
+
+// batched BigInt::mod_pow over one modulus: out[i] = bases[i]^exps[i or 0] mod modulus (ONE zkp_modexp_batch)
+inline std::vector<BigInt> mod_pow_batch(const std::vector<BigInt>& bases, const std::vector<BigInt>& exps, const BigInt& modulus) {
+  Engine& e = Engine::instance();
+  const size_t b = modulus.bit_length(), cnt = bases.size();
+  const uint32_t mb = b <= 2048 ? 2048 : b <= 4096 ? 4096 : 8192, L = mb / 32;
+  const bool shared = exps.size() == 1;
+  if (!shared && exps.size() != cnt) throw std::invalid_argument("mod_pow_batch: exps must have 1 or bases.size() entries");
+  std::vector<uint32_t> bb(cnt * L), ee(exps.size() * L), mm(L), out(cnt * L);
+  for (size_t i = 0; i < cnt; i++) (bases[i] % modulus).to_limbs(&bb[i * L], L);
+  for (size_t i = 0; i < exps.size(); i++) exps[i].to_limbs(&ee[i * L], L);
+  modulus.to_limbs(mm.data(), L);
+  if (cnt) e.check(zkp_modexp_batch(e.ctx(), mb, mb, cnt, bb.data(), ee.data(), shared ? 0 : L, mm.data(), 0, out.data(), 0), "zkp_modexp_batch");
+  std::vector<BigInt> r;
+  for (size_t i = 0; i < cnt; i++) r.push_back(BigInt::from_limbs(&out[i * L], L));
+  return r;
 }
 
 // ------------------------------------------------------------------ RangeProofNi
@@ -319,6 +337,62 @@ class NiCorrectKeyProof {
     e.check(zkp_correct_key_ni_verify_batch(e.ctx(), nb, 1, n.data(), sg.data(), salt, (uint32_t)salt_len, &v, 0), "zkp_correct_key_ni_verify_batch");
     return Result(v == ZKP_VERDICT_ACCEPT);
   }
+};
+
+// ------------------------------------------------------------------ interactive CorrectKey (src/zkproofs/correct_key.rs:28-183)
+// the same 2048-bit modexp shape x40, composed on the host from batched GPU calls.
+struct Challenge { std::vector<BigInt> sn; BigInt e; std::vector<BigInt> z; };   // :29-39
+struct VerificationAid { BigInt s_digest; };                                       // :41-45
+struct CorrectKeyProof { BigInt s_digest; };                                       // :47-51
+enum class CorrectKeyProveError { SniNotCoprimeWithN, ZiNotCoprimeWithN, RniNotCoprimeWithN, EWasntComputedCorrectly };   // :174-183
+
+struct CorrectKey {
+  static constexpr size_t STATISTICAL_ERROR_FACTOR = 40;   // :26
+  static BigInt digest_chain(const BigInt* first, const std::vector<BigInt>& a, const std::vector<BigInt>* b = nullptr) {
+    detail::Sha256 s;
+    if (first) s.update(*first);
+    for (auto& v : a) s.update(v);
+    if (b) for (auto& v : *b) s.update(v);
+    return s.finish();
+  }
+  // :64-102
+  static std::pair<Challenge, VerificationAid> challenge(const EncryptionKey& ek) {
+    std::vector<BigInt> s, r;
+    for (size_t i = 0; i < STATISTICAL_ERROR_FACTOR; i++) { s.push_back(BigInt::sample_below(ek.n)); r.push_back(BigInt::sample_below(ek.n)); }
+    std::vector<BigInt> both = s; both.insert(both.end(), r.begin(), r.end());
+    std::vector<BigInt> pw = mod_pow_batch(both, {ek.n}, ek.n);                               // sn, rn  (:73-76, :86-89)
+    std::vector<BigInt> sn(pw.begin(), pw.begin() + STATISTICAL_ERROR_FACTOR), rn(pw.begin() + STATISTICAL_ERROR_FACTOR, pw.end());
+    BigInt e = digest_chain(&ek.n, sn, &rn);                                                  // :91
+    std::vector<BigInt> se = mod_pow_batch(s, {e}, ek.n);                                     // s_i^e  (:96)
+    std::vector<BigInt> z;
+    for (size_t i = 0; i < STATISTICAL_ERROR_FACTOR; i++) z.push_back((r[i] * se[i]) % ek.n);
+    return {Challenge{sn, e, z}, VerificationAid{digest_chain(nullptr, s)}};                  // :100-102
+  }
+  // :104-162 — returns the proof or the error
+  struct ProveResult {
+    bool ok; CorrectKeyProof proof; CorrectKeyProveError err;
+    bool is_ok() const { return ok; }
+    bool is_err() const { return !ok; }
+    const CorrectKeyProof& unwrap() const { if (!ok) throw Panic("called `Result::unwrap()` on an `Err` value"); return proof; }
+  };
+  static ProveResult prove(const DecryptionKey& dk, const Challenge& ch) {
+    const BigInt dk_n = dk.q * dk.p, one = BigInt::one();
+    auto fail = [](CorrectKeyProveError e) { return ProveResult{false, CorrectKeyProof{}, e}; };
+    for (auto& v : ch.sn) if (BigInt::gcd(dk_n, v) != one) return fail(CorrectKeyProveError::SniNotCoprimeWithN);   // :110-116
+    for (auto& v : ch.z) if (BigInt::gcd(dk_n, v) != one) return fail(CorrectKeyProveError::ZiNotCoprimeWithN);     // :119-125
+    const BigInt phi = (dk.q - one) * (dk.p - one);
+    const BigInt phimine = phi - (ch.e % phi);                                                                       // :130
+    std::vector<BigInt> zn = mod_pow_batch(ch.z, {dk_n}, dk_n), snphi = mod_pow_batch(ch.sn, {phimine}, dk_n);       // :135-137
+    std::vector<BigInt> rn;
+    for (size_t i = 0; i < ch.z.size(); i++) rn.push_back((zn[i] * snphi[i]) % dk_n);
+    for (auto& v : rn) if (BigInt::gcd(dk_n, v) != one) return fail(CorrectKeyProveError::RniNotCoprimeWithN);       // :143-148
+    if (ch.e != digest_chain(&dk_n, ch.sn, &rn)) return fail(CorrectKeyProveError::EWasntComputedCorrectly);         // :151-156
+    // s_digest = H(extract_nroot(dk, sn_i)...): sn_i^(n^-1 mod phi) mod n  ([upstream] extract_nroot)              // :159
+    std::vector<BigInt> roots = mod_pow_batch(ch.sn, {BigInt::mod_inv(dk_n, phi)}, dk_n);
+    return ProveResult{true, CorrectKeyProof{digest_chain(nullptr, roots)}, CorrectKeyProveError::EWasntComputedCorrectly};
+  }
+  // :164-171
+  static Result verify(const CorrectKeyProof& proof, const VerificationAid& va) { return Result(proof.s_digest == va.s_digest); }
 };
 
 // ------------------------------------------------------------------ CompositeDLogProof
