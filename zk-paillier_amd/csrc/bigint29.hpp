@@ -120,7 +120,7 @@ __device__ __forceinline__ void lds_store_block(uint32_t* p, const uint32_t (&v)
 // R = A * B / 2^(29*G*W) mod M.  A: this lane's block of A (registers); B: staged in LDS as G
 // blocks of BLK words; N: this lane's block of the modulus; n1 = -M^-1 mod 2^29.
 // Operand limbs may be "almost normalised" (< 2^29 + 2^8); operand values < 2M.
-// Result: limbs 1.. < 2^29, limb 0 < 2^29 + 16; value < 2M (<= M when B == 1).
+// Result: limbs 1.. < 2^29, limb 0 < 2^29 + 16; value < 2M (<= M when B == 1).  R may alias A (in place).
 //
 // Word-level CIOS over a sliding window of W 64-bit column accumulators per lane.  Sub-step
 // (s,t) handles limb b = B[s*W+t]: every lane adds A_j*b to its W columns, lane 0's bottom
@@ -143,11 +143,9 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
 
 #pragma unroll 1
   for (int s = 0; s < G; s++) {
-    uint32_t Bs[W];
-    lds_load_block(Bs, ldsB + s * BLK);
 #pragma unroll
     for (int t = 0; t < W; t++) {
-      const uint32_t b = Bs[t];
+      const uint32_t b = ldsB[s * BLK + t];
 #pragma unroll
       for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)A[k] * b;
       const uint32_t q = bcast0<G>((ORUP ? (uint32_t)c[t] : (uint32_t)c[t] * n1) & LMASK);

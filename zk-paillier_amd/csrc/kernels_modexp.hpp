@@ -121,7 +121,14 @@ template <int G> __device__ __forceinline__ void canonical_words(const Grp<G>& g
 // Exponentiation ladders.  In: X = base in Montgomery form (regs), exponent words in g.expw()
 // (valid words + zero padding).  Out: X = base^exp in Montgomery form (value < 2M~), also staged in B().
 // tab: this group's TAB*L-word table in global memory; cst: the modulus' constant record.
-// Both ladders run on M~ (Orup) and keep ONE montmul call site in their main loop.
+// Both ladders run on M~ (Orup), work IN PLACE on X (the B operand of every product is the staged copy of X
+// in LDS, so a table product just loads the table entry over X's registers) and keep ONE montmul call site
+// in their main loop.
+
+// in-place product on the Orup multiple: X = X * B() / R
+template <int G> __device__ __forceinline__ void mmo_ip(const Grp<G>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
+  montmul<G, true>(X, X, g.B(), NT, 1u, g.gl);
+}
 
 // (a) per-item exponents (sigma^n mod n with a different n per proof, DLog): fixed 5-bit windows, uniform
 //     control flow whatever the exponents are.  1.2 t + 30 products.
@@ -129,21 +136,20 @@ template <int G>
 __device__ __forceinline__ void powm_fixed(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst) {
   using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
-  uint32_t NT[W], T[W], R[W];
+  uint32_t NT[W];
   load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
-  // table: T[0] = R mod M (Montgomery one), T[1] = X, T[k] = T[k-1]*X
-  load_limbs_global<G>(T, cst + CL::OFF_R1, g.gl);
-  store_limbs_global<G>(tab, T, g.gl);
+  // table: T[0] = R mod M (Montgomery one), T[1] = X, T[k] = T[k-1]*X  (B() = X throughout)
+  {
+    uint32_t T[W];
+    load_limbs_global<G>(T, cst + CL::OFF_R1, g.gl);
+    store_limbs_global<G>(tab, T, g.gl);
+  }
   store_limbs_global<G>(tab + L, X, g.gl);
   stageB<G>(g, X);
-#pragma unroll
-  for (int k = 0; k < W; k++) T[k] = X[k];
 #pragma unroll 1
   for (int e = 2; e < TAB; e++) {
-    mmo<G>(g, NT, R, T);
-#pragma unroll
-    for (int k = 0; k < W; k++) T[k] = R[k];
-    store_limbs_global<G>(tab + e * L, T, g.gl);
+    mmo_ip<G>(g, NT, X);
+    store_limbs_global<G>(tab + e * L, X, g.gl);
   }
   const uint32_t* ew = g.expw();
   const int nwin = (exp_bits + WIN - 1) / WIN;
@@ -159,97 +165,85 @@ __device__ __forceinline__ void powm_fixed(const Grp<G>& g, uint32_t (&X)[W], in
   // (nwin-1) rounds of [5 squarings, 1 table product] as one loop with one montmul call site
 #pragma unroll 1
   for (int step = 0; step < (nwin - 1) * (WIN + 1); step++) {
-    const int ph = step % (WIN + 1);
-    if (ph == WIN) {
-      load_limbs_global<G>(T, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
-    } else {
-#pragma unroll
-      for (int k = 0; k < W; k++) T[k] = X[k];
-    }
-    mmo<G>(g, NT, R, T);
-#pragma unroll
-    for (int k = 0; k < W; k++) X[k] = R[k];
+    if (step % (WIN + 1) == WIN) load_limbs_global<G>(X, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
+    mmo_ip<G>(g, NT, X);
     stageB<G>(g, X);
   }
 }
 
 // (b) ONE exponent for the whole launch (Paillier Enc under a shared key: exponent n): sliding windows of
-//     up to 6 bits over a table of the 32 odd powers; the schedule depends on the exponent only, so it is
-//     wave-uniform (scalar branches).  ~ t + t/7 + 33 products.
+//     up to 6 bits over a table of the 32 odd powers.  The schedule depends on the exponent only; it is
+//     computed once per launch by k_sliding_schedule and read here as one byte per product:
+//       0x80|e  first op: X = tab[e]          0x00  square          0x40|e  multiply by tab[e] = X0^(2e+1)
+//       0xFE    exponent is zero: X = R1       0xFF  end
+//     ~ t + t/7 + 33 products.
 constexpr int SWIN = 6;
+constexpr uint8_t OP_END = 0xFF, OP_ZERO = 0xFE, OP_FIRST = 0x80, OP_MUL = 0x40;
+
+__global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int exp_bits, uint8_t* __restrict__ ops) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  auto bit = [&](int i) -> int { return (int)((exp_words[i >> 5] >> (i & 31)) & 1u); };
+  int n = 0, i = exp_bits - 1;
+  while (i >= 0 && !bit(i)) i--;
+  if (i < 0) { ops[0] = OP_ZERO; ops[1] = OP_END; return; }
+  bool started = false;
+  while (i >= 0) {
+    if (!bit(i)) { ops[n++] = 0; i--; continue; }
+    int l = i - SWIN + 1; if (l < 0) l = 0;
+    while (!bit(l)) l++;
+    int val = 0;
+    for (int k = i; k >= l; k--) val = (val << 1) | bit(k);
+    if (!started) { ops[n++] = (uint8_t)(OP_FIRST | (val >> 1)); started = true; }
+    else { for (int k = 0; k < i - l + 1; k++) ops[n++] = 0; ops[n++] = (uint8_t)(OP_MUL | (val >> 1)); }
+    i = l - 1;
+  }
+  ops[n] = OP_END;
+}
+
 template <int G>
-__device__ __forceinline__ void powm_sliding(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst) {
+__device__ __forceinline__ void powm_sliding(const Grp<G>& g, uint32_t (&X)[W], const uint8_t* __restrict__ ops, uint32_t* tab, const uint32_t* cst) {
   using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
   static_assert((1 << (SWIN - 1)) == TAB, "table size");
-  uint32_t NT[W], T[W], R[W];
+  uint32_t NT[W];
   load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
-  // odd powers: tab[e] = X^(2e+1);  X2 = X^2 staged in B() while the table is built
+  // odd powers: tab[e] = X0^(2e+1);  X0^2 staged in B() while the table is built
   store_limbs_global<G>(tab, X, g.gl);
   stageB<G>(g, X);
-  mmo<G>(g, NT, R, X);
-  stageB<G>(g, R);
+  {
+    uint32_t S[W];
 #pragma unroll
-  for (int k = 0; k < W; k++) T[k] = X[k];
+    for (int k = 0; k < W; k++) S[k] = X[k];
+    mmo_ip<G>(g, NT, S);
+    stageB<G>(g, S);
+  }
 #pragma unroll 1
   for (int e = 1; e < TAB; e++) {
-    mmo<G>(g, NT, R, T);
-#pragma unroll
-    for (int k = 0; k < W; k++) T[k] = R[k];
-    store_limbs_global<G>(tab + e * L, T, g.gl);
+    mmo_ip<G>(g, NT, X);
+    store_limbs_global<G>(tab + e * L, X, g.gl);
   }
-  const uint32_t* ew = g.expw();
-  auto bit = [&](int i) -> int { return (int)((__builtin_amdgcn_readfirstlane(ew[i >> 5]) >> (i & 31)) & 1u); };
-  int i = exp_bits - 1;
-  while (i >= 0 && !bit(i)) i--;
-  if (i < 0) {                                     // exponent 0
+  int i = 0;
+  int op = __builtin_amdgcn_readfirstlane((int)ops[0]);
+  if (op == OP_ZERO) {
     load_limbs_global<G>(X, cst + CL::OFF_R1, g.gl);
     stageB<G>(g, X);
     return;
   }
-  int nsq = 0, mulval = 0;
-  bool started = false;
+  load_limbs_global<G>(X, tab + (op & (TAB - 1)) * L, g.gl);     // OP_FIRST
+  stageB<G>(g, X);
 #pragma unroll 1
-  for (;;) {
-    int op;                                        // 0: square, v > 0: multiply by X^v (v odd)
-    if (nsq > 0) { op = 0; nsq--; }
-    else if (mulval) { op = mulval; mulval = 0; }
-    else {
-      if (i < 0) break;
-      if (!bit(i)) { op = 0; i--; }
-      else {
-        int l = i - SWIN + 1; if (l < 0) l = 0;
-        while (!bit(l)) l++;
-        int val = 0;
-        for (int k = i; k >= l; k--) val = (val << 1) | bit(k);
-        const int len = i - l + 1;
-        i = l - 1;
-        if (!started) {                            // first window: X = table entry, no squarings
-          started = true;
-          load_limbs_global<G>(X, tab + (val >> 1) * L, g.gl);
-          stageB<G>(g, X);
-          continue;
-        }
-        nsq = len; mulval = val;
-        continue;
-      }
-    }
-    if (op == 0) {
-#pragma unroll
-      for (int k = 0; k < W; k++) T[k] = X[k];
-    } else {
-      load_limbs_global<G>(T, tab + (op >> 1) * L, g.gl);
-    }
-    mmo<G>(g, NT, R, T);
-#pragma unroll
-    for (int k = 0; k < W; k++) X[k] = R[k];
+  for (i = 1;; i++) {
+    op = __builtin_amdgcn_readfirstlane((int)ops[i]);
+    if (op == OP_END) break;
+    if (op & OP_MUL) load_limbs_global<G>(X, tab + (op & (TAB - 1)) * L, g.gl);   // B() still holds the running value
+    mmo_ip<G>(g, NT, X);
     stageB<G>(g, X);
   }
 }
 
 template <int G>
-__device__ __forceinline__ void powm(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst, bool shared_exponent) {
-  if (shared_exponent) powm_sliding<G>(g, X, exp_bits, tab, cst);
+__device__ __forceinline__ void powm(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst, const uint8_t* sched) {
+  if (sched) powm_sliding<G>(g, X, sched, tab, cst);
   else powm_fixed<G>(g, X, exp_bits, tab, cst);
 }
 
@@ -416,6 +410,7 @@ struct ModexpArgs {
   int exp_bits;
   int io_words;             // words per base element (<= NW; values are zero-extended)
   int out_words;            // words per out element
+  const uint8_t* sched;     // sliding-window schedule of the launch-uniform exponent (k_sliding_schedule), or null
 };
 
 template <int G>
@@ -446,7 +441,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
     load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
     stageB<G>(g, X);
     mm<G>(g, X, T);
-    powm<G>(g, X, a.exp_bits, tab, cst, a.exp_stride == 0);
+    powm<G>(g, X, a.exp_bits, tab, cst, a.sched);
     // leave the Montgomery domain: montmul(X, 1) <= M
     stage_one<G>(g);
     mm<G>(g, R, X);
@@ -528,6 +523,7 @@ struct EncArgs {
   const uint32_t* c1; const uint32_t* c2; const uint32_t* cipher_x;
   uint8_t* verdict;             // [B] a failing item clears its proof's verdict
   const unsigned long long* count_ptr;   // mode 1: device-resident item count (overrides `count`)
+  const uint8_t* sched;                  // sliding-window schedule when every item uses the same key (exponent n), or null
   uint32_t ef;
 };
 
@@ -603,7 +599,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
     for (int s = 0; s < nsteps; s++) {
       if (s == 1) {
         fetch_words<G>(g, g.expw(), pn, kw);                         // exponent = n
-        powm<G>(g, X, a.n_bits, tab, cst, a.n_stride == 0);
+        powm<G>(g, X, a.n_bits, tab, cst, a.sched);
         continue;
       }
       // ---- operands

@@ -141,6 +141,17 @@ template <int G> static int32_t check_setup_status(zkp_ctx* c, uint64_t count, D
   return ZKP_OK;
 }
 
+// sliding-window schedule for a launch-uniform exponent (device resident, ctx scratch slot 15)
+static int32_t build_schedule(zkp_ctx* c, const uint32_t* exp_words, uint32_t exp_bits, const uint8_t** out) {
+  DevBuf& b = c->scratch[15];
+  int32_t st = ensure(c, b, (size_t)exp_bits + 64);
+  if (st) return st;
+  hipLaunchKernelGGL(k_sliding_schedule, dim3(1), dim3(64), 0, c->stream, exp_words, (int)exp_bits, (uint8_t*)b.p);
+  HIPCHK(c, hipGetLastError());
+  *out = (const uint8_t*)b.p;
+  return ZKP_OK;
+}
+
 template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_t items, unsigned* blocks_out) {
   using LL = LdsLayout<G>;
   const uint64_t need = (items + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK;
@@ -226,7 +237,9 @@ static int32_t modexp_core(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const 
   unsigned blocks = 0;
   int32_t st;
   if ((st = table_for<G>(c, k_modexp<G>, count, &blocks))) return st;
-  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words, out_words ? out_words : io_words};
+  const uint8_t* sched = nullptr;
+  if (exp_stride == 0 && (st = build_schedule(c, exp, exp_bits, &sched))) return st;
+  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words, out_words ? out_words : io_words, sched};
   {
     TimedRegion tr(c, count);
     hipLaunchKernelGGL(k_modexp<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
@@ -336,6 +349,7 @@ static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint3
   a.n = n; a.n_stride = n_stride; a.consts = (const uint32_t*)c->consts.p; a.const_stride = n_stride ? (uint64_t)CL::WORDS : 0;
   a.table = (uint32_t*)c->table.p; a.count = count; a.n_bits = (int)n_bits; a.mode = 0;
   a.m = m; a.r = r; a.out = out; a.items_per_key = n_stride ? 1 : count;
+  if (n_stride == 0 && (st = build_schedule(c, n, n_bits, &a.sched))) return st;
   {
     TimedRegion tr(c, count);
     hipLaunchKernelGGL(k_enc<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
