@@ -23,9 +23,9 @@ sys.path.insert(0, ROOT)
 PEAK_LIMB_MAC_PER_S = 3.19e13
 HBM_PEAK_GBS = 8000.0
 # HBM-side bytes per Enc of k_enc measured with rocprofv3 PMC passes of this same command
-# (profiles/r01_pmc_bench_b512_v3kernel.json: FETCH_SIZE 87.9 KB + WRITE_SIZE 26.1 KB per Enc, raw counters;
+# (profiles/r01_pmc_bench_b512_v4kernel.json: FETCH_SIZE 83.7 KB + WRITE_SIZE 21.8 KB per Enc, raw counters;
 # almost all of it is the per-exponentiation window table spilling out of L2, not operand traffic)
-PMC_HBM_BYTES_PER_ENC = 87860.6 + 26062.1
+PMC_HBM_BYTES_PER_ENC = 83737.6 + 21779.5
 # algorithmic 32x32->64 limb-MACs of one Enc at n=2048: 1.2*2048 modmuls x (2*128^2+128)
 def enc_limb_macs(n_bits):
     Lw = 2 * n_bits // 32
@@ -165,7 +165,7 @@ def main():
     bytes_per_enc = 4 * kw * 4 + 8
     roofline = {"bound": "valu", "achieved": ach / 1e12, "peak": PEAK_LIMB_MAC_PER_S / 1e12, "unit": "Tlimb-MAC/s",
                 "frac": ach / PEAK_LIMB_MAC_PER_S, "traffic": PMC_HBM_BYTES_PER_ENC * enc_per_launch,
-                "traffic_note": "bytes per launch = PMC-measured FETCH_SIZE+WRITE_SIZE per Enc (profiles/r01_pmc_bench_b512_v3kernel.json) x Enc of the launch; algorithmic operand bytes are ~1 KB per Enc",
+                "traffic_note": "bytes per launch = PMC-measured FETCH_SIZE+WRITE_SIZE per Enc (profiles/r01_pmc_bench_b512_v4kernel.json) x Enc of the launch; algorithmic operand bytes are ~1 KB per Enc",
                 "kernel": f"k_enc<{144 // lpl}> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer)",
                 "kernel_ms_per_launch": kms / max(launches, 1),
                 "modexps_per_launch": enc_per_launch,
