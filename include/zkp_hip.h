@@ -199,6 +199,24 @@ int32_t zkp_ciphertext_proof_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_
                                           const uint32_t* c, const uint32_t* z1, const uint32_t* z2, const uint32_t* c_prime,
                                           uint8_t* out_verdict, uint32_t flags);
 
+/* VerlinProof (src/zkproofs/verlin_proof.rs:35-165): phi_x = c^x * c'^x' * Enc(x'', r_x).
+ *   gen_phi(c, c', y, y', y'', r_y) = c^y * c'^y' * Enc(y'', r_y) mod n^2                         (:138-165)
+ *   prove : phi_a = gen_phi(c, c', a, a', a'', r_a); e = H(n || c || c' || phi_x || phi_a);
+ *           z = x e + a, z' = x' e + a', z'' = x'' e + a'' (over Z); r_z = r_x^e * r_a mod n^2     (:60-99)
+ *   verify: gen_phi(c, c', z, z', z'', r_z) == phi_x^e * phi_a mod n^2                             (:101-135)
+ * c, c_prime, phi_x, phi_a, r_z: [B][2kw]; witness x, x_prime, x_double_prime, r_x and the nonces a, a_prime,
+ * a_double_prime, r_a (sampled by the caller, :61-67): [B][kw]; z, z_prime, z_double_prime: [B][kw + ZKP_Z1_EXTRA_LIMBS]. */
+int32_t zkp_verlin_proof_prove_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride,
+                                     const uint32_t* c, const uint32_t* c_prime, const uint32_t* phi_x,
+                                     const uint32_t* x, const uint32_t* x_prime, const uint32_t* x_double_prime, const uint32_t* r_x,
+                                     const uint32_t* a, const uint32_t* a_prime, const uint32_t* a_double_prime, const uint32_t* r_a,
+                                     uint32_t* out_phi_a, uint32_t* out_z, uint32_t* out_z_prime, uint32_t* out_z_double_prime,
+                                     uint32_t* out_r_z, uint32_t flags);
+int32_t zkp_verlin_proof_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride,
+                                      const uint32_t* c, const uint32_t* c_prime, const uint32_t* phi_x, const uint32_t* phi_a,
+                                      const uint32_t* z, const uint32_t* z_prime, const uint32_t* z_double_prime, const uint32_t* r_z,
+                                      uint8_t* out_verdict, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

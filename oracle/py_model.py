@@ -315,3 +315,26 @@ def ciphertext_proof_verify(n, c, z1, z2, c_prime) -> bool:
     nn = n * n
     e = compute_digest([n, c, c_prime])
     return enc(n, z1, z2) == (pow(c, e, nn) * c_prime) % nn
+
+
+# ----------------------------------------------------------------------------- VerlinProof
+
+def gen_phi(n, c, c_prime, y, y_prime, y_double_prime, r_y):
+    """verlin_proof.rs:138-165: c^y * c'^y' * Enc(y'', r_y) mod n^2."""
+    nn = n * n
+    return (pow(c, y, nn) * pow(c_prime, y_prime, nn) % nn) * enc(n, y_double_prime, r_y) % nn
+
+
+def verlin_prove(n, c, c_prime, phi_x, x, xp, xpp, r_x, a, ap, app, r_a):
+    """verlin_proof.rs:60-99 with the nonces (a, a', a'', r_a) injected."""
+    nn = n * n
+    phi_a = gen_phi(n, c, c_prime, a, ap, app, r_a)
+    e = compute_digest([n, c, c_prime, phi_x, phi_a])
+    return phi_a, x * e + a, xp * e + ap, xpp * e + app, (pow(r_x, e, nn) * r_a) % nn
+
+
+def verlin_verify(n, c, c_prime, phi_x, phi_a, z, zp, zpp, r_z) -> bool:
+    """verlin_proof.rs:101-135."""
+    nn = n * n
+    e = compute_digest([n, c, c_prime, phi_x, phi_a])
+    return gen_phi(n, c, c_prime, z, zp, zpp, r_z) == (pow(phi_x, e, nn) * phi_a) % nn

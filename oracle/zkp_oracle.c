@@ -662,3 +662,81 @@ int32_t oracle_ciphertext_proof_verify_batch(uint32_t n_bits, uint64_t batch, co
                                              const uint32_t* z1, const uint32_t* z2, const uint32_t* c_prime, uint8_t* out_verdict) {
   return sigma_verify(1, n_bits, batch, n, n_stride, c, z1, z2, c_prime, out_verdict);
 }
+
+/* ------------------------------------------------------------------ VerlinProof (verlin_proof.rs:35-165) */
+static void gen_phi_mpz(mpz_t out, const mpz_t n, const mpz_t nn, const mpz_t c, const mpz_t cp, const mpz_t y, const mpz_t yp,
+                        const mpz_t ypp, const mpz_t ry, mpz_t t, mpz_t u) {
+  mpz_powm(out, c, y, nn);          /* Paillier::mul(c, y)  :147-151 */
+  mpz_powm(t, cp, yp, nn);          /* Paillier::mul(c', y') :152-156 */
+  mpz_mul(out, out, t);
+  mpz_mod(out, out, nn);            /* Paillier::add :162 */
+  enc_mpz(t, n, nn, ypp, ry, u);    /* Enc(y'', r_y) :157-161 */
+  mpz_mul(out, out, t);
+  mpz_mod(out, out, nn);            /* Paillier::add :163 */
+}
+
+static void verlin_challenge(mpz_t e, const mpz_t n, const mpz_t c, const mpz_t cp, const mpz_t phi_x, const mpz_t phi_a) {
+  mpz_t it[5];
+  mpz_init_set(it[0], n); mpz_init_set(it[1], c); mpz_init_set(it[2], cp); mpz_init_set(it[3], phi_x); mpz_init_set(it[4], phi_a);
+  compute_digest(e, (const mpz_t*)it, 5); /* :78-84, 102-108 */
+  for (int i = 0; i < 5; i++) mpz_clear(it[i]);
+}
+
+int32_t oracle_verlin_proof_prove_batch(uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* c,
+                                        const uint32_t* c_prime, const uint32_t* phi_x, const uint32_t* x, const uint32_t* x_prime,
+                                        const uint32_t* x_double_prime, const uint32_t* r_x, const uint32_t* a, const uint32_t* a_prime,
+                                        const uint32_t* a_double_prime, const uint32_t* r_a, uint32_t* out_phi_a, uint32_t* out_z,
+                                        uint32_t* out_z_prime, uint32_t* out_z_double_prime, uint32_t* out_r_z) {
+  const size_t kw = n_bits / 32, zw = kw + ZKP_Z1_EXTRA_LIMBS;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int64_t b = 0; b < (int64_t)batch; b++) {
+    mpz_t zn, znn, zc, zcp, zphx, v[8], pa, e, t, u;
+    mpz_inits(zn, znn, zc, zcp, zphx, pa, e, t, u, NULL);
+    const uint32_t* src[8] = {x, x_prime, x_double_prime, r_x, a, a_prime, a_double_prime, r_a};
+    for (int i = 0; i < 8; i++) { mpz_init(v[i]); limbs_to_mpz(v[i], src[i] + b * kw, kw); }
+    limbs_to_mpz(zn, n + b * n_stride, kw);
+    mpz_mul(znn, zn, zn);
+    limbs_to_mpz(zc, c + b * 2 * kw, 2 * kw);
+    limbs_to_mpz(zcp, c_prime + b * 2 * kw, 2 * kw);
+    limbs_to_mpz(zphx, phi_x + b * 2 * kw, 2 * kw);
+    gen_phi_mpz(pa, zn, znn, zc, zcp, v[4], v[5], v[6], v[7], t, u);   /* phi_a :69-77 */
+    verlin_challenge(e, zn, zc, zcp, zphx, pa);
+    uint32_t* outs[3] = {out_z, out_z_prime, out_z_double_prime};
+    for (int i = 0; i < 3; i++) { mpz_mul(t, v[i], e); mpz_add(t, t, v[4 + i]); mpz_to_limbs(outs[i] + b * zw, zw, t); }   /* :85-87 */
+    mpz_powm(t, v[3], e, znn);
+    mpz_mul(t, t, v[7]);
+    mpz_mod(t, t, znn);                                               /* r_z :88-89 */
+    mpz_to_limbs(out_r_z + b * 2 * kw, 2 * kw, t);
+    mpz_to_limbs(out_phi_a + b * 2 * kw, 2 * kw, pa);
+    for (int i = 0; i < 8; i++) mpz_clear(v[i]);
+    mpz_clears(zn, znn, zc, zcp, zphx, pa, e, t, u, NULL);
+  }
+  return 0;
+}
+
+int32_t oracle_verlin_proof_verify_batch(uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* c,
+                                         const uint32_t* c_prime, const uint32_t* phi_x, const uint32_t* phi_a, const uint32_t* z,
+                                         const uint32_t* z_prime, const uint32_t* z_double_prime, const uint32_t* r_z, uint8_t* out_verdict) {
+  const size_t kw = n_bits / 32, zw = kw + ZKP_Z1_EXTRA_LIMBS;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int64_t b = 0; b < (int64_t)batch; b++) {
+    mpz_t zn, znn, zc, zcp, zphx, pa, z0, z1, z2, rz, e, lhs, rhs, t, u;
+    mpz_inits(zn, znn, zc, zcp, zphx, pa, z0, z1, z2, rz, e, lhs, rhs, t, u, NULL);
+    limbs_to_mpz(zn, n + b * n_stride, kw);
+    mpz_mul(znn, zn, zn);
+    limbs_to_mpz(zc, c + b * 2 * kw, 2 * kw);
+    limbs_to_mpz(zcp, c_prime + b * 2 * kw, 2 * kw);
+    limbs_to_mpz(zphx, phi_x + b * 2 * kw, 2 * kw);
+    limbs_to_mpz(pa, phi_a + b * 2 * kw, 2 * kw);
+    limbs_to_mpz(z0, z + b * zw, zw); limbs_to_mpz(z1, z_prime + b * zw, zw); limbs_to_mpz(z2, z_double_prime + b * zw, zw);
+    limbs_to_mpz(rz, r_z + b * 2 * kw, 2 * kw);
+    verlin_challenge(e, zn, zc, zcp, zphx, pa);
+    mpz_powm(rhs, zphx, e, znn);
+    mpz_mul(rhs, rhs, pa);
+    mpz_mod(rhs, rhs, znn);                                           /* phi_x^e * phi_a :109-118 */
+    gen_phi_mpz(lhs, zn, znn, zc, zcp, z0, z1, z2, rz, t, u);         /* phi_z :120-128 */
+    out_verdict[b] = mpz_cmp(lhs, rhs) == 0 ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
+    mpz_clears(zn, znn, zc, zcp, zphx, pa, z0, z1, z2, rz, e, lhs, rhs, t, u, NULL);
+  }
+  return 0;
+}

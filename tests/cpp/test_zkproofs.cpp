@@ -193,6 +193,21 @@ static void test_incorrect_zk_proof_2() {
   ASSERT(CorrectKey::verify(proof_results.unwrap(), verification_aid).is_err());   // manipulated aid
 }
 
+// ---- verlin_proof.rs tests (:181-262).  (Paillier::encrypt draws its own randomness; here Enc with a sampled r.)
+static void verlin_case(bool bad) {
+  auto [ek, dk] = test_keypair().keys();
+  BigInt x = BigInt::sample_below(ek.n), x_prime = BigInt::sample_below(ek.n), x_double_prime = BigInt::sample_below(ek.n);
+  BigInt r_x = BigInt::sample_below(ek.n);
+  while (BigInt::gcd(r_x, ek.n) != BigInt::one()) r_x = BigInt::sample_below(ek.n);
+  BigInt c = Paillier::encrypt_with_chosen_randomness(ek, x, BigInt::sample_below(ek.n));
+  BigInt c_prime = Paillier::encrypt_with_chosen_randomness(ek, x_prime, BigInt::sample_below(ek.n));
+  BigInt phi_x = gen_phi(ek, c, c_prime, bad ? x * BigInt(2) : x, x_prime, x_double_prime, r_x);   // bad: x_bad = 2x injected (:226-236)
+  VerlinProof proof = VerlinProof::prove(VerlinWitness{x, x_prime, x_double_prime, r_x}, VerlinStatement{ek, c, c_prime, phi_x});
+  ASSERT(proof.verify(VerlinStatement{ek, c, c_prime, phi_x}).is_ok());
+}
+static void test_verlin_proof() { verlin_case(false); }
+static void test_bad_verlin_proof() { verlin_case(true); }   // #[should_panic]
+
 int main() {
   run("range_proof_ni::test_prover", test_prover);
   run("range_proof_ni::test_verifier_for_correct_proof", test_verifier_for_correct_proof);
@@ -211,6 +226,8 @@ int main() {
   run("correct_key::test_correct_zk_proof", test_correct_zk_proof);
   run("correct_key::test_incorrect_zk_proof", test_incorrect_zk_proof);
   run("correct_key::test_incorrect_zk_proof_2", test_incorrect_zk_proof_2);
+  run("verlin_proof::test_verlin_proof", test_verlin_proof);
+  run("verlin_proof::test_bad_verlin_proof", test_bad_verlin_proof, true);
   std::printf("%d failure(s)\n", failures);
   return failures ? 1 : 0;
 }

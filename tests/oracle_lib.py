@@ -132,3 +132,19 @@ class Oracle:
         v = np.zeros(B, np.uint8)
         self.lib.oracle_ciphertext_proof_verify_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(c), p(z1), p(z2), p(c_prime), p(v))
         return v
+
+    # ---- VerlinProof
+    def verlin_proof_prove(self, n_bits, n, n_stride, c, c_prime, phi_x, witness, nonces):
+        B = c.shape[0]; zw = n_bits // 32 + 16
+        phi_a = np.zeros_like(c); r_z = np.zeros_like(c)
+        z = [np.zeros((B, zw), np.uint32) for _ in range(3)]
+        self.lib.oracle_verlin_proof_prove_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(c), p(c_prime), p(phi_x),
+                                                 *[p(a) for a in witness], *[p(a) for a in nonces], p(phi_a), p(z[0]), p(z[1]), p(z[2]), p(r_z))
+        return phi_a, z[0], z[1], z[2], r_z
+
+    def verlin_proof_verify(self, n_bits, n, n_stride, c, c_prime, phi_x, phi_a, z, zp, zpp, r_z):
+        B = c.shape[0]
+        v = np.zeros(B, np.uint8)
+        self.lib.oracle_verlin_proof_verify_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(c), p(c_prime), p(phi_x), p(phi_a),
+                                                  p(z), p(zp), p(zpp), p(r_z), p(v))
+        return v

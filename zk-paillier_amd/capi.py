@@ -72,6 +72,8 @@ EXPORTS = {
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_ciphertext_proof_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_verlin_proof_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64] + [C.c_void_p] * 16 + [C.c_uint32]),
+    "zkp_verlin_proof_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64] + [C.c_void_p] * 9 + [C.c_uint32]),
 }
 
 Z1_EXTRA_LIMBS = 16
@@ -213,3 +215,12 @@ class Context:
     def ciphertext_proof_verify(self, n_bits, batch, n, n_stride, c, z1, z2, c_prime, out_verdict):
         self.check(self.lib.zkp_ciphertext_proof_verify_batch(self.h, n_bits, batch, ptr(n), n_stride, ptr(c), ptr(z1), ptr(z2), ptr(c_prime),
                                                               ptr(out_verdict), self._flags(n, c, z1, z2, c_prime, out_verdict)))
+
+    def verlin_proof_prove(self, n_bits, batch, n, n_stride, c, c_prime, phi_x, witness, nonces, outs):
+        """witness = (x, x', x'', r_x); nonces = (a, a', a'', r_a); outs = (phi_a, z, z', z'', r_z)"""
+        arrs = [c, c_prime, phi_x, *witness, *nonces, *outs]
+        self.check(self.lib.zkp_verlin_proof_prove_batch(self.h, n_bits, batch, ptr(n), n_stride, *[ptr(a) for a in arrs], self._flags(n, *arrs)))
+
+    def verlin_proof_verify(self, n_bits, batch, n, n_stride, c, c_prime, phi_x, phi_a, z, zp, zpp, r_z, out_verdict):
+        arrs = [c, c_prime, phi_x, phi_a, z, zp, zpp, r_z, out_verdict]
+        self.check(self.lib.zkp_verlin_proof_verify_batch(self.h, n_bits, batch, ptr(n), n_stride, *[ptr(a) for a in arrs], self._flags(n, *arrs)))

@@ -528,6 +528,43 @@ __global__ void __launch_bounds__(256) k_sigma_hash(SigmaHashArgs a) {
   }
 }
 
+// VerlinProof challenge e = H(n || c || c' || phi_x || phi_a) (verlin_proof.rs:78-84, 102-108) and, for prove,
+// the three integer responses z = x e + a (:85-87).
+struct VerlinHashArgs {
+  const uint32_t* n; uint64_t n_stride; const uint32_t* v[4];   // c, c', phi_x, phi_a : [B][2kw]
+  uint32_t kw; uint64_t batch; uint32_t* e;
+  const uint32_t* x[3]; const uint32_t* a[3]; uint32_t* z[3]; uint32_t zw;   // nullable
+};
+__global__ void __launch_bounds__(256) k_verlin_hash(VerlinHashArgs a) {
+  __shared__ uint32_t shabuf[16 * 256];
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.batch) return;
+  const int kw = (int)a.kw;
+  Sha256 s;
+  s.init(shabuf + threadIdx.x, 256);
+  s.put_bigint(a.n + b * a.n_stride, kw);
+  for (int k = 0; k < 4; k++) s.put_bigint(a.v[k] + b * 2 * kw, 2 * kw);
+  uint32_t d[8], e[8];
+  s.finish(d);
+#pragma unroll
+  for (int k = 0; k < 8; k++) { e[k] = d[7 - k]; a.e[b * 8 + k] = e[k]; }
+  for (int q = 0; q < 3; q++) {
+    if (!a.z[q]) continue;
+    const uint32_t* x = a.x[q] + b * kw;
+    const uint32_t* ad = a.a[q] + b * kw;
+    uint32_t* z = a.z[q] + b * a.zw;
+    for (uint32_t w = 0; w < a.zw; w++) z[w] = w < (uint32_t)kw ? ad[w] : 0u;
+    for (int i = 0; i < 8; i++) {
+      uint64_t carry = 0;
+      for (int j = 0; j < kw; j++) {
+        const uint64_t t = (uint64_t)e[i] * x[j] + z[i + j] + carry;
+        z[i + j] = (uint32_t)t; carry = t >> 32;
+      }
+      for (uint32_t w = i + kw; carry && w < a.zw; w++) { const uint64_t t = (uint64_t)z[w] + carry; z[w] = (uint32_t)t; carry = t >> 32; }
+    }
+  }
+}
+
 // verdict[b] = (lhs[b] == rhs[b]) word for word (`c_z == c_z_test`, zero_enc_proof.rs:90, correct_ciphertext.rs:93)
 struct WordsCmpArgs { const uint32_t* lhs; const uint32_t* rhs; const uint32_t* consts; uint64_t const_stride; int st_off; uint32_t words; uint64_t batch; uint8_t* verdict; };
 __global__ void __launch_bounds__(256) k_words_compare(WordsCmpArgs a) {

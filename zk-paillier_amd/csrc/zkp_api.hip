@@ -25,7 +25,7 @@ struct zkp_ctx {
   hipStream_t stream = nullptr;
   int cus = 0;
   std::string err;
-  DevBuf consts, consts2, table, scratch[16];
+  DevBuf consts, consts2, table, scratch[24];
   // timing of the dominant kernels
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;

@@ -11,6 +11,7 @@
 //   zkproofs::{CompositeDLogProof,DLogStatement}::{prove,verify}    same
 //     src/zkproofs/wi_dlog_proof.rs:33-91
 //   zkproofs::{CorrectKey,Challenge,VerificationAid,CorrectKeyProof} same (interactive, correct_key.rs:28-183)
+//   zkproofs::{VerlinProof,VerlinStatement,VerlinWitness}, gen_phi   same (verlin_proof.rs:35-165)
 //   zkproofs::{ZeroProof,ZeroStatement,ZeroWitness}                 same (zero_enc_proof.rs:26-95)
 //   zkproofs::{CiphertextProof,CiphertextStatement,CiphertextWitness} same (correct_ciphertext.rs:23-98)
 //   paillier::{Keypair,EncryptionKey,DecryptionKey,Paillier}        same names, only what the path needs
@@ -475,6 +476,51 @@ class CiphertextProof {
     st.ek.n.to_limbs(n.data(), kw); st.c.to_limbs(c.data(), 2 * kw); z1.to_limbs(a1.data(), z1w); z2.to_limbs(a2.data(), 2 * kw); c_prime.to_limbs(ac.data(), 2 * kw);
     uint8_t v = 9;
     e.check(zkp_ciphertext_proof_verify_batch(e.ctx(), nb, 1, n.data(), 0, c.data(), a1.data(), a2.data(), ac.data(), &v, 0), "zkp_ciphertext_proof_verify_batch");
+    return Result(v == ZKP_VERDICT_ACCEPT);
+  }
+};
+
+// ------------------------------------------------------------------ VerlinProof (src/zkproofs/verlin_proof.rs:35-165)
+struct VerlinWitness { BigInt x, x_prime, x_double_prime, r_x; };
+struct VerlinStatement { EncryptionKey ek; BigInt c, c_prime, phi_x; };
+
+// gen_phi (verlin_proof.rs:138-165) = c^y * c'^y' * Enc(y'', r_y) mod n^2, from three batched GPU calls
+inline BigInt gen_phi(const EncryptionKey& ek, const BigInt& c, const BigInt& c_prime, const BigInt& y, const BigInt& y_prime,
+                      const BigInt& y_double_prime, const BigInt& r_y) {
+  std::vector<BigInt> p = mod_pow_batch({c, c_prime}, {y, y_prime}, ek.nn);
+  BigInt e3 = Paillier::encrypt_with_chosen_randomness(ek, y_double_prime % ek.n, r_y);   // (1 + m n) mod n^2 depends on m mod n only; r_y < n for honest callers
+  return ((p[0] * p[1]) % ek.nn) * e3 % ek.nn;
+}
+
+class VerlinProof {
+ public:
+  BigInt phi_a, z, z_prime, z_double_prime, r_z;
+  static VerlinProof prove(const VerlinWitness& w, const VerlinStatement& st) {   // :60-99
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.ek.n), kw = nb / 32, zw = kw + ZKP_Z1_EXTRA_LIMBS;
+    const BigInt a = BigInt::sample_below(st.ek.n), ap = BigInt::sample_below(st.ek.n), app = BigInt::sample_below(st.ek.n);   // :61-63
+    BigInt r_a = BigInt::sample_below(st.ek.n);
+    while (BigInt::gcd(r_a, st.ek.n) != BigInt::one()) r_a = BigInt::sample_below(st.ek.n);                                   // :64-67
+    auto L1 = [&](const BigInt& v, size_t n) { std::vector<uint32_t> o(n); v.to_limbs(o.data(), n); return o; };
+    auto n = L1(st.ek.n, kw), c = L1(st.c, 2 * kw), cp = L1(st.c_prime, 2 * kw), phx = L1(st.phi_x, 2 * kw);
+    auto x = L1(w.x, kw), xp = L1(w.x_prime, kw), xpp = L1(w.x_double_prime, kw), rx = L1(w.r_x, kw);
+    auto va = L1(a, kw), vap = L1(ap, kw), vapp = L1(app, kw), vra = L1(r_a, kw);
+    std::vector<uint32_t> pa(2 * kw), z(zw), zp(zw), zpp(zw), rz(2 * kw);
+    e.check(zkp_verlin_proof_prove_batch(e.ctx(), nb, 1, n.data(), 0, c.data(), cp.data(), phx.data(), x.data(), xp.data(), xpp.data(), rx.data(),
+                                         va.data(), vap.data(), vapp.data(), vra.data(), pa.data(), z.data(), zp.data(), zpp.data(), rz.data(), 0),
+            "zkp_verlin_proof_prove_batch");
+    return VerlinProof{BigInt::from_limbs(pa.data(), 2 * kw), BigInt::from_limbs(z.data(), zw), BigInt::from_limbs(zp.data(), zw),
+                       BigInt::from_limbs(zpp.data(), zw), BigInt::from_limbs(rz.data(), 2 * kw)};
+  }
+  Result verify(const VerlinStatement& st) const {                                // :101-135
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.ek.n), kw = nb / 32, zw = kw + ZKP_Z1_EXTRA_LIMBS;
+    auto L1 = [&](const BigInt& v, size_t n) { std::vector<uint32_t> o(n); v.to_limbs(o.data(), n); return o; };
+    auto n = L1(st.ek.n, kw), c = L1(st.c, 2 * kw), cp = L1(st.c_prime, 2 * kw), phx = L1(st.phi_x, 2 * kw), pa = L1(phi_a, 2 * kw);
+    auto vz = L1(z, zw), vzp = L1(z_prime, zw), vzpp = L1(z_double_prime, zw), vrz = L1(r_z, 2 * kw);
+    uint8_t v = 9;
+    e.check(zkp_verlin_proof_verify_batch(e.ctx(), nb, 1, n.data(), 0, c.data(), cp.data(), phx.data(), pa.data(), vz.data(), vzp.data(), vzpp.data(),
+                                          vrz.data(), &v, 0), "zkp_verlin_proof_verify_batch");
     return Result(v == ZKP_VERDICT_ACCEPT);
   }
 };
