@@ -35,17 +35,49 @@ struct RangeHashArgs {
   uint8_t ok_value;    // value written when the challenge is long enough
 };
 
-__global__ void __launch_bounds__(256) k_range_hash(RangeHashArgs a) {
-  __shared__ uint32_t shabuf[16 * 256];
-  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.batch) return;
+// One wavefront per 64 proofs, one proof per lane (SHA-256 is sequential per proof).  The operands are read with
+// wave-cooperative coalesced loads (512 B per instruction) into an LDS tile of 64 rows (row stride 2kw+1 words: the
+// lanes then walk their own rows conflict-free), instead of 64 lanes each chasing its own 4-byte stream through HBM.
+constexpr int HASH_PROOFS = 64;
+
+__device__ __forceinline__ void hash_stage_value(uint32_t* tile, int row_stride, const uint32_t* base, uint64_t proof_stride_words,
+                                                  int nwords, int nproofs, int lane) {
+  // tile[p][w] = base[p * proof_stride_words + w]
+  wave_lds_fence();
+  for (int w0 = 0; w0 < nwords; w0 += 64) {
+    const int w = w0 + lane;
+#pragma unroll 8
+    for (int p = 0; p < HASH_PROOFS; p++) {
+      if (p < nproofs && w < nwords) tile[p * row_stride + w] = base[(uint64_t)p * proof_stride_words + w];
+    }
+  }
+  wave_lds_fence();
+}
+
+__global__ void __launch_bounds__(HASH_PROOFS) k_range_hash(RangeHashArgs a) {
+  extern __shared__ __align__(16) uint32_t hash_lds[];
+  const int lane = threadIdx.x;
+  const uint64_t b0 = (uint64_t)blockIdx.x * HASH_PROOFS;
+  const uint64_t b = b0 + lane;
+  const bool live = b < a.batch;
+  const int nproofs = (int)((a.batch - b0) < HASH_PROOFS ? (a.batch - b0) : HASH_PROOFS);
+  const int kw = (int)a.kw, row_stride = 2 * kw + 1;
+  uint32_t* shabuf = hash_lds;                         // [16][64]
+  uint32_t* tile = hash_lds + 16 * HASH_PROOFS;        // [64][2kw+1]
+  const uint32_t* row = tile + lane * row_stride;
   Sha256 s;
-  s.init(shabuf + threadIdx.x, 256);
-  s.put_bigint(a.n + b * a.n_stride, (int)a.kw);
-  const uint32_t* c1 = a.c1 + b * a.ef * 2 * a.kw;
-  const uint32_t* c2 = a.c2 + b * a.ef * 2 * a.kw;
-  for (uint32_t i = 0; i < a.ef; i++) s.put_bigint(c1 + (uint64_t)i * 2 * a.kw, 2 * (int)a.kw);
-  for (uint32_t i = 0; i < a.ef; i++) s.put_bigint(c2 + (uint64_t)i * 2 * a.kw, 2 * (int)a.kw);
+  s.init(shabuf + lane, HASH_PROOFS);
+  hash_stage_value(tile, row_stride, a.n + b0 * a.n_stride, a.n_stride, kw, nproofs, lane);
+  if (live) s.put_bigint(row, kw);
+  const uint64_t pstride = (uint64_t)a.ef * 2 * kw;    // words between consecutive proofs in c1 / c2
+  for (int half = 0; half < 2; half++) {
+    const uint32_t* cbase = (half ? a.c2 : a.c1) + b0 * pstride;
+    for (uint32_t i = 0; i < a.ef; i++) {
+      hash_stage_value(tile, row_stride, cbase + (uint64_t)i * 2 * kw, pstride, 2 * kw, nproofs, lane);
+      if (live) s.put_bigint(row, 2 * kw);
+    }
+  }
+  if (!live) return;
   uint32_t d[8];
   s.finish(d);
   uint8_t db[32];

@@ -30,13 +30,13 @@ struct Sha256 {
 
   __device__ __forceinline__ static uint32_t ror(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
 
-  __device__ void init(uint32_t* lds_buf, int lds_stride) {
+  __device__ __forceinline__ void init(uint32_t* lds_buf, int lds_stride) {
     h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
     h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
     buf = lds_buf; stride = lds_stride; widx = 0; pend = 0; npend = 0; nbytes = 0;
   }
 
-  __device__ void compress() {
+  __device__ __forceinline__ void compress() {
     uint32_t w[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = buf[i * stride];
@@ -89,7 +89,7 @@ struct Sha256 {
 
   // minimal big-endian encoding of the little-endian limb array v[0..nwords): zero -> one 00 byte
   // ([upstream] curv BigInt::to_bytes over GMP: (sizeinbase(x,2)+7)/8 bytes)
-  __device__ void put_bigint(const uint32_t* v, int nwords) {
+  __device__ __forceinline__ void put_bigint(const uint32_t* v, int nwords) {
     int top = nwords - 1;
     while (top > 0 && v[top] == 0) top--;
     const uint32_t tw = v[top];
@@ -98,7 +98,7 @@ struct Sha256 {
     for (int i = top - 1; i >= 0; i--) put_word(v[i]);
   }
 
-  __device__ void finish(uint32_t (&out)[8]) {
+  __device__ __forceinline__ void finish(uint32_t (&out)[8]) {
     const uint64_t bits = nbytes * 8;
     put_bytes(0x80, 1);
     // pad with zero bytes until 8 bytes remain in the block
