@@ -156,6 +156,32 @@ def test_boundary_masked_x(ctx, oracle):
     assert np.array_equal(vo, vg)
 
 
+def test_masked_x_exactly_T_is_accepted(ctx, oracle):
+    """N3: the verifier's Mask check is inclusive (range_proof.rs:338) while the prover's choice is strict (:233-234).
+    With w2 = T - x on every row, x + w1 = 2T fails the strict test, the prover answers j = 2 with masked_x = T exactly,
+    and the verifier must accept it."""
+    n_bits, kw = 1024, 32
+    n = H.test_key(1024)[2]
+    cases = H.build_range_case(b"gpu-eqT", [n], n_bits, 2)
+    for c in cases:
+        T = c["range"] // 3
+        c["w2"] = [T - c["x"]] * 128
+        c["w1"] = [2 * T - c["x"]] * 128
+    pb_o, wt = H.fill_batch(cases, n_bits, True, oracle)
+    pb_g = clone_inputs(pb_o)
+    oracle_prove(oracle, pb_o, wt)
+    gpu_prove(ctx, pb_g, wt)
+    assert_same_proofs(pb_o, pb_g)
+    mask = pb_g.resp_kind == zkp.RESP_MASK
+    assert mask.any() and (pb_g.resp_j[mask] == 2).all()
+    T0 = cases[0]["range"] // 3
+    assert all(L.limbs_to_int(pb_g.resp_w1[0, i]) == T0 for i in range(128) if mask[0, i])
+    vo = np.zeros(2, np.uint8); vg = np.full(2, 7, np.uint8)
+    oracle.range_ni_verify(pb_o.struct(), vo)
+    ctx.range_ni_verify(pb_g.struct(), vg, device=False)
+    assert list(vo) == list(vg) == [zkp.VERDICT_ACCEPT] * 2
+
+
 def test_device_pointer_mode_and_error_factor_zero(ctx, oracle):
     torch = pytest.importorskip("torch")
     n_bits = 1024
