@@ -66,7 +66,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run (RANK / WORLD_SIZE set) the RCCL path is exercised even at world size 1
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -87,7 +89,7 @@ def main():
 
     def barrier():
         sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         sync()
 
@@ -98,14 +100,14 @@ def main():
     sync()
     pstruct, wstruct = pb.struct(), wt.struct()
     verdict = torch.zeros(B, dtype=torch.uint8, device=dev)
-    gathered_v = torch.zeros(B * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered_v = torch.zeros(B * world, dtype=torch.uint8, device=dev) if use_dist else None
     gathered_c = None
-    if world > 1 and not args.no_prove_leg:
+    if use_dist and not args.no_prove_leg:
         gathered_c = [torch.empty((B * world,) + tuple(pb.c1.shape[1:]), dtype=pb.c1.dtype, device=dev) for _ in range(2)]
 
     def prove_step():
         ctx.range_ni_prove(pstruct, wstruct, None, None, None, device=True)
-        if world > 1:
+        if use_dist:
             ctx.synchronize()
             dist.all_gather_into_tensor(gathered_c[0], pb.c1)
             dist.all_gather_into_tensor(gathered_c[1], pb.c2)
@@ -113,7 +115,7 @@ def main():
 
     def verify_step():
         ctx.range_ni_verify(pstruct, verdict, device=True)
-        if world > 1:
+        if use_dist:
             ctx.synchronize()
             dist.all_gather_into_tensor(gathered_v, verdict)
             torch.cuda.synchronize()
@@ -130,7 +132,7 @@ def main():
         dt = time.perf_counter() - t0
         kms, launches, modexps = ctx.timing_get()
         ctx.timing_reset(False)
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -156,8 +158,10 @@ def main():
     dt, kms, launches, modexps = timed(verify_step, args.steps, args.warmup)
     sync()
     ok = bool(torch.equal(verdict, expect))
-    if world > 1:
+    if use_dist:
         ok = ok and bool(torch.equal(gathered_v.view(world, B)[rank], expect))
+        if gathered_c is not None:
+            ok = ok and bool(torch.equal(gathered_c[0].view(world, B, *pb.c1.shape[1:])[rank], pb.c1))
     value = B * world * args.steps / dt
     enc_per_launch = modexps / max(launches, 1)
     ach = modexps * enc_limb_macs(n_bits) / (kms * 1e-3) if kms else 0.0
@@ -239,10 +243,10 @@ def main():
                "data": "synthetic", "verdicts_ok": ok,
                "config": {"workload": f"BASELINE.json configs[1]: batch={B} RangeProofNi verify per GPU, n={n_bits} (reference fixture key), "
                                       f"128 rows/proof, 1/64 of the proofs tampered; prove leg = configs[2]",
-                          "parallelism": f"proof-index sharding x{world}, all-gather of verdicts" if world > 1 else "single GPU"},
+                          "parallelism": f"proof-index sharding x{world}, RCCL all-gather of verdicts (verify) and c1/c2 slabs (prove)" if use_dist else "single GPU"},
                "prove": prove, "roofline": roofline, "cpu_baseline": cpu, "other_configs": other}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
