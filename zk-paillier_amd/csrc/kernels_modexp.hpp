@@ -524,6 +524,7 @@ struct EncArgs {
   uint8_t* verdict;             // [B] a failing item clears its proof's verdict
   const unsigned long long* count_ptr;   // mode 1: device-resident item count (overrides `count`)
   const uint8_t* sched;                  // sliding-window schedule when every item uses the same key (exponent n), or null
+  unsigned long long* work_counter;      // zeroed per launch: wavefronts claim work items (64/G at a time) dynamically
   uint32_t ef;
 };
 
@@ -552,16 +553,21 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
   Grp<G> g;
   grp_init<G>(g, lds_raw);
   const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
-  const uint64_t ngrp = (uint64_t)gridDim.x * LL::GROUPS_PER_BLOCK;
   uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
   const int kw = a.n_bits / 32;
   const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
-  const uint64_t rounds = (count + ngrp - 1) / ngrp;
   const int lane = threadIdx.x & 63;
   const unsigned long long gmask = ((1ull << G) - 1) << (lane & ~(G - 1));
   const int nsteps = a.mode == 0 ? 6 : 10;
-  for (uint64_t rd = 0; rd < rounds; rd++) {
-    const uint64_t idx = rd * ngrp + ggrp;
+  // Work items are claimed per wavefront (64/G consecutive items at a time) from a device counter: the verify work
+  // list has a data-dependent length, a static round-robin would leave most of the chip idle in its last round.
+  // Every group of a wavefront runs the same number of iterations (surplus groups recompute the last item).
+  for (;;) {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / G));
+    base = __shfl(base, 0);
+    if (base >= count) break;
+    const uint64_t idx = base + (uint64_t)(lane / G);
     const bool live = idx < count;
     const uint64_t item = live ? idx : count - 1;
     uint64_t key;

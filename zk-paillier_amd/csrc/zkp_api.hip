@@ -152,6 +152,17 @@ static int32_t build_schedule(zkp_ctx* c, const uint32_t* exp_words, uint32_t ex
   return ZKP_OK;
 }
 
+// zeroed work counter for the next k_enc launch (ctx scratch slot 18; one 8-byte slot per launch in flight is enough
+// because launches of one ctx are ordered on its stream)
+static int32_t fresh_work_counter(zkp_ctx* c, unsigned long long** out) {
+  DevBuf& b = c->scratch[18];
+  int32_t st = ensure(c, b, 64);
+  if (st) return st;
+  HIPCHK(c, hipMemsetAsync(b.p, 0, 64, c->stream));
+  *out = (unsigned long long*)b.p;
+  return ZKP_OK;
+}
+
 template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_t items, unsigned* blocks_out) {
   using LL = LdsLayout<G>;
   const uint64_t need = (items + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK;
@@ -350,6 +361,7 @@ static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint3
   a.table = (uint32_t*)c->table.p; a.count = count; a.n_bits = (int)n_bits; a.mode = 0;
   a.m = m; a.r = r; a.out = out; a.items_per_key = n_stride ? 1 : count;
   if (n_stride == 0 && (st = build_schedule(c, n, n_bits, &a.sched))) return st;
+  if ((st = fresh_work_counter(c, &a.work_counter))) return st;
   {
     TimedRegion tr(c, count);
     hipLaunchKernelGGL(k_enc<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
