@@ -411,6 +411,7 @@ struct ModexpArgs {
   int io_words;             // words per base element (<= NW; values are zero-extended)
   int out_words;            // words per out element
   const uint8_t* sched;     // sliding-window schedule of the launch-uniform exponent (k_sliding_schedule), or null
+  unsigned long long* work_counter;   // zeroed per launch: wavefronts claim 64/G items at a time
 };
 
 template <int G>
@@ -422,13 +423,16 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
   Grp<G> g;
   grp_init<G>(g, lds_raw);
   const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
-  const uint64_t ngrp = (uint64_t)gridDim.x * LL::GROUPS_PER_BLOCK;
   uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
   const int exp_words = a.exp_bits / 32;
-  // every wave iterates the same number of times; surplus groups recompute the last item and skip the store
-  const uint64_t rounds = (a.count + ngrp - 1) / ngrp;
-  for (uint64_t rd = 0; rd < rounds; rd++) {
-    const uint64_t idx = rd * ngrp + ggrp;
+  // wavefronts claim 64/G consecutive items at a time; surplus groups recompute the last item and skip the store
+  const int lane = threadIdx.x & 63;
+  for (;;) {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / G));
+    base = __shfl(base, 0);
+    if (base >= a.count) break;
+    const uint64_t idx = base + (uint64_t)(lane / G);
     const bool live = idx < a.count;
     const uint64_t item = live ? idx : a.count - 1;
     const uint32_t* cst = a.consts + item * a.const_stride;

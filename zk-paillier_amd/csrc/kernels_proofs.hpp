@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(256) k_ck_hash(CkHashArgs a) {
 struct CkCheckArgs {
   const uint32_t* n; const uint32_t* sigma; const uint32_t* mgf; const uint32_t* consts;
   uint32_t* table; uint8_t* verdict; uint64_t count; int n_bits;
+  unsigned long long* work_counter;
 };
 
 template <int G>
@@ -334,12 +335,15 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
   Grp<G> g;
   grp_init<G>(g, lds_raw);
   const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
-  const uint64_t ngrp = (uint64_t)gridDim.x * LL::GROUPS_PER_BLOCK;
   uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
   const int kw = a.n_bits / 32;
-  const uint64_t rounds = (a.count + ngrp - 1) / ngrp;
-  for (uint64_t rd = 0; rd < rounds; rd++) {
-    const uint64_t idx = rd * ngrp + ggrp;
+  const int lane0 = threadIdx.x & 63;
+  for (;;) {
+    unsigned long long base = 0;
+    if (lane0 == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / G));
+    base = __shfl(base, 0);
+    if (base >= a.count) break;
+    const uint64_t idx = base + (uint64_t)(lane0 / G);
     const bool live = idx < a.count;
     const uint64_t item = live ? idx : a.count - 1;
     const uint64_t b = item / ZKP_CORRECT_KEY_M2;

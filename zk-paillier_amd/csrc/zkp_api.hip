@@ -250,7 +250,9 @@ static int32_t modexp_core(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const 
   if ((st = table_for<G>(c, k_modexp<G>, count, &blocks))) return st;
   const uint8_t* sched = nullptr;
   if (exp_stride == 0 && (st = build_schedule(c, exp, exp_bits, &sched))) return st;
-  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words, out_words ? out_words : io_words, sched};
+  unsigned long long* wc = nullptr;
+  if ((st = fresh_work_counter(c, &wc))) return st;
+  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words, out_words ? out_words : io_words, sched, wc};
   {
     TimedRegion tr(c, count);
     hipLaunchKernelGGL(k_modexp<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
