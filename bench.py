@@ -19,13 +19,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# measured on MI355X (profiles/valu_rates_r01.jsonl): v_mad_u64_u32, 8 waves/SIMD, 256 CUs
-PEAK_LIMB_MAC_PER_S = 3.19e13
+# measured on MI355X (profiles/valu_rates_long_r01.jsonl, 16 ms kernels so that the clock has settled):
+# v_mad_u64_u32, 16 independent accumulators, 8 waves/SIMD, 256 CUs -> 3.474e13 lane-MAC/s (4.53 cycles per wave64 issue);
+# the short (1 ms) run of profiles/valu_rates_r01.jsonl read 3.19e13 and was used in the first bench lines of this round
+PEAK_LIMB_MAC_PER_S = 3.474e13
 HBM_PEAK_GBS = 8000.0
 # HBM-side bytes per Enc of k_enc measured with rocprofv3 PMC passes of this same command
-# (profiles/r01_pmc_bench_b512_v4kernel.json: FETCH_SIZE 83.7 KB + WRITE_SIZE 21.8 KB per Enc, raw counters;
+# (profiles/r01_pmc_bench_b512_v5kernel.json: FETCH_SIZE 86.2 KB + WRITE_SIZE 21.8 KB per Enc, raw counters;
 # almost all of it is the per-exponentiation window table spilling out of L2, not operand traffic)
-PMC_HBM_BYTES_PER_ENC = 83737.6 + 21779.5
+PMC_HBM_BYTES_PER_ENC = 86193.1 + 21814.2
 # algorithmic 32x32->64 limb-MACs of one Enc at n=2048: 1.2*2048 modmuls x (2*128^2+128)
 def enc_limb_macs(n_bits):
     Lw = 2 * n_bits // 32
@@ -169,7 +171,7 @@ def main():
     bytes_per_enc = 4 * kw * 4 + 8
     roofline = {"bound": "valu", "achieved": ach / 1e12, "peak": PEAK_LIMB_MAC_PER_S / 1e12, "unit": "Tlimb-MAC/s",
                 "frac": ach / PEAK_LIMB_MAC_PER_S, "traffic": PMC_HBM_BYTES_PER_ENC * enc_per_launch,
-                "traffic_note": "bytes per launch = PMC-measured FETCH_SIZE+WRITE_SIZE per Enc (profiles/r01_pmc_bench_b512_v4kernel.json) x Enc of the launch; algorithmic operand bytes are ~1 KB per Enc",
+                "traffic_note": "bytes per launch = PMC-measured FETCH_SIZE+WRITE_SIZE per Enc (profiles/r01_pmc_bench_b512_v5kernel.json) x Enc of the launch; algorithmic operand bytes are ~1 KB per Enc",
                 "kernel": f"k_enc<{144 // lpl}> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer)",
                 "kernel_ms_per_launch": kms / max(launches, 1),
                 "modexps_per_launch": enc_per_launch,

@@ -4,7 +4,10 @@
 #include <cstdio>
 #include <cstdint>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
-constexpr int ITER = 8192;
+#ifndef ITER_N
+#define ITER_N 8192
+#endif
+constexpr int ITER = ITER_N;
 
 #define DECL uint64_t acc[16]; uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x; uint32_t x[8]; \
   _Pragma("unroll") for (int i = 0; i < 16; i++) acc[i] = i + threadIdx.x; \

@@ -13,7 +13,10 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 
-constexpr int ITER = 4096;
+#ifndef ITER_N
+#define ITER_N 4096
+#endif
+constexpr int ITER = ITER_N;
 
 #define REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
