@@ -411,9 +411,9 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
 // ------------------------------------------------------------------------------------------
 // CompositeDLogProof (wi_dlog_proof.rs:46-91), one thread per proof for the byte/word-level parts.
 
-// gcd(a, N) == 1 for odd N: binary GCD on kw-word integers kept in thread-interleaved global scratch
-// (word w of thread t at base[w * stride + t]: coalesced).
-__device__ bool coprime_to_odd(const uint32_t* a, const uint32_t* N, int kw, uint32_t* u, uint32_t* v, uint64_t stride) {
+// gcd(a, N) == 1 for odd N: binary GCD on kw-word integers kept in thread-interleaved LDS
+// (word w of lane t at base[w * stride + t]: conflict-free).  Trailing zeros are stripped many bits at a time.
+__device__ __forceinline__ bool coprime_to_odd(const uint32_t* a, const uint32_t* N, int kw, uint32_t* u, uint32_t* v, int stride) {
   bool uz = true;
   for (int w = 0; w < kw; w++) { const uint32_t x = a[w]; u[w * stride] = x; v[w * stride] = N[w]; uz = uz && x == 0; }
   if (uz) {                         // gcd(0, N) = N
@@ -421,30 +421,38 @@ __device__ bool coprime_to_odd(const uint32_t* a, const uint32_t* N, int kw, uin
     for (int w = 1; w < kw; w++) one = one && N[w] == 0;
     return one;
   }
+  int nu = kw, nv = kw;             // live word counts (high words that became zero are skipped)
   for (;;) {
-    // make u odd
-    for (;;) {
-      if (u[0] & 1) break;
-      uint32_t carry = 0;
-      for (int w = kw - 1; w >= 0; w--) { const uint32_t x = u[w * stride]; u[w * stride] = (x >> 1) | (carry << 31); carry = x & 1; }
+    // make u odd: drop whole zero words, then the remaining trailing zero bits at once
+    int zw = 0;
+    while (u[zw * stride] == 0) zw++;                 // u != 0 here
+    const int zb = __builtin_ctz(u[zw * stride]);
+    if (zw | zb) {
+      for (int w = 0; w < nu; w++) {
+        const int s0 = w + zw;
+        const uint32_t lo = s0 < nu ? u[s0 * stride] : 0u, hi = s0 + 1 < nu ? u[(s0 + 1) * stride] : 0u;
+        u[w * stride] = zb ? ((lo >> zb) | (hi << (32 - zb))) : lo;
+      }
     }
+    while (nu > 1 && u[(nu - 1) * stride] == 0) nu--;
+    while (nv > 1 && v[(nv - 1) * stride] == 0) nv--;
     // compare
-    int cmp = 0;
-    for (int w = kw - 1; w >= 0; w--) {
+    int cmp = nu != nv ? (nu > nv ? 1 : -1) : 0;
+    for (int w = nu - 1; cmp == 0 && w >= 0; w--) {
       const uint32_t x = u[w * stride], y = v[w * stride];
-      if (x != y) { cmp = x > y ? 1 : -1; break; }
+      if (x != y) cmp = x > y ? 1 : -1;
     }
     if (cmp == 0) break;            // gcd = u = v
-    if (cmp < 0) { uint32_t* t = u; u = v; v = t; }
+    if (cmp < 0) { uint32_t* t = u; u = v; v = t; const int tn = nu; nu = nv; nv = tn; }
     uint32_t borrow = 0;            // u -= v  (both odd -> u even, non-zero)
-    for (int w = 0; w < kw; w++) {
-      const uint64_t d = (uint64_t)u[w * stride] - v[w * stride] - borrow;
+    for (int w = 0; w < nu; w++) {
+      const uint64_t d = (uint64_t)u[w * stride] - (w < nv ? v[w * stride] : 0u) - borrow;
       u[w * stride] = (uint32_t)d;
       borrow = (uint32_t)(d >> 63);
     }
   }
   bool one = v[0] == 1;
-  for (int w = 1; w < kw; w++) one = one && v[w * stride] == 0;
+  for (int w = 1; w < nv; w++) one = one && v[w * stride] == 0;
   return one;
 }
 
@@ -454,19 +462,20 @@ struct DlogHashArgs {
   uint32_t* e;            // [B][8] little-endian words of e = H(x || g || N || ni)
   // verify only
   uint8_t* verdict;       // ACCEPT / MALFORMED to start with (nullable in prove)
-  uint32_t* gcd_scratch;  // [2][2*kw][B]
   // prove only: y = r + e * secret  (wi_dlog_proof.rs:62)
   const uint32_t* secret; const uint32_t* r; uint32_t* y; uint32_t yw;
 };
 
-__global__ void __launch_bounds__(256) k_dlog_hash(DlogHashArgs a) {
-  __shared__ uint32_t shabuf[16 * 256];
-  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+constexpr int DLOG_THREADS = 64;
+__global__ void __launch_bounds__(DLOG_THREADS) k_dlog_hash(DlogHashArgs a) {
+  extern __shared__ __align__(16) uint32_t dlog_lds[];   // [16][64] SHA block buffers | [2*kw][64] gcd operands
+  uint32_t* shabuf = dlog_lds;
+  const uint64_t b = (uint64_t)blockIdx.x * DLOG_THREADS + threadIdx.x;
   if (b >= a.batch) return;
   const int kw = (int)a.kw;
   const uint32_t *N = a.N + b * kw, *g = a.g + b * kw, *ni = a.ni + b * kw, *x = a.x + b * kw;
   Sha256 s;
-  s.init(shabuf + threadIdx.x, 256);
+  s.init(shabuf + threadIdx.x, DLOG_THREADS);
   s.put_bigint(x, kw); s.put_bigint(g, kw); s.put_bigint(N, kw); s.put_bigint(ni, kw);   // :56-61 / :75-80
   uint32_t d[8], e[8];
   s.finish(d);
@@ -479,9 +488,9 @@ __global__ void __launch_bounds__(256) k_dlog_hash(DlogHashArgs a) {
     big = big || N[4] > 1 || (N[4] == 1 && (N[0] | N[1] | N[2] | N[3]) != 0);
     bool ok = big && (N[0] & 1);    // even N: Montgomery path undefined -> reported as malformed (documented deviation)
     if (ok) {
-      uint32_t* u = a.gcd_scratch + b;
-      uint32_t* v = a.gcd_scratch + (uint64_t)kw * a.batch + b;
-      ok = coprime_to_odd(g, N, kw, u, v, a.batch) && coprime_to_odd(ni, N, kw, u, v, a.batch);
+      uint32_t* u = dlog_lds + 16 * DLOG_THREADS + threadIdx.x;
+      uint32_t* v = u + kw * DLOG_THREADS;
+      ok = coprime_to_odd(g, N, kw, u, v, DLOG_THREADS) && coprime_to_odd(ni, N, kw, u, v, DLOG_THREADS);
     }
     a.verdict[b] = ok ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_MALFORMED;
   }
