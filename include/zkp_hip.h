@@ -149,6 +149,20 @@ int32_t zkp_range_ni_prove_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p,
 int32_t zkp_range_ni_verify_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p,
                                   uint8_t* out_verdict, uint32_t flags);
 
+/* The three functions of the interactive RangeProof, usable on their own with any error_factor <= 256 and a
+ * challenge supplied by the caller (the verifier's random bits of RangeProof::verifier_commit, range_proof.rs:118-126;
+ * benches/all.rs:10-53 runs them with STATISTICAL_ERROR_FACTOR = 40).  e: [B][32] challenge bytes left aligned,
+ * e_len: [B] byte counts (bit i of a challenge is bit 7-(i%8) of byte i/8, range_proof.rs:221,267).
+ *   generate_encrypted_pairs (range_proof.rs:128-193): c1 = Enc(w1, r1), c2 = Enc(w2, r2), EF = p->error_factor rows
+ *   generate_proof           (range_proof.rs:210-252): resp_* from the witness and e
+ *   verifier_output          (range_proof.rs:254-355): verdicts from (c1, c2, resp_*, e) */
+int32_t zkp_range_generate_encrypted_pairs_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w,
+                                                 uint32_t flags);
+int32_t zkp_range_generate_proof_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w,
+                                       const uint8_t* e, const uint8_t* e_len, uint8_t* out_status, uint32_t flags);
+int32_t zkp_range_verifier_output_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p, const uint8_t* e, const uint8_t* e_len,
+                                        uint8_t* out_verdict, uint32_t flags);
+
 /* ------------------------------------------------------------------ NiCorrectKeyProof
  * NiCorrectKeyProof::verify (src/zkproofs/correct_key_ni.rs:73-100) for B (key, proof)
  * pairs: rho_i from the SHA-256 MGF (:77-86,105-117), sigma_i^n mod n (:90-93),

@@ -236,9 +236,13 @@ static uint32_t fs_challenge(const mpz_t n, const uint32_t* c1, const uint32_t* 
 /* bit_vec::BitVec::from_bytes indexing (range_proof.rs:221,225,267,272): MSB first. */
 static int challenge_bit(const uint8_t* e, uint32_t i) { return (e[i / 8] >> (7 - (i % 8))) & 1; }
 
-int32_t oracle_range_ni_prove_batch(const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w, uint8_t* out_e,
-                                    uint8_t* out_e_len, uint8_t* out_status) {
-  const size_t kw = p->n_bits / 32, EF = ZKP_SECURITY_PARAMETER;
+/* phases: 1 = generate_encrypted_pairs (range_proof.rs:128-193), 2 = generate_proof (:210-252).  e_in != NULL:
+ * externally supplied challenge bytes (the interactive protocol, RangeProof::verifier_commit :118-126), else the
+ * Fiat-Shamir challenge of RangeProofNi::prove (range_proof_ni.rs:58-61). */
+static int32_t range_prove_core(const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w, size_t EF, int phases, const uint8_t* e_in,
+                                const uint8_t* e_len_in, uint8_t* out_e, uint8_t* out_e_len, uint8_t* out_status) {
+  const size_t kw = p->n_bits / 32;
+  if (phases & 1) {
   /* generate_encrypted_pairs, range_proof.rs:161-187 (randomness injected, :136-159); the pool runs over the
    * flattened (proof, c1|c2, row) list */
 #pragma omp parallel num_threads(n_threads)
@@ -264,6 +268,8 @@ int32_t oracle_range_ni_prove_batch(const zkp_range_ni_proofs* p, const zkp_rang
     }
     mpz_clears(zn, znn, zm, zr, zc, t, NULL);
   }
+  }
+  if (!(phases & 2)) return 0;
   for (uint64_t b = 0; b < p->batch; b++) {
     const uint32_t* nl = p->n + b * p->n_stride;
     uint32_t* c1 = p->c1 + b * EF * 2 * kw;
@@ -272,7 +278,9 @@ int32_t oracle_range_ni_prove_batch(const zkp_range_ni_proofs* p, const zkp_rang
     mpz_inits(zn, x, r, third, two_thirds, t, u, wv, rv, NULL);
     limbs_to_mpz(zn, nl, kw);
     uint8_t e[32];
-    uint32_t elen = fs_challenge(zn, c1, c2, (uint32_t)EF, kw, e);
+    uint32_t elen;
+    if (e_in) { memcpy(e, e_in + b * 32, 32); elen = e_len_in[b]; }
+    else elen = fs_challenge(zn, c1, c2, (uint32_t)EF, kw, e);
     if (out_e) memcpy(out_e + b * 32, e, 32);
     if (out_e_len) out_e_len[b] = (uint8_t)elen;
     uint8_t status = 0;
@@ -318,7 +326,19 @@ int32_t oracle_range_ni_prove_batch(const zkp_range_ni_proofs* p, const zkp_rang
   return 0;
 }
 
-int32_t oracle_range_ni_verify_batch(const zkp_range_ni_proofs* p, uint8_t* out_verdict) {
+int32_t oracle_range_ni_prove_batch(const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w, uint8_t* out_e,
+                                    uint8_t* out_e_len, uint8_t* out_status) {
+  return range_prove_core(p, w, ZKP_SECURITY_PARAMETER, 3, NULL, NULL, out_e, out_e_len, out_status);
+}
+int32_t oracle_range_generate_encrypted_pairs_batch(const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w) {
+  return range_prove_core(p, w, p->error_factor, 1, NULL, NULL, NULL, NULL, NULL);
+}
+int32_t oracle_range_generate_proof_batch(const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w, const uint8_t* e,
+                                          const uint8_t* e_len, uint8_t* out_status) {
+  return range_prove_core(p, w, p->error_factor, 2, e, e_len, NULL, NULL, out_status);
+}
+
+static int32_t range_verify_core(const zkp_range_ni_proofs* p, const uint8_t* e_in, const uint8_t* e_len_in, uint8_t* out_verdict) {
   const size_t kw = p->n_bits / 32, EF = p->error_factor;
   const int64_t B = (int64_t)p->batch;
   uint8_t* e_all = (uint8_t*)calloc((size_t)B + 1, 32);
@@ -328,7 +348,9 @@ int32_t oracle_range_ni_verify_batch(const zkp_range_ni_proofs* p, uint8_t* out_
     mpz_t zn;
     mpz_init(zn);
     limbs_to_mpz(zn, p->n + b * p->n_stride, kw);
-    uint32_t elen = fs_challenge(zn, p->c1 + b * EF * 2 * kw, p->c2 + b * EF * 2 * kw, (uint32_t)EF, kw, e_all + b * 32);
+    uint32_t elen;
+    if (e_in) { memcpy(e_all + b * 32, e_in + b * 32, 32); elen = e_len_in[b]; }
+    else elen = fs_challenge(zn, p->c1 + b * EF * 2 * kw, p->c2 + b * EF * 2 * kw, (uint32_t)EF, kw, e_all + b * 32);
     /* bits_of_e[i] index panic when the challenge is shorter than error_factor bits */
     out_verdict[b] = ((size_t)elen * 8 < EF) ? ZKP_VERDICT_MALFORMED : ZKP_VERDICT_ACCEPT;
     mpz_clear(zn);
@@ -393,6 +415,14 @@ int32_t oracle_range_ni_verify_batch(const zkp_range_ni_proofs* p, uint8_t* out_
   }
   free(e_all);
   return 0;
+}
+
+int32_t oracle_range_ni_verify_batch(const zkp_range_ni_proofs* p, uint8_t* out_verdict) {
+  return range_verify_core(p, NULL, NULL, out_verdict);
+}
+/* RangeProof::verifier_output (range_proof.rs:254-355) with the verifier's own challenge bytes (interactive protocol) */
+int32_t oracle_range_verifier_output_batch(const zkp_range_ni_proofs* p, const uint8_t* e, const uint8_t* e_len, uint8_t* out_verdict) {
+  return range_verify_core(p, e, e_len, out_verdict);
 }
 
 /* ------------------------------------------------------------------ NiCorrectKeyProof */

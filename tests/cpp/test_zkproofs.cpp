@@ -208,7 +208,60 @@ static void verlin_case(bool bad) {
 static void test_verlin_proof() { verlin_case(false); }
 static void test_bad_verlin_proof() { verlin_case(true); }   // #[should_panic]
 
+// ---- range_proof.rs tests (:385-525)
+static constexpr size_t SEF = RangeProof::STATISTICAL_ERROR_FACTOR;
+static void test_generate_encrypted_pairs() {   // :386-391
+  auto [ek, dk] = test_keypair().keys();
+  BigInt range = BigInt(0x000FFFFFFFFFFFFFull);
+  auto [ep, data] = RangeProof::generate_encrypted_pairs(ek, range, SEF);
+  ASSERT(ep.c1.size() == SEF && ep.c2.size() == SEF && data.w1.size() == SEF);
+  for (size_t i = 0; i < SEF; i++) ASSERT(ep.c1[i] == Paillier::encrypt_with_chosen_randomness(ek, data.w1[i], data.r1[i]));
+}
+static void test_commit_decommit() {   // :394-408
+  auto [verifier_ek, verifier_dk] = test_keypair().keys();
+  auto vc = RangeProof::verifier_commit(verifier_ek);
+  auto [challenge, verification_aid] = CorrectKey::challenge(verifier_ek);
+  auto proof_results = CorrectKey::prove(verifier_dk, challenge);
+  ASSERT(proof_results.is_ok());
+  ASSERT(CorrectKey::verify(proof_results.unwrap(), verification_aid).is_ok());
+  ASSERT(RangeProof::verify_commit(verifier_ek, vc.com, vc.r, vc.e).is_ok());
+  ChallengeBits other = vc.e; other.bytes[0] ^= 1;
+  ASSERT(!RangeProof::verify_commit(verifier_ek, vc.com, vc.r, other).is_ok());
+}
+static void test_generate_proof() {   // :411-428
+  auto [ek, dk] = test_keypair().keys();
+  auto [verifier_ek, verifier_dk] = test_keypair().keys();
+  BigInt range = BigInt(0x000FFFFFFFFFFFFFull);
+  auto vc = RangeProof::verifier_commit(verifier_ek);
+  auto [ep, data] = RangeProof::generate_encrypted_pairs(ek, range, SEF);
+  BigInt secret_r = BigInt::sample_below(ek.n);
+  BigInt secret_x = BigInt(0x0FFFFFFFull);
+  Proof z = RangeProof::generate_proof(ek, secret_x, secret_r, vc.e, range, data, SEF);
+  ASSERT(z.responses.size() == SEF);
+}
+static void interactive_case(bool honest) {   // :431-525
+  BigInt range = BigInt::sample(RANGE_BITS);
+  auto [ek, dk] = test_keypair().keys();
+  auto [verifier_ek, verifier_dk] = test_keypair().keys();
+  auto vc = RangeProof::verifier_commit(verifier_ek);
+  ASSERT(RangeProof::verify_commit(verifier_ek, vc.com, vc.r, vc.e).is_ok());
+  auto [ep, data] = RangeProof::generate_encrypted_pairs(ek, range, SEF);
+  BigInt secret_r = BigInt::sample_below(ek.n);
+  BigInt secret_x = honest ? BigInt::sample_below(range.div_floor(BigInt(3))) : BigInt::sample_range(BigInt(100) * range, BigInt(10000) * range);
+  BigInt cipher_x = Paillier::encrypt_with_chosen_randomness(ek, secret_x, secret_r);
+  Proof z = RangeProof::generate_proof(ek, secret_x, secret_r, vc.e, range, data, SEF);
+  Result result = RangeProof::verifier_output(ek, vc.e, ep, z, range, cipher_x, SEF);
+  ASSERT(result.is_ok() == honest);
+}
+static void test_range_proof_correct_proof() { interactive_case(true); }
+static void test_range_proof_incorrect_proof() { interactive_case(false); }
+
 int main() {
+  run("range_proof::test_generate_encrypted_pairs", test_generate_encrypted_pairs);
+  run("range_proof::test_commit_decommit", test_commit_decommit);
+  run("range_proof::test_generate_proof", test_generate_proof);
+  run("range_proof::test_range_proof_correct_proof", test_range_proof_correct_proof);
+  run("range_proof::test_range_proof_incorrect_proof", test_range_proof_incorrect_proof);
   run("range_proof_ni::test_prover", test_prover);
   run("range_proof_ni::test_verifier_for_correct_proof", test_verifier_for_correct_proof);
   run("range_proof_ni::test_verifier_for_incorrect_proof", test_verifier_for_incorrect_proof, true);

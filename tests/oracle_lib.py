@@ -148,3 +148,13 @@ class Oracle:
         self.lib.oracle_verlin_proof_verify_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(c), p(c_prime), p(phi_x), p(phi_a),
                                                   p(z), p(zp), p(zpp), p(r_z), p(v))
         return v
+
+    # ---- interactive RangeProof building blocks
+    def range_generate_encrypted_pairs(self, proofs, wit):
+        return self.lib.oracle_range_generate_encrypted_pairs_batch(C.byref(proofs), C.byref(wit))
+
+    def range_generate_proof(self, proofs, wit, e, e_len, out_status):
+        return self.lib.oracle_range_generate_proof_batch(C.byref(proofs), C.byref(wit), p(e), p(e_len), p(out_status))
+
+    def range_verifier_output(self, proofs, e, e_len, out_verdict):
+        return self.lib.oracle_range_verifier_output_batch(C.byref(proofs), p(e), p(e_len), p(out_verdict))

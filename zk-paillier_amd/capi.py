@@ -58,6 +58,10 @@ EXPORTS = {
     "zkp_range_ni_prove_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness),
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_range_ni_verify_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_uint32]),
+    "zkp_range_generate_encrypted_pairs_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness), C.c_uint32]),
+    "zkp_range_generate_proof_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness), C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_uint32]),
+    "zkp_range_verifier_output_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_correct_key_ni_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "zkp_dlog_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
@@ -224,3 +228,15 @@ class Context:
     def verlin_proof_verify(self, n_bits, batch, n, n_stride, c, c_prime, phi_x, phi_a, z, zp, zpp, r_z, out_verdict):
         arrs = [c, c_prime, phi_x, phi_a, z, zp, zpp, r_z, out_verdict]
         self.check(self.lib.zkp_verlin_proof_verify_batch(self.h, n_bits, batch, ptr(n), n_stride, *[ptr(a) for a in arrs], self._flags(n, *arrs)))
+
+    # ---- interactive RangeProof building blocks (challenge supplied by the caller)
+    def range_generate_encrypted_pairs(self, proofs, wit, device: bool):
+        self.check(self.lib.zkp_range_generate_encrypted_pairs_batch(self.h, C.byref(proofs), C.byref(wit), ZKP_F_DEVICE_PTRS if device else 0))
+
+    def range_generate_proof(self, proofs, wit, e, e_len, out_status, device: bool):
+        self.check(self.lib.zkp_range_generate_proof_batch(self.h, C.byref(proofs), C.byref(wit), ptr(e), ptr(e_len), ptr(out_status),
+                                                           ZKP_F_DEVICE_PTRS if device else 0))
+
+    def range_verifier_output(self, proofs, e, e_len, out_verdict, device: bool):
+        self.check(self.lib.zkp_range_verifier_output_batch(self.h, C.byref(proofs), ptr(e), ptr(e_len), ptr(out_verdict),
+                                                            ZKP_F_DEVICE_PTRS if device else 0))

@@ -33,6 +33,7 @@ struct RangeHashArgs {
   uint32_t* two_thirds;// [B][kw]
   uint8_t* verdict;    // [B] verify: ACCEPT or MALFORMED to start with; prove: status 0 / MALFORMED
   uint8_t ok_value;    // value written when the challenge is long enough
+  const uint8_t* e_in; const uint8_t* e_len_in;   // externally supplied challenge (interactive protocol): no hashing
 };
 
 // One wavefront per 64 proofs, one proof per lane (SHA-256 is sequential per proof).  The operands are read with
@@ -65,29 +66,36 @@ __global__ void __launch_bounds__(HASH_PROOFS) k_range_hash(RangeHashArgs a) {
   uint32_t* shabuf = hash_lds;                         // [16][64]
   uint32_t* tile = hash_lds + 16 * HASH_PROOFS;        // [64][2kw+1]
   const uint32_t* row = tile + lane * row_stride;
-  Sha256 s;
-  s.init(shabuf + lane, HASH_PROOFS);
-  hash_stage_value(tile, row_stride, a.n + b0 * a.n_stride, a.n_stride, kw, nproofs, lane);
-  if (live) s.put_bigint(row, kw);
-  const uint64_t pstride = (uint64_t)a.ef * 2 * kw;    // words between consecutive proofs in c1 / c2
-  for (int half = 0; half < 2; half++) {
-    const uint32_t* cbase = (half ? a.c2 : a.c1) + b0 * pstride;
-    for (uint32_t i = 0; i < a.ef; i++) {
-      hash_stage_value(tile, row_stride, cbase + (uint64_t)i * 2 * kw, pstride, 2 * kw, nproofs, lane);
-      if (live) s.put_bigint(row, 2 * kw);
-    }
-  }
-  if (!live) return;
-  uint32_t d[8];
-  s.finish(d);
-  uint8_t db[32];
-#pragma unroll
-  for (int i = 0; i < 8; i++) { db[4 * i] = d[i] >> 24; db[4 * i + 1] = d[i] >> 16; db[4 * i + 2] = d[i] >> 8; db[4 * i + 3] = d[i]; }
-  int lead = 0;
-  while (lead < 31 && db[lead] == 0) lead++;      // BigInt round trip drops leading zero bytes; zero -> "00"
+  int elen;
   uint8_t* e = a.e + b * 32;
-  for (int i = 0; i < 32; i++) e[i] = (i + lead < 32) ? db[i + lead] : 0;
-  const int elen = 32 - lead;
+  if (a.e_in) {                                        // wave-uniform: the whole launch either hashes or copies
+    if (!live) return;
+    for (int i = 0; i < 32; i++) e[i] = a.e_in[b * 32 + i];
+    elen = a.e_len_in[b];
+  } else {
+    Sha256 s;
+    s.init(shabuf + lane, HASH_PROOFS);
+    hash_stage_value(tile, row_stride, a.n + b0 * a.n_stride, a.n_stride, kw, nproofs, lane);
+    if (live) s.put_bigint(row, kw);
+    const uint64_t pstride = (uint64_t)a.ef * 2 * kw;    // words between consecutive proofs in c1 / c2
+    for (int half = 0; half < 2; half++) {
+      const uint32_t* cbase = (half ? a.c2 : a.c1) + b0 * pstride;
+      for (uint32_t i = 0; i < a.ef; i++) {
+        hash_stage_value(tile, row_stride, cbase + (uint64_t)i * 2 * kw, pstride, 2 * kw, nproofs, lane);
+        if (live) s.put_bigint(row, 2 * kw);
+      }
+    }
+    if (!live) return;
+    uint32_t d[8];
+    s.finish(d);
+    uint8_t db[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { db[4 * i] = d[i] >> 24; db[4 * i + 1] = d[i] >> 16; db[4 * i + 2] = d[i] >> 8; db[4 * i + 3] = d[i]; }
+    int lead = 0;
+    while (lead < 31 && db[lead] == 0) lead++;      // BigInt round trip drops leading zero bytes; zero -> "00"
+    for (int i = 0; i < 32; i++) e[i] = (i + lead < 32) ? db[i + lead] : 0;
+    elen = 32 - lead;
+  }
   a.e_len[b] = (uint8_t)elen;
   // bits_of_e[i] for i < EF must exist, otherwise the reference panics (index out of bounds)
   a.verdict[b] = ((uint32_t)elen * 8 >= a.ef) ? a.ok_value : (uint8_t)ZKP_VERDICT_MALFORMED;

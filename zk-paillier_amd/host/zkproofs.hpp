@@ -5,6 +5,7 @@
 //
 //   reference                                                      here
 //   zkproofs::RangeProofNi::{prove,verify,verify_self}              RangeProofNi::{prove,verify,verify_self}   (+ *_batch)
+//   zkproofs::RangeProof::{verifier_commit,verify_commit,generate_encrypted_pairs,generate_proof,verifier_output}   RangeProof::*
 //     src/zkproofs/range_proof_ni.rs:36-128
 //   zkproofs::NiCorrectKeyProof::{proof,verify}                     NiCorrectKeyProof::{proof,verify}
 //     src/zkproofs/correct_key_ni.rs:36-100
@@ -289,6 +290,140 @@ struct Sha256 {
 // src/zkproofs/utils.rs:9-22
 inline BigInt compute_digest(std::initializer_list<const BigInt*> items) { Sha256 s; for (auto* v : items) s.update(*v); return s.finish(); }
 }  // namespace detail
+
+// ------------------------------------------------------------------ interactive RangeProof (src/zkproofs/range_proof.rs:83-355)
+struct DataRandomnessPairs { std::vector<BigInt> w1, w2, r1, r2; };   // range_proof.rs:41-47
+struct ChallengeBits { std::vector<uint8_t> bytes; };                 // :49-50
+struct Commitment { BigInt com; };                                    // :83
+struct ChallengeRandomness { BigInt r; };                             // :100
+
+struct RangeProof {
+  static constexpr size_t STATISTICAL_ERROR_FACTOR = 40;   // range_proof.rs:30
+
+  // :359-369
+  static BigInt compute_digest(const std::vector<uint8_t>& bytes) { detail::Sha256 s; s.update(bytes.data(), bytes.size()); return s.finish(); }
+  static BigInt get_paillier_commitment(const EncryptionKey& ek, const BigInt& x, const BigInt& r) { return Paillier::encrypt_with_chosen_randomness(ek, x, r); }
+
+  struct VerifierCommit { Commitment com; ChallengeRandomness r; ChallengeBits e; };
+  // :118-126 — e = STATISTICAL_ERROR_FACTOR random bits, com = Enc(SHA256(e), r)
+  static VerifierCommit verifier_commit(const EncryptionKey& ek) {
+    ChallengeBits e;
+    e.bytes.resize(STATISTICAL_ERROR_FACTOR / 8);
+    std::random_device rd;
+    for (auto& b : e.bytes) b = (uint8_t)rd();
+    BigInt r = BigInt::sample_below(ek.n);
+    return {Commitment{get_paillier_commitment(ek, compute_digest(e.bytes), r)}, ChallengeRandomness{r}, e};
+  }
+  // :195-208
+  static Result verify_commit(const EncryptionKey& ek, const Commitment& com, const ChallengeRandomness& r, const ChallengeBits& e) {
+    return Result(com.com == get_paillier_commitment(ek, compute_digest(e.bytes), r.r));
+  }
+
+  // :128-193 — the 2 * error_factor encryptions are one launch
+  static std::pair<EncryptedPairs, DataRandomnessPairs> generate_encrypted_pairs(const EncryptionKey& ek, const BigInt& range, size_t error_factor) {
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    const size_t EF = error_factor;
+    DataRandomnessPairs d;
+    const BigInt third = range.div_floor(BigInt(3)), two_thirds = BigInt(2) * third;   // :133-134
+    std::random_device rd;
+    for (size_t i = 0; i < EF; i++) {
+      BigInt a = BigInt::sample_range(third, two_thirds), c = a - third;                // :136-141
+      if (rd() & 1) std::swap(a, c);                                                     // :144-149
+      d.w1.push_back(a); d.w2.push_back(c);
+      d.r1.push_back(BigInt::sample_below(ek.n)); d.r2.push_back(BigInt::sample_below(ek.n));   // :151-159
+    }
+    std::vector<uint32_t> n(kw), w1(EF * kw), w2(EF * kw), r1(EF * kw), r2(EF * kw), c1(EF * 2 * kw), c2(EF * 2 * kw);
+    ek.n.to_limbs(n.data(), kw);
+    for (size_t i = 0; i < EF; i++) {
+      d.w1[i].to_limbs(&w1[i * kw], kw); d.w2[i].to_limbs(&w2[i * kw], kw); d.r1[i].to_limbs(&r1[i * kw], kw); d.r2[i].to_limbs(&r2[i * kw], kw);
+    }
+    zkp_range_ni_proofs p{};
+    p.n_bits = nb; p.error_factor = (uint32_t)EF; p.batch = 1; p.n = n.data(); p.c1 = c1.data(); p.c2 = c2.data();
+    zkp_range_ni_witness w{nullptr, nullptr, w1.data(), w2.data(), r1.data(), r2.data()};
+    e.check(zkp_range_generate_encrypted_pairs_batch(e.ctx(), &p, &w, 0), "zkp_range_generate_encrypted_pairs_batch");
+    EncryptedPairs ep;
+    for (size_t i = 0; i < EF; i++) {
+      ep.c1.push_back(BigInt::from_limbs(&c1[i * 2 * kw], 2 * kw)); ep.c2.push_back(BigInt::from_limbs(&c2[i * 2 * kw], 2 * kw));
+    }
+    return {ep, d};
+  }
+
+  static void pack_challenge(const ChallengeBits& e, uint8_t (&eb)[32], uint8_t& elen) {
+    if (e.bytes.size() > 32) throw std::invalid_argument("ChallengeBits: the fixed-layout ABI carries at most 256 challenge bits");
+    std::memset(eb, 0, 32);
+    std::memcpy(eb, e.bytes.data(), e.bytes.size());
+    elen = (uint8_t)e.bytes.size();
+  }
+
+  // :210-252
+  static Proof generate_proof(const EncryptionKey& ek, const BigInt& secret_x, const BigInt& secret_r, const ChallengeBits& ch, const BigInt& range,
+                              const DataRandomnessPairs& d, size_t error_factor) {
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    const size_t EF = error_factor;
+    if (d.w1.size() < EF || d.w2.size() < EF || d.r1.size() < EF || d.r2.size() < EF) throw Panic("index out of bounds");   // data.w1[i]
+    std::vector<uint32_t> n(kw), rg(kw), x(kw), r(kw), w1(EF * kw), w2(EF * kw), r1(EF * kw), r2(EF * kw);
+    std::vector<uint32_t> rw1(EF * kw), rr1(EF * kw), rw2(EF * kw), rr2(EF * kw);
+    std::vector<uint8_t> kind(EF), jj(EF);
+    ek.n.to_limbs(n.data(), kw); range.to_limbs(rg.data(), kw); secret_x.to_limbs(x.data(), kw); secret_r.to_limbs(r.data(), kw);
+    for (size_t i = 0; i < EF; i++) {
+      d.w1[i].to_limbs(&w1[i * kw], kw); d.w2[i].to_limbs(&w2[i * kw], kw); d.r1[i].to_limbs(&r1[i * kw], kw); d.r2[i].to_limbs(&r2[i * kw], kw);
+    }
+    uint8_t eb[32], elen, status = 0;
+    pack_challenge(ch, eb, elen);
+    zkp_range_ni_proofs p{};
+    p.n_bits = nb; p.error_factor = (uint32_t)EF; p.batch = 1; p.n = n.data(); p.range = rg.data();
+    p.resp_kind = kind.data(); p.resp_j = jj.data(); p.resp_w1 = rw1.data(); p.resp_r1 = rr1.data(); p.resp_w2 = rw2.data(); p.resp_r2 = rr2.data();
+    zkp_range_ni_witness w{x.data(), r.data(), w1.data(), w2.data(), r1.data(), r2.data()};
+    e.check(zkp_range_generate_proof_batch(e.ctx(), &p, &w, eb, &elen, &status, 0), "zkp_range_generate_proof_batch");
+    if (status != 0) throw Panic("RangeProof::generate_proof: malformed (the reference would panic: bits_of_e[i])");
+    Proof out;
+    for (size_t t = 0; t < EF; t++) {
+      Response rs;
+      if (kind[t] == ZKP_RESP_OPEN) {
+        rs.kind = Response::Open;
+        rs.w1 = BigInt::from_limbs(&rw1[t * kw], kw); rs.r1 = BigInt::from_limbs(&rr1[t * kw], kw);
+        rs.w2 = BigInt::from_limbs(&rw2[t * kw], kw); rs.r2 = BigInt::from_limbs(&rr2[t * kw], kw);
+      } else {
+        rs.kind = Response::Mask; rs.j = jj[t];
+        rs.masked_x = BigInt::from_limbs(&rw1[t * kw], kw); rs.masked_r = BigInt::from_limbs(&rr1[t * kw], kw);
+      }
+      out.responses.push_back(std::move(rs));
+    }
+    return out;
+  }
+
+  // :254-355
+  static Result verifier_output(const EncryptionKey& ek, const ChallengeBits& ch, const EncryptedPairs& ep, const Proof& proof, const BigInt& range,
+                                const BigInt& cipher_x, size_t error_factor) {
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    const size_t EF = error_factor;
+    if (proof.responses.size() < EF || ep.c1.size() < EF || ep.c2.size() < EF) throw Panic("index out of bounds");   // :274,293,296
+    std::vector<uint32_t> n(kw), rg(kw), ct(2 * kw), c1(EF * 2 * kw), c2(EF * 2 * kw), rw1(EF * kw), rr1(EF * kw), rw2(EF * kw), rr2(EF * kw);
+    std::vector<uint8_t> kind(EF), jj(EF);
+    ek.n.to_limbs(n.data(), kw); range.to_limbs(rg.data(), kw); cipher_x.to_limbs(ct.data(), 2 * kw);
+    for (size_t t = 0; t < EF; t++) {
+      ep.c1[t].to_limbs(&c1[t * 2 * kw], 2 * kw); ep.c2[t].to_limbs(&c2[t * 2 * kw], 2 * kw);
+      const Response& rs = proof.responses[t];
+      if (rs.kind == Response::Open) {
+        kind[t] = ZKP_RESP_OPEN;
+        rs.w1.to_limbs(&rw1[t * kw], kw); rs.r1.to_limbs(&rr1[t * kw], kw); rs.w2.to_limbs(&rw2[t * kw], kw); rs.r2.to_limbs(&rr2[t * kw], kw);
+      } else {
+        kind[t] = ZKP_RESP_MASK; jj[t] = rs.j;
+        rs.masked_x.to_limbs(&rw1[t * kw], kw); rs.masked_r.to_limbs(&rr1[t * kw], kw);
+      }
+    }
+    uint8_t eb[32], elen, verdict = 0;
+    pack_challenge(ch, eb, elen);
+    zkp_range_ni_proofs p{nb, (uint32_t)EF, 1, 0, n.data(), rg.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
+                          rw1.data(), rr1.data(), rw2.data(), rr2.data()};
+    e.check(zkp_range_verifier_output_batch(e.ctx(), &p, eb, &elen, &verdict, 0), "zkp_range_verifier_output_batch");
+    if (verdict == ZKP_VERDICT_MALFORMED) throw Panic("RangeProof::verifier_output: malformed proof (the reference would panic)");
+    return Result(verdict == ZKP_VERDICT_ACCEPT);
+  }
+};
 
 // ------------------------------------------------------------------ NiCorrectKeyProof
 static const uint8_t SALT_STRING[4] = {75, 90, 101, 110};   // correct_key_ni.rs:28
