@@ -231,6 +231,46 @@ int32_t zkp_verlin_proof_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t ba
                                       const uint32_t* z, const uint32_t* z_prime, const uint32_t* z_double_prime, const uint32_t* r_z,
                                       uint8_t* out_verdict, uint32_t flags);
 
+/* ------------------------------------------------------------------ modular inverse (L1)
+ * out[i] = a[i]^-1 mod M[i]: curv BigInt::mod_inv (GMP mpz_invert) as used by multiplication_proof.rs:95,133 and
+ * correct_message.rs:53,76,141.  mod_bits in {2048, 4096, 8192}; a, M, out: mod_bits/32 words per element.
+ * out_status[i]: 0 = out[i] holds the inverse, 1 = no inverse exists (mod_inv returns None; out[i] = 0),
+ * 2 = outside the domain of this entry point (a >= M, M even or M < 3; out[i] = 0). */
+#define ZKP_INV_OK 0
+#define ZKP_INV_NONE 1
+#define ZKP_INV_DOMAIN 2
+int32_t zkp_modinv_batch(zkp_ctx* ctx, uint32_t mod_bits, uint64_t count, const uint32_t* a, const uint32_t* modulus, uint64_t mod_stride,
+                         uint32_t* out, uint8_t* out_status, uint32_t flags);
+
+/* ------------------------------------------------------------------ MulProof
+ * multiplication_proof.rs:60-146.  kw = n_bits/32.  Statement: e_a, e_b, e_c [B][2kw].  Witness: a, b [B][kw] (c is not read
+ * by the prover), r_a, r_b, r_c [B][kw].  Nonces the reference samples (:61-62), supplied by the caller: d, r_d [B][kw].
+ * Proof: f [B][kw], z1, z2, e_d, e_db [B][2kw].
+ * prove: out_status[b] = 0, or ZKP_VERDICT_MALFORMED where `mod_inv(..).unwrap()` (:95) panics in the reference.
+ * verify: verdict bytes as above; MALFORMED where :133 panics. */
+int32_t zkp_mul_proof_prove_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* e_a,
+                                  const uint32_t* e_b, const uint32_t* e_c, const uint32_t* a, const uint32_t* b, const uint32_t* r_a,
+                                  const uint32_t* r_b, const uint32_t* r_c, const uint32_t* d, const uint32_t* r_d, uint32_t* out_f,
+                                  uint32_t* out_z1, uint32_t* out_z2, uint32_t* out_e_d, uint32_t* out_e_db, uint8_t* out_status, uint32_t flags);
+int32_t zkp_mul_proof_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* e_a,
+                                   const uint32_t* e_b, const uint32_t* e_c, const uint32_t* f, const uint32_t* z1, const uint32_t* z2,
+                                   const uint32_t* e_d, const uint32_t* e_db, uint8_t* out_verdict, uint32_t flags);
+
+/* ------------------------------------------------------------------ CorrectMessageProof
+ * correct_message.rs:35-162: ring proof that a ciphertext encrypts one of K valid messages (K = num_messages >= 1, the same for
+ * every proof of the batch).  valid_messages [B][K][kw]; message [B][kw].  Values the reference samples, supplied by the caller:
+ * r (:43), w (:65) [B][kw]; e_sim [B][K-1][8] (:59-61, 256-bit); z_sim [B][K-1][kw] (:62-64).
+ * Proof: ciphertext [B][2kw], e_vec [B][K][8], z_vec [B][K][kw], a_vec [B][K][2kw].
+ * prove: out_status[b] = MALFORMED where the reference panics (no valid message equals `message`: index out of bounds :74).
+ * verify: MALFORMED where `assert_eq!(chal, ei_sum)` (:132) panics; REJECT / ACCEPT from :144-161. */
+int32_t zkp_correct_message_prove_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, uint32_t num_messages, const uint32_t* n,
+                                        uint64_t n_stride, const uint32_t* valid_messages, const uint32_t* message, const uint32_t* r,
+                                        const uint32_t* e_sim, const uint32_t* z_sim, const uint32_t* w, uint32_t* out_ciphertext,
+                                        uint32_t* out_e_vec, uint32_t* out_z_vec, uint32_t* out_a_vec, uint8_t* out_status, uint32_t flags);
+int32_t zkp_correct_message_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t batch, uint32_t num_messages, const uint32_t* n,
+                                         uint64_t n_stride, const uint32_t* valid_messages, const uint32_t* ciphertext, const uint32_t* e_vec,
+                                         const uint32_t* z_vec, const uint32_t* a_vec, uint8_t* out_verdict, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

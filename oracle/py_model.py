@@ -338,3 +338,115 @@ def verlin_verify(n, c, c_prime, phi_x, phi_a, z, zp, zpp, r_z) -> bool:
     nn = n * n
     e = compute_digest([n, c, c_prime, phi_x, phi_a])
     return gen_phi(n, c, c_prime, z, zp, zpp, r_z) == (pow(phi_x, e, nn) * phi_a) % nn
+
+
+# ----------------------------------------------------------------------------- mod_inv, MulProof, CorrectMessageProof
+
+def mod_inv(a: int, m: int):
+    """[upstream] curv BigInt::mod_inv -> GMP mpz_invert: None when gcd(a, m) != 1."""
+    try:
+        return pow(a, -1, m)
+    except ValueError:
+        return None
+
+
+class Panic(Exception):
+    """a Rust panic of the reference (unwrap on None, assert_eq!, index out of bounds)"""
+
+
+def mul_proof_prove(n, e_a, e_b, e_c, a, b, r_a, r_b, r_c, d, r_d):
+    """multiplication_proof.rs:60-104 with (d, r_d) injected (:61-62 samples them)."""
+    nn = n * n
+    e_d = enc(n, d, r_d)
+    r_db = r_d * r_b                      # :69, not reduced
+    db = d * b                            # :70, not reduced
+    e_db = enc(n, db, r_db)
+    e = compute_digest([n, e_a, e_b, e_c, e_d, e_db])
+    f = (e * a % n + d) % n               # :87-88
+    z1 = pow(r_a, e, nn) * r_d % nn       # :89-90
+    r_b_f = pow(r_b, f, nn)
+    r_db_r_c_e = r_db * pow(r_c, e, nn) % nn
+    inv = mod_inv(r_db_r_c_e, nn)
+    if inv is None:
+        raise Panic("mod_inv unwrap :95")
+    z2 = r_b_f * inv % nn
+    return f, z1, z2, e_d, e_db
+
+
+def mul_proof_verify(n, e_a, e_b, e_c, f, z1, z2, e_d, e_db) -> bool:
+    """multiplication_proof.rs:106-146."""
+    nn = n * n
+    e = compute_digest([n, e_a, e_b, e_c, e_d, e_db])
+    enc_f_z1 = enc(n, f, z1)
+    enc_0_z2 = enc(n, 0, z2)
+    lhs1 = pow(e_a, e, nn) * e_d % nn
+    t = e_db * pow(e_c, e, nn) % nn
+    inv = mod_inv(t, nn)
+    if inv is None:
+        raise Panic("mod_inv unwrap :133")
+    lhs2 = pow(e_b, f, nn) * inv % nn
+    return lhs1 == enc_f_z1 and lhs2 == enc_0_z2
+
+
+CM_B = 256  # correct_message.rs:19
+
+
+def correct_message_prove(n, valid_messages, message, r, e_sim, z_sim, w):
+    """correct_message.rs:35-123 with (r, ei_vec, zi_vec, w) injected."""
+    nn = n * n
+    K = len(valid_messages)
+    if K < 1:
+        raise Panic("num_of_message - 1 underflows")
+    ciphertext = enc(n, message, r)
+    ui = []
+    for m in valid_messages:
+        gm = (m * n + 1) % nn
+        gi = mod_inv(gm, nn)
+        if gi is None:
+            raise Panic("mod_inv unwrap :53")
+        ui.append(ciphertext * gi % nn)
+    a_vec = []
+    j = 0
+    for i in range(K):
+        if valid_messages[i] == message:
+            a_vec.append(pow(w, n, nn))
+        else:
+            if j >= len(z_sim):
+                raise Panic("index out of bounds :74")
+            zi_n = pow(z_sim[j], n, nn)
+            ui_ei = pow(ui[i], e_sim[j], nn)
+            inv = mod_inv(ui_ei, nn)
+            if inv is None:
+                raise Panic("mod_inv unwrap :76")
+            j += 1
+            a_vec.append(zi_n * inv % nn)
+    two = 1 << CM_B
+    chal = compute_digest(a_vec) % two
+    ei = (chal - sum(e_sim) % two) % two
+    zi = w * pow(r, ei, n) % n
+    e_vec, z_vec = [], []
+    j = 0
+    for i in range(K):
+        if valid_messages[i] == message:
+            e_vec.append(ei); z_vec.append(zi)
+        else:
+            e_vec.append(e_sim[j]); z_vec.append(z_sim[j]); j += 1
+    return ciphertext, e_vec, z_vec, a_vec
+
+
+def correct_message_verify(n, valid_messages, ciphertext, e_vec, z_vec, a_vec) -> bool:
+    """correct_message.rs:124-162."""
+    nn = n * n
+    two = 1 << CM_B
+    chal = compute_digest(a_vec) % two
+    if chal != sum(e_vec) % two:
+        raise Panic("assert_eq!(chal, ei_sum) :132")
+    ok = True
+    for i, m in enumerate(valid_messages):
+        gm = (m * n + 1) % nn
+        gi = mod_inv(gm, nn)
+        if gi is None:
+            raise Panic("mod_inv unwrap :141")
+        u = ciphertext * gi % nn
+        ok = ok and (pow(u, e_vec[i], nn) * a_vec[i] % nn == pow(z_vec[i], n, nn))
+    return ok

@@ -770,3 +770,213 @@ int32_t oracle_verlin_proof_verify_batch(uint32_t n_bits, uint64_t batch, const 
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------ mod_inv (curv BigInt::mod_inv -> mpz_invert) */
+int32_t oracle_modinv_batch(uint32_t mod_bits, uint64_t count, const uint32_t* a, const uint32_t* modulus, uint64_t mod_stride,
+                            uint32_t* out, uint8_t* out_status) {
+  const size_t kw = mod_bits / 32;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 4)
+  for (int64_t i = 0; i < (int64_t)count; i++) {
+    mpz_t za, zm, zr;
+    mpz_inits(za, zm, zr, NULL);
+    limbs_to_mpz(za, a + i * kw, kw);
+    limbs_to_mpz(zm, modulus + i * mod_stride, kw);
+    memset(out + i * kw, 0, kw * 4);
+    if (mpz_cmp(za, zm) >= 0 || mpz_even_p(zm) || mpz_cmp_ui(zm, 3) < 0) out_status[i] = ZKP_INV_DOMAIN;
+    else if (!mpz_invert(zr, za, zm)) out_status[i] = ZKP_INV_NONE;
+    else { out_status[i] = ZKP_INV_OK; mpz_to_limbs(out + i * kw, kw, zr); }
+    mpz_clears(za, zm, zr, NULL);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ MulProof (multiplication_proof.rs:60-146) */
+static void mul_challenge(mpz_t e, const mpz_t n, const mpz_t ea, const mpz_t eb, const mpz_t ec, const mpz_t ed, const mpz_t edb) {
+  mpz_t it[6];
+  mpz_init_set(it[0], n); mpz_init_set(it[1], ea); mpz_init_set(it[2], eb); mpz_init_set(it[3], ec); mpz_init_set(it[4], ed); mpz_init_set(it[5], edb);
+  compute_digest(e, (const mpz_t*)it, 6); /* :77-84, 107-114 */
+  for (int i = 0; i < 6; i++) mpz_clear(it[i]);
+}
+
+int32_t oracle_mul_proof_prove_batch(uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* e_a,
+                                     const uint32_t* e_b, const uint32_t* e_c, const uint32_t* a, const uint32_t* b, const uint32_t* r_a,
+                                     const uint32_t* r_b, const uint32_t* r_c, const uint32_t* d, const uint32_t* r_d, uint32_t* out_f,
+                                     uint32_t* out_z1, uint32_t* out_z2, uint32_t* out_e_d, uint32_t* out_e_db, uint8_t* out_status) {
+  const size_t kw = n_bits / 32;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int64_t i = 0; i < (int64_t)batch; i++) {
+    mpz_t zn, znn, ea, eb, ec, za, zb, ra, rb, rc, zd, rd, ed, edb, rdb, db, e, f, z1, z2, t, u;
+    mpz_inits(zn, znn, ea, eb, ec, za, zb, ra, rb, rc, zd, rd, ed, edb, rdb, db, e, f, z1, z2, t, u, NULL);
+    limbs_to_mpz(zn, n + i * n_stride, kw); mpz_mul(znn, zn, zn);
+    limbs_to_mpz(ea, e_a + i * 2 * kw, 2 * kw); limbs_to_mpz(eb, e_b + i * 2 * kw, 2 * kw); limbs_to_mpz(ec, e_c + i * 2 * kw, 2 * kw);
+    limbs_to_mpz(za, a + i * kw, kw); limbs_to_mpz(zb, b + i * kw, kw);
+    limbs_to_mpz(ra, r_a + i * kw, kw); limbs_to_mpz(rb, r_b + i * kw, kw); limbs_to_mpz(rc, r_c + i * kw, kw);
+    limbs_to_mpz(zd, d + i * kw, kw); limbs_to_mpz(rd, r_d + i * kw, kw);
+    enc_mpz(ed, zn, znn, zd, rd, t);                 /* :63-68 */
+    mpz_mul(rdb, rd, rb);                            /* :69 */
+    mpz_mul(db, zd, zb);                             /* :70 */
+    enc_mpz(edb, zn, znn, db, rdb, t);               /* :71-76 */
+    mul_challenge(e, zn, ea, eb, ec, ed, edb);
+    mpz_mul(f, e, za); mpz_mod(f, f, zn);            /* mod_mul :87 */
+    mpz_add(f, f, zd); mpz_mod(f, f, zn);            /* mod_add :88 */
+    mpz_powm(z1, ra, e, znn); mpz_mul(z1, z1, rd); mpz_mod(z1, z1, znn);   /* :89-90 */
+    mpz_powm(t, rc, e, znn); mpz_mul(t, rdb, t); mpz_mod(t, t, znn);       /* :92-93 */
+    memset(out_f + i * kw, 0, kw * 4); memset(out_z1 + i * 2 * kw, 0, kw * 8); memset(out_z2 + i * 2 * kw, 0, kw * 8);
+    mpz_to_limbs(out_e_d + i * 2 * kw, 2 * kw, ed); mpz_to_limbs(out_e_db + i * 2 * kw, 2 * kw, edb);
+    if (!mpz_invert(u, t, znn)) {                    /* .unwrap() :95 */
+      out_status[i] = ZKP_VERDICT_MALFORMED;
+    } else {
+      mpz_powm(z2, rb, f, znn); mpz_mul(z2, z2, u); mpz_mod(z2, z2, znn);  /* :91,96 */
+      mpz_to_limbs(out_f + i * kw, kw, f); mpz_to_limbs(out_z1 + i * 2 * kw, 2 * kw, z1); mpz_to_limbs(out_z2 + i * 2 * kw, 2 * kw, z2);
+      out_status[i] = 0;
+    }
+    mpz_clears(zn, znn, ea, eb, ec, za, zb, ra, rb, rc, zd, rd, ed, edb, rdb, db, e, f, z1, z2, t, u, NULL);
+  }
+  return 0;
+}
+
+int32_t oracle_mul_proof_verify_batch(uint32_t n_bits, uint64_t batch, const uint32_t* n, uint64_t n_stride, const uint32_t* e_a,
+                                      const uint32_t* e_b, const uint32_t* e_c, const uint32_t* f, const uint32_t* z1, const uint32_t* z2,
+                                      const uint32_t* e_d, const uint32_t* e_db, uint8_t* out_verdict) {
+  const size_t kw = n_bits / 32;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int64_t i = 0; i < (int64_t)batch; i++) {
+    mpz_t zn, znn, ea, eb, ec, zf, s1, s2, ed, edb, e, c1, c2, l1, l2, t, u, zero;
+    mpz_inits(zn, znn, ea, eb, ec, zf, s1, s2, ed, edb, e, c1, c2, l1, l2, t, u, zero, NULL);
+    limbs_to_mpz(zn, n + i * n_stride, kw); mpz_mul(znn, zn, zn);
+    limbs_to_mpz(ea, e_a + i * 2 * kw, 2 * kw); limbs_to_mpz(eb, e_b + i * 2 * kw, 2 * kw); limbs_to_mpz(ec, e_c + i * 2 * kw, 2 * kw);
+    limbs_to_mpz(zf, f + i * kw, kw); limbs_to_mpz(s1, z1 + i * 2 * kw, 2 * kw); limbs_to_mpz(s2, z2 + i * 2 * kw, 2 * kw);
+    limbs_to_mpz(ed, e_d + i * 2 * kw, 2 * kw); limbs_to_mpz(edb, e_db + i * 2 * kw, 2 * kw);
+    mul_challenge(e, zn, ea, eb, ec, ed, edb);
+    enc_mpz(c1, zn, znn, zf, s1, t);                 /* Enc(f, z1) :116-122 */
+    enc_mpz(c2, zn, znn, zero, s2, t);               /* Enc(0, z2) :123-129 */
+    mpz_powm(l1, ea, e, znn); mpz_mul(l1, l1, ed); mpz_mod(l1, l1, znn);    /* :131-132 */
+    mpz_powm(t, ec, e, znn); mpz_mul(t, edb, t); mpz_mod(t, t, znn);        /* :133-134 */
+    if (!mpz_invert(u, t, znn)) {                    /* .unwrap() :135 */
+      out_verdict[i] = ZKP_VERDICT_MALFORMED;
+    } else {
+      mpz_powm(l2, eb, zf, znn); mpz_mul(l2, l2, u); mpz_mod(l2, l2, znn);  /* :136-137 */
+      out_verdict[i] = (mpz_cmp(l1, c1) == 0 && mpz_cmp(l2, c2) == 0) ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
+    }
+    mpz_clears(zn, znn, ea, eb, ec, zf, s1, s2, ed, edb, e, c1, c2, l1, l2, t, u, zero, NULL);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ CorrectMessageProof (correct_message.rs:35-162) */
+/* u_i = ciphertext * ((m_i*n + 1) % nn)^-1 mod nn (:50-56, 136-144); returns 0 when mod_inv has no result */
+static int cm_u(mpz_t u, const mpz_t ct, const mpz_t m, const mpz_t n, const mpz_t nn, mpz_t t) {
+  mpz_mul(t, m, n); mpz_add_ui(t, t, 1); mpz_tdiv_r(t, t, nn);
+  if (!mpz_invert(t, t, nn)) return 0;
+  mpz_mul(u, ct, t); mpz_mod(u, u, nn);
+  return 1;
+}
+static void cm_challenge(mpz_t chal, const mpz_t* a_vec, uint32_t K) {
+  compute_digest(chal, a_vec, (int)K);
+  mpz_fdiv_r_2exp(chal, chal, 256);                  /* .modulus(2^B) :88, :129 */
+}
+
+int32_t oracle_correct_message_prove_batch(uint32_t n_bits, uint64_t batch, uint32_t K, const uint32_t* n, uint64_t n_stride,
+                                           const uint32_t* valid_messages, const uint32_t* message, const uint32_t* r, const uint32_t* e_sim,
+                                           const uint32_t* z_sim, const uint32_t* w, uint32_t* out_ciphertext, uint32_t* out_e_vec,
+                                           uint32_t* out_z_vec, uint32_t* out_a_vec, uint8_t* out_status) {
+  const size_t kw = n_bits / 32;
+  if (K < 1) return 1;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int64_t b = 0; b < (int64_t)batch; b++) {
+    mpz_t zn, znn, msg, zr, zw, ct, m, u, t, x, chal, sum, ei, zi;
+    mpz_inits(zn, znn, msg, zr, zw, ct, m, u, t, x, chal, sum, ei, zi, NULL);
+    mpz_t* av = (mpz_t*)malloc(sizeof(mpz_t) * K);
+    for (uint32_t i = 0; i < K; i++) mpz_init(av[i]);
+    limbs_to_mpz(zn, n + b * n_stride, kw); mpz_mul(znn, zn, zn);
+    limbs_to_mpz(msg, message + b * kw, kw); limbs_to_mpz(zr, r + b * kw, kw); limbs_to_mpz(zw, w + b * kw, kw);
+    enc_mpz(ct, zn, znn, msg, zr, t);                /* :44-49 */
+    int panic = 0;
+    uint32_t j = 0;
+    uint8_t* match = (uint8_t*)calloc(K, 1);
+    for (uint32_t i = 0; i < K && !panic; i++) {
+      limbs_to_mpz(m, valid_messages + (b * K + i) * kw, kw);
+      match[i] = mpz_cmp(m, msg) == 0;
+      if (!cm_u(u, ct, m, zn, znn, t)) { panic = 1; break; }          /* :53 (never: gcd(1 + m n, nn) = 1) */
+      if (match[i]) {
+        mpz_powm(av[i], zw, zn, znn);                                 /* :69-70 */
+      } else {
+        if (j >= K - 1) { panic = 1; break; }                         /* zi_vec[j] out of bounds :72 */
+        limbs_to_mpz(x, z_sim + (b * (K - 1) + j) * kw, kw);
+        mpz_powm(x, x, zn, znn);                                      /* zi^n :72 */
+        limbs_to_mpz(t, e_sim + (b * (K - 1) + j) * 8, 8);
+        mpz_powm(u, u, t, znn);                                       /* ui^ei :73 */
+        if (!mpz_invert(u, u, znn)) { panic = 1; break; }             /* :74 */
+        mpz_mul(av[i], x, u); mpz_mod(av[i], av[i], znn);             /* :76 */
+        j++;
+      }
+    }
+    memset(out_e_vec + b * K * 8, 0, K * 32); memset(out_z_vec + b * K * kw, 0, K * kw * 4); memset(out_a_vec + b * K * 2 * kw, 0, K * kw * 8);
+    mpz_to_limbs(out_ciphertext + b * 2 * kw, 2 * kw, ct);
+    if (panic) {
+      out_status[b] = ZKP_VERDICT_MALFORMED;
+    } else {
+      cm_challenge(chal, (const mpz_t*)av, K);
+      mpz_set_ui(sum, 0);
+      for (uint32_t k = 0; k + 1 < K; k++) { limbs_to_mpz(t, e_sim + (b * (K - 1) + k) * 8, 8); mpz_add(sum, sum, t); }   /* :90-91 (all K-1 of them) */
+      mpz_fdiv_r_2exp(sum, sum, 256);
+      mpz_sub(ei, chal, sum); mpz_fdiv_r_2exp(ei, ei, 256);            /* mod_sub :93 */
+      mpz_powm(zi, zr, ei, zn); mpz_mul(zi, zw, zi); mpz_mod(zi, zi, zn);   /* :94-95 */
+      j = 0;
+      for (uint32_t i = 0; i < K; i++) {
+        if (match[i]) {
+          mpz_to_limbs(out_e_vec + (b * K + i) * 8, 8, ei); mpz_to_limbs(out_z_vec + (b * K + i) * kw, kw, zi);
+        } else {
+          memcpy(out_e_vec + (b * K + i) * 8, e_sim + (b * (K - 1) + j) * 8, 32);
+          memcpy(out_z_vec + (b * K + i) * kw, z_sim + (b * (K - 1) + j) * kw, kw * 4);
+          j++;
+        }
+        mpz_to_limbs(out_a_vec + (b * K + i) * 2 * kw, 2 * kw, av[i]);
+      }
+      out_status[b] = 0;
+    }
+    free(match);
+    for (uint32_t i = 0; i < K; i++) mpz_clear(av[i]);
+    free(av);
+    mpz_clears(zn, znn, msg, zr, zw, ct, m, u, t, x, chal, sum, ei, zi, NULL);
+  }
+  return 0;
+}
+
+int32_t oracle_correct_message_verify_batch(uint32_t n_bits, uint64_t batch, uint32_t K, const uint32_t* n, uint64_t n_stride,
+                                            const uint32_t* valid_messages, const uint32_t* ciphertext, const uint32_t* e_vec,
+                                            const uint32_t* z_vec, const uint32_t* a_vec, uint8_t* out_verdict) {
+  const size_t kw = n_bits / 32;
+  if (K < 1) return 1;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int64_t b = 0; b < (int64_t)batch; b++) {
+    mpz_t zn, znn, ct, m, u, t, x, chal, sum;
+    mpz_inits(zn, znn, ct, m, u, t, x, chal, sum, NULL);
+    mpz_t* av = (mpz_t*)malloc(sizeof(mpz_t) * K);
+    limbs_to_mpz(zn, n + b * n_stride, kw); mpz_mul(znn, zn, zn);
+    limbs_to_mpz(ct, ciphertext + b * 2 * kw, 2 * kw);
+    for (uint32_t i = 0; i < K; i++) {
+      mpz_init(av[i]); limbs_to_mpz(av[i], a_vec + (b * K + i) * 2 * kw, 2 * kw);
+      limbs_to_mpz(t, e_vec + (b * K + i) * 8, 8); mpz_add(sum, sum, t);
+    }
+    cm_challenge(chal, (const mpz_t*)av, K);
+    mpz_fdiv_r_2exp(sum, sum, 256);
+    uint8_t v = ZKP_VERDICT_ACCEPT;
+    if (mpz_cmp(chal, sum) != 0) v = ZKP_VERDICT_MALFORMED;           /* assert_eq! :132 */
+    for (uint32_t i = 0; i < K && v != ZKP_VERDICT_MALFORMED; i++) {
+      limbs_to_mpz(m, valid_messages + (b * K + i) * kw, kw);
+      if (!cm_u(u, ct, m, zn, znn, t)) { v = ZKP_VERDICT_MALFORMED; break; }
+      limbs_to_mpz(x, z_vec + (b * K + i) * kw, kw);
+      mpz_powm(x, x, zn, znn);                                        /* zi^n :146 */
+      limbs_to_mpz(t, e_vec + (b * K + i) * 8, 8);
+      mpz_powm(u, u, t, znn);                                         /* ui^ei :147 */
+      mpz_mul(u, u, av[i]); mpz_mod(u, u, znn);                       /* :148 */
+      if (mpz_cmp(u, x) != 0) v = ZKP_VERDICT_REJECT;                 /* :149; all() :151 (no panic can follow) */
+    }
+    out_verdict[b] = v;
+    for (uint32_t i = 0; i < K; i++) mpz_clear(av[i]);
+    free(av);
+    mpz_clears(zn, znn, ct, m, u, t, x, chal, sum, NULL);
+  }
+  return 0;
+}

@@ -158,3 +158,39 @@ class Oracle:
 
     def range_verifier_output(self, proofs, e, e_len, out_verdict):
         return self.lib.oracle_range_verifier_output_batch(C.byref(proofs), p(e), p(e_len), p(out_verdict))
+
+    # ---- mod_inv, MulProof, CorrectMessageProof
+    def modinv(self, mod_bits, a, mod, mod_stride):
+        out = np.zeros_like(a); st = np.full(a.shape[0], 9, np.uint8)
+        self.lib.oracle_modinv_batch(C.c_uint32(mod_bits), C.c_uint64(a.shape[0]), p(a), p(mod), C.c_uint64(mod_stride), p(out), p(st))
+        return out, st
+
+    def mul_proof_prove(self, n_bits, n, n_stride, e_a, e_b, e_c, a, b, r_a, r_b, r_c, d, r_d):
+        B = e_a.shape[0]; kw = n_bits // 32
+        f = np.zeros((B, kw), np.uint32); z1, z2, e_d, e_db = (np.zeros((B, 2 * kw), np.uint32) for _ in range(4))
+        st = np.full(B, 9, np.uint8)
+        self.lib.oracle_mul_proof_prove_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(e_a), p(e_b), p(e_c), p(a), p(b),
+                                              p(r_a), p(r_b), p(r_c), p(d), p(r_d), p(f), p(z1), p(z2), p(e_d), p(e_db), p(st))
+        return f, z1, z2, e_d, e_db, st
+
+    def mul_proof_verify(self, n_bits, n, n_stride, e_a, e_b, e_c, f, z1, z2, e_d, e_db):
+        B = e_a.shape[0]
+        v = np.full(B, 9, np.uint8)
+        self.lib.oracle_mul_proof_verify_batch(C.c_uint32(n_bits), C.c_uint64(B), p(n), C.c_uint64(n_stride), p(e_a), p(e_b), p(e_c), p(f), p(z1),
+                                               p(z2), p(e_d), p(e_db), p(v))
+        return v
+
+    def correct_message_prove(self, n_bits, K, n, n_stride, valid, message, r, e_sim, z_sim, w):
+        B = message.shape[0]; kw = n_bits // 32
+        ct = np.zeros((B, 2 * kw), np.uint32); e_vec = np.zeros((B, K, 8), np.uint32); z_vec = np.zeros((B, K, kw), np.uint32)
+        a_vec = np.zeros((B, K, 2 * kw), np.uint32); st = np.full(B, 9, np.uint8)
+        self.lib.oracle_correct_message_prove_batch(C.c_uint32(n_bits), C.c_uint64(B), C.c_uint32(K), p(n), C.c_uint64(n_stride), p(valid), p(message),
+                                                    p(r), p(e_sim), p(z_sim), p(w), p(ct), p(e_vec), p(z_vec), p(a_vec), p(st))
+        return ct, e_vec, z_vec, a_vec, st
+
+    def correct_message_verify(self, n_bits, K, n, n_stride, valid, ct, e_vec, z_vec, a_vec):
+        B = ct.shape[0]
+        v = np.full(B, 9, np.uint8)
+        self.lib.oracle_correct_message_verify_batch(C.c_uint32(n_bits), C.c_uint64(B), C.c_uint32(K), p(n), C.c_uint64(n_stride), p(valid), p(ct),
+                                                     p(e_vec), p(z_vec), p(a_vec), p(v))
+        return v

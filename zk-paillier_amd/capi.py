@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libzkp_hip.so")
 ZKP_OK, ZKP_EINVAL, ZKP_ENONCANONICAL, ZKP_EDEVICE, ZKP_ENOMEM = range(5)
 ZKP_F_DEVICE_PTRS = 1
 VERDICT_REJECT, VERDICT_ACCEPT, VERDICT_MALFORMED = 0, 1, 2
+INV_OK, INV_NONE, INV_DOMAIN = 0, 1, 2
 RESP_OPEN, RESP_MASK = 0, 1
 SECURITY_PARAMETER = 128
 CORRECT_KEY_M2 = 11
@@ -62,6 +63,11 @@ EXPORTS = {
     "zkp_range_generate_proof_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness), C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_uint32]),
     "zkp_range_verifier_output_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_modinv_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_mul_proof_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64] + [C.c_void_p] * 16 + [C.c_uint32]),
+    "zkp_mul_proof_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64] + [C.c_void_p] * 9 + [C.c_uint32]),
+    "zkp_correct_message_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64] + [C.c_void_p] * 11 + [C.c_uint32]),
+    "zkp_correct_message_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64] + [C.c_void_p] * 6 + [C.c_uint32]),
     "zkp_correct_key_ni_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "zkp_dlog_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
@@ -240,3 +246,26 @@ class Context:
     def range_verifier_output(self, proofs, e, e_len, out_verdict, device: bool):
         self.check(self.lib.zkp_range_verifier_output_batch(self.h, C.byref(proofs), ptr(e), ptr(e_len), ptr(out_verdict),
                                                             ZKP_F_DEVICE_PTRS if device else 0))
+
+    # ---- mod_inv, MulProof
+    def modinv(self, mod_bits, count, a, mod, mod_stride, out, out_status):
+        self.check(self.lib.zkp_modinv_batch(self.h, mod_bits, count, ptr(a), ptr(mod), mod_stride, ptr(out), ptr(out_status),
+                                             self._flags(a, mod, out, out_status)))
+
+    def mul_proof_prove(self, n_bits, batch, n, n_stride, e_a, e_b, e_c, a, b, r_a, r_b, r_c, d, r_d, out_f, out_z1, out_z2, out_e_d, out_e_db, out_status):
+        arrs = (e_a, e_b, e_c, a, b, r_a, r_b, r_c, d, r_d, out_f, out_z1, out_z2, out_e_d, out_e_db, out_status)
+        self.check(self.lib.zkp_mul_proof_prove_batch(self.h, n_bits, batch, ptr(n), n_stride, *[ptr(x) for x in arrs], self._flags(n, *arrs)))
+
+    def mul_proof_verify(self, n_bits, batch, n, n_stride, e_a, e_b, e_c, f, z1, z2, e_d, e_db, out_verdict):
+        arrs = (e_a, e_b, e_c, f, z1, z2, e_d, e_db, out_verdict)
+        self.check(self.lib.zkp_mul_proof_verify_batch(self.h, n_bits, batch, ptr(n), n_stride, *[ptr(x) for x in arrs], self._flags(n, *arrs)))
+
+    # ---- CorrectMessageProof
+    def correct_message_prove(self, n_bits, batch, K, n, n_stride, valid, message, r, e_sim, z_sim, w, out_ct, out_e_vec, out_z_vec, out_a_vec, out_status):
+        arrs = (valid, message, r, e_sim if K > 1 else None, z_sim if K > 1 else None, w, out_ct, out_e_vec, out_z_vec, out_a_vec, out_status)
+        self.check(self.lib.zkp_correct_message_prove_batch(self.h, n_bits, batch, K, ptr(n), n_stride, *[ptr(x) for x in arrs],
+                                                            self._flags(n, *[x for x in arrs if x is not None])))
+
+    def correct_message_verify(self, n_bits, batch, K, n, n_stride, valid, ct, e_vec, z_vec, a_vec, out_verdict):
+        arrs = (valid, ct, e_vec, z_vec, a_vec, out_verdict)
+        self.check(self.lib.zkp_correct_message_verify_batch(self.h, n_bits, batch, K, ptr(n), n_stride, *[ptr(x) for x in arrs], self._flags(n, *arrs)))

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
 struct ModmulArgs {
   const uint32_t* a; const uint32_t* b; const uint32_t* consts; uint64_t const_stride; uint32_t* out; uint64_t count;
   int io_words;             // words per out element (and per a / b element unless overridden below)
-  int a_words = 0, b_words = 0;
+  int a_words = 0, b_words = 0;   // b == nullptr: the factor 1 (out = a mod M, canonical)
 };
 template <int G>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_modmul(ModmulArgs a) {
@@ -482,8 +482,8 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modmul(ModmulArgs a) {
   load_limbs_global<G>(Y, cst + CL::OFF_R2, g.gl);
   stageB<G>(g, Y);
   mm<G>(g, R, X);                         // a*R
-  load_value<G>(g, Y, a.b + item * bw, bw);
-  stageB<G>(g, Y);
+  if (a.b) { load_value<G>(g, Y, a.b + item * bw, bw); stageB<G>(g, Y); }
+  else stage_one<G>(g);
   mm<G>(g, X, R);                         // a*b  (< M + eps, value may equal a multiple? a*b*R/R reduced: <= M)
   // X < 2M possible when b >= M: force through montmul(.,1) after re-entering the domain is overkill;
   // instead reduce once more: X*R2/R then *1/R

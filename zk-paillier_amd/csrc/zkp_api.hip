@@ -12,6 +12,7 @@
 #include "../../include/zkp_hip.h"
 #include "kernels_modexp.hpp"
 #include "kernels_proofs.hpp"
+#include "kernels_inv.hpp"
 
 using namespace zkp;
 
@@ -25,7 +26,7 @@ struct zkp_ctx {
   hipStream_t stream = nullptr;
   int cus = 0;
   std::string err;
-  DevBuf consts, consts2, table, scratch[24];
+  DevBuf consts, consts2, table, scratch[48];
   // timing of the dominant kernels
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -397,3 +398,4 @@ extern "C" int32_t zkp_paillier_enc_batch(zkp_ctx* c, uint32_t n_bits, uint64_t 
 }
 
 #include "zkp_api_proofs.inc"
+#include "zkp_api_mul.inc"
