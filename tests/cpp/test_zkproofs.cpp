@@ -208,6 +208,39 @@ static void verlin_case(bool bad) {
 static void test_verlin_proof() { verlin_case(false); }
 static void test_bad_verlin_proof() { verlin_case(true); }   // #[should_panic]
 
+// ---- multiplication_proof.rs tests (:172-290)
+static void mul_case(bool honest) {
+  auto [ek, dk] = test_keypair().keys();
+  BigInt a = BigInt::sample_below(ek.n), b = BigInt::sample_below(ek.n);
+  BigInt c = (a * b) % ek.n;
+  if (!honest) c = c + BigInt::one();
+  BigInt r_a = sample_paillier_random(ek.n), r_b = sample_paillier_random(ek.n), r_c = sample_paillier_random(ek.n);
+  MulStatement st{ek, Paillier::encrypt_with_chosen_randomness(ek, a, r_a), Paillier::encrypt_with_chosen_randomness(ek, b, r_b),
+                  Paillier::encrypt_with_chosen_randomness(ek, c, r_c)};
+  MulWitness w{a, b, c, r_a, r_b, r_c};
+  MulProof proof = MulProof::prove(w, st);
+  ASSERT(proof.verify(st).is_ok());
+}
+static void test_mul_proof() { mul_case(true); }
+static void test_bad_mul_proof() { mul_case(false); }   // #[should_panic]
+static void test_mod_inv() {
+  auto [ek, dk] = test_keypair().keys();
+  std::vector<BigInt> v = {BigInt(3), BigInt::sample_below(ek.nn), dk.p, BigInt(0)};
+  auto r = mod_inv_batch(v, ek.nn);
+  ASSERT(r[0].some && (r[0].value * v[0]) % ek.nn == BigInt::one());
+  ASSERT(r[1].some && (r[1].value * v[1]) % ek.nn == BigInt::one());
+  ASSERT(!r[2].some && !r[3].some);
+}
+// ---- correct_message.rs tests (:169-200)
+static void cm_case(uint64_t message) {
+  std::vector<BigInt> valid = {BigInt(3), BigInt(4), BigInt(5), BigInt(6)};
+  auto [ek, dk] = test_keypair().keys();
+  CorrectMessageProof proof = CorrectMessageProof::prove(ek, valid, BigInt(message));
+  ASSERT(proof.verify().is_ok());
+}
+static void test_correct_message_zk_proof() { cm_case(4); }
+static void test_bad_message_zk_proof() { cm_case(7); }   // #[should_panic]
+
 // ---- range_proof.rs tests (:385-525)
 static constexpr size_t SEF = RangeProof::STATISTICAL_ERROR_FACTOR;
 static void test_generate_encrypted_pairs() {   // :386-391
@@ -257,6 +290,11 @@ static void test_range_proof_correct_proof() { interactive_case(true); }
 static void test_range_proof_incorrect_proof() { interactive_case(false); }
 
 int main() {
+  run("multiplication_proof::test_mul_proof", test_mul_proof);
+  run("multiplication_proof::test_bad_mul_proof", test_bad_mul_proof, true);
+  run("mod_inv batch", test_mod_inv);
+  run("correct_message::test_correct_message_zk_proof", test_correct_message_zk_proof);
+  run("correct_message::test_bad_message_zk_proof", test_bad_message_zk_proof, true);
   run("range_proof::test_generate_encrypted_pairs", test_generate_encrypted_pairs);
   run("range_proof::test_commit_decommit", test_commit_decommit);
   run("range_proof::test_generate_proof", test_generate_proof);

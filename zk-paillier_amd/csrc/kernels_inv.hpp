@@ -13,8 +13,7 @@ namespace zkp {
 //   invariants u == x*a, v == y*a (mod M); u loses its trailing zero bits z at a time and x is divided by 2^z
 //   modulo M in ONE multiply-accumulate pass (x + ((x0 * -M^-1) mod 2^z) * M is divisible by 2^z); then the larger
 //   of (u, v) is reduced by the other.  gcd = v at the end; the inverse is y when gcd == 1.
-// u, v, x, y live in thread-interleaved LDS (word w of lane t at base[w * LANES + t]: conflict-free); the modulus is
-// read from global memory (one broadcast load per word when the batch shares it).  Data-dependent trip counts: lanes
+// u, v, x, y and a copy of M live in thread-interleaved LDS (word w of lane t at base[w * LANES + t]: conflict-free).  Data-dependent trip counts: lanes
 // of a wavefront wait for the slowest one.
 struct ModinvArgs {
   const uint32_t* a; uint64_t a_stride;        // words between consecutive items
@@ -36,6 +35,7 @@ __global__ void __launch_bounds__(64) k_modinv(ModinvArgs a) {
   uint32_t* v = u + (size_t)kw * S;
   uint32_t* x = v + (size_t)kw * S;
   uint32_t* y = x + (size_t)kw * S;
+  uint32_t* Ml = y + (size_t)kw * S;                  // this lane's copy of the modulus
   // domain: M odd, M >= 3, 0 <= a < M
   int cmp = 0;
   bool a_zero = true, m_small = M[0] < 3;
@@ -52,30 +52,47 @@ __global__ void __launch_bounds__(64) k_modinv(ModinvArgs a) {
 #pragma unroll
   for (int it = 0; it < 5; it++) minv *= 2u - M[0] * minv;
   minv = 0u - minv;                                   // -M^-1 mod 2^32
-  for (int w = 0; w < kw; w++) { u[w * S] = A[w]; v[w * S] = M[w]; x[w * S] = w == 0; y[w * S] = 0; }
+  for (int w = 0; w < kw; w++) { u[w * S] = A[w]; v[w * S] = M[w]; Ml[w * S] = M[w]; x[w * S] = w == 0; y[w * S] = 0; }
   int nu = kw, nv = kw;                               // live word counts of u, v
+  // The word loops below work on chunks of CH words: all loads of a chunk are issued before its first store (the
+  // compiler cannot prove that u, v, x, y and M do not alias, so a plain loop would serialise load -> store -> load and
+  // pay the LDS round trip per word).  kw is a multiple of CH and words above a live count are zero, so a chunk may
+  // run past nu / nv inside the array.
+  constexpr int CH = 8;
   for (;;) {
     // ---- u odd: drop zw whole zero words and zb bits; x /= 2^(32 zw + zb) mod M
     int zw = 0;
     while (u[zw * S] == 0) zw++;
     const int zb = __builtin_ctz(u[zw * S]);
     if (zw | zb) {
-      for (int w = 0; w < nu; w++) {
-        const int s0 = w + zw;
-        const uint32_t lo = s0 < nu ? u[s0 * S] : 0u, hi = s0 + 1 < nu ? u[(s0 + 1) * S] : 0u;
-        u[w * S] = zb ? ((lo >> zb) | (hi << (32 - zb))) : lo;
+      for (int w0 = 0; w0 < nu; w0 += CH) {
+        uint32_t t[CH + 1];
+#pragma unroll
+        for (int k = 0; k <= CH; k++) { const int s0 = w0 + k + zw; t[k] = s0 < kw ? u[s0 * S] : 0u; }
+#pragma unroll
+        for (int k = 0; k < CH; k++) u[(w0 + k) * S] = zb ? ((t[k] >> zb) | (t[k + 1] << (32 - zb))) : t[k];
       }
       for (int step = 0; step < zw + (zb ? 1 : 0); step++) {
         const int z = step < zw ? 32 : zb;
         const uint32_t t = (x[0] * minv) & (z == 32 ? 0xFFFFFFFFu : ((1u << z) - 1));
         uint64_t carry = 0;
         uint32_t prev = 0;
-        for (int w = 0; w < kw; w++) {
-          const uint64_t acc = (uint64_t)t * M[w] + x[w * S] + carry;
-          const uint32_t low = (uint32_t)acc;
-          carry = acc >> 32;
-          if (w > 0) x[(w - 1) * S] = z == 32 ? low : ((prev >> z) | (low << (32 - z)));
-          prev = low;
+        for (int w0 = 0; w0 < kw; w0 += CH) {
+          uint32_t xs[CH], ms[CH], lo[CH];
+#pragma unroll
+          for (int k = 0; k < CH; k++) { xs[k] = x[(w0 + k) * S]; ms[k] = Ml[(w0 + k) * S]; }
+#pragma unroll
+          for (int k = 0; k < CH; k++) {
+            const uint64_t acc = (uint64_t)t * ms[k] + xs[k] + carry;
+            lo[k] = (uint32_t)acc;
+            carry = acc >> 32;
+          }
+#pragma unroll
+          for (int k = 0; k < CH; k++) {
+            const uint32_t below = k ? lo[k - 1] : prev;
+            if (w0 + k > 0) x[(w0 + k - 1) * S] = z == 32 ? lo[k] : ((below >> z) | (lo[k] << (32 - z)));
+          }
+          prev = lo[CH - 1];
         }
         x[(kw - 1) * S] = z == 32 ? (uint32_t)carry : ((prev >> z) | ((uint32_t)carry << (32 - z)));
       }
@@ -93,24 +110,38 @@ __global__ void __launch_bounds__(64) k_modinv(ModinvArgs a) {
       t = x; x = y; y = t;
       const int tn = nu; nu = nv; nv = tn;
     }
-    uint32_t borrow = 0;                              // u -= v (both odd: the difference is even and not zero)
-    for (int w = 0; w < nu; w++) {
-      const uint64_t d = (uint64_t)u[w * S] - (w < nv ? v[w * S] : 0u) - borrow;
-      u[w * S] = (uint32_t)d;
-      borrow = (uint32_t)(d >> 63);
+    uint32_t borrow = 0;                              // u -= v (both odd: the difference is even and not zero; nv <= nu)
+    for (int w0 = 0; w0 < nu; w0 += CH) {
+      uint32_t p[CH], q[CH];
+#pragma unroll
+      for (int k = 0; k < CH; k++) { p[k] = u[(w0 + k) * S]; q[k] = v[(w0 + k) * S]; }
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
+        u[(w0 + k) * S] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 63);
+      }
     }
-    borrow = 0;                                       // x = (x - y) mod M
-    for (int w = 0; w < kw; w++) {
-      const uint64_t d = (uint64_t)x[w * S] - y[w * S] - borrow;
-      x[w * S] = (uint32_t)d;
-      borrow = (uint32_t)(d >> 63);
+    // x = (x - y) mod M: x < y is decided from the top first, then ONE pass computes x - y (+ M)
+    int lt = 0;
+    for (int w = kw - 1; lt == 0 && w >= 0; w--) {
+      const uint32_t p = x[w * S], q = y[w * S];
+      if (p != q) lt = p < q ? 1 : -1;
     }
-    if (borrow) {
-      uint32_t cy = 0;
-      for (int w = 0; w < kw; w++) {
-        const uint64_t s = (uint64_t)x[w * S] + M[w] + cy;
-        x[w * S] = (uint32_t)s;
-        cy = (uint32_t)(s >> 32);
+    const uint32_t addm = lt > 0 ? 0xFFFFFFFFu : 0u;
+    uint32_t cy = 0;
+    borrow = 0;
+    for (int w0 = 0; w0 < kw; w0 += CH) {
+      uint32_t p[CH], q[CH], m[CH];
+#pragma unroll
+      for (int k = 0; k < CH; k++) { p[k] = x[(w0 + k) * S]; q[k] = y[(w0 + k) * S]; m[k] = Ml[(w0 + k) * S] & addm; }
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
+        borrow = (uint32_t)(d >> 63);
+        const uint64_t sm = (uint64_t)(uint32_t)d + m[k] + cy;
+        cy = (uint32_t)(sm >> 32);
+        x[(w0 + k) * S] = (uint32_t)sm;
       }
     }
   }

@@ -5,6 +5,7 @@
 //
 //   reference                                                      here
 //   zkproofs::RangeProofNi::{prove,verify,verify_self}              RangeProofNi::{prove,verify,verify_self}   (+ *_batch)
+//   zkproofs::{MulProof, CorrectMessageProof}::{prove,verify}, BigInt::mod_inv    MulProof, CorrectMessageProof, mod_inv_batch
 //   zkproofs::RangeProof::{verifier_commit,verify_commit,generate_encrypted_pairs,generate_proof,verifier_output}   RangeProof::*
 //     src/zkproofs/range_proof_ni.rs:36-128
 //   zkproofs::NiCorrectKeyProof::{proof,verify}                     NiCorrectKeyProof::{proof,verify}
@@ -656,6 +657,119 @@ class VerlinProof {
     uint8_t v = 9;
     e.check(zkp_verlin_proof_verify_batch(e.ctx(), nb, 1, n.data(), 0, c.data(), cp.data(), phx.data(), pa.data(), vz.data(), vzp.data(), vzpp.data(),
                                           vrz.data(), &v, 0), "zkp_verlin_proof_verify_batch");
+    return Result(v == ZKP_VERDICT_ACCEPT);
+  }
+};
+
+// ------------------------------------------------------------------ BigInt::mod_inv (batched on the GPU)
+// None (std::nullopt-like: empty vector entry flagged) when no inverse exists; throws std::domain_error outside the ABI's domain
+struct ModInvResult { bool some; BigInt value; };
+inline std::vector<ModInvResult> mod_inv_batch(const std::vector<BigInt>& a, const BigInt& modulus) {
+  Engine& e = Engine::instance();
+  uint32_t mb = width_for(modulus); if (mb < 2048) mb = 2048;
+  const size_t L = mb / 32, cnt = a.size();
+  std::vector<uint32_t> av(cnt * L), mv(L), out(cnt * L);
+  std::vector<uint8_t> stv(cnt);
+  modulus.to_limbs(mv.data(), L);
+  for (size_t i = 0; i < cnt; i++) (a[i] % modulus).to_limbs(&av[i * L], L);
+  if (cnt) e.check(zkp_modinv_batch(e.ctx(), mb, cnt, av.data(), mv.data(), 0, out.data(), stv.data(), 0), "zkp_modinv_batch");
+  std::vector<ModInvResult> r;
+  for (size_t i = 0; i < cnt; i++) {
+    if (stv[i] == ZKP_INV_DOMAIN) throw std::domain_error("mod_inv: even or trivial modulus");
+    r.push_back({stv[i] == ZKP_INV_OK, BigInt::from_limbs(&out[i * L], L)});
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------ MulProof (src/zkproofs/multiplication_proof.rs)
+struct MulWitness { BigInt a, b, c, r_a, r_b, r_c; };          // :42-50
+struct MulStatement { EncryptionKey ek; BigInt e_a, e_b, e_c; };   // :52-58
+inline BigInt sample_paillier_random(const BigInt& modulo) {    // :148-154
+  BigInt r = BigInt::sample_below(modulo);
+  while (BigInt::gcd(r, modulo) != BigInt::one()) r = BigInt::sample_below(modulo);
+  return r;
+}
+class MulProof {
+ public:
+  BigInt f, z1, z2, e_d, e_db;
+  static MulProof prove(const MulWitness& w, const MulStatement& st) {   // :60-104
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.ek.n), kw = nb / 32;
+    const BigInt d = BigInt::sample_below(st.ek.n), r_d = sample_paillier_random(st.ek.n);   // :61-62
+    auto L1 = [&](const BigInt& v, size_t n) { std::vector<uint32_t> o(n); v.to_limbs(o.data(), n); return o; };
+    auto n = L1(st.ek.n, kw), ea = L1(st.e_a, 2 * kw), eb = L1(st.e_b, 2 * kw), ec = L1(st.e_c, 2 * kw);
+    auto a = L1(w.a, kw), b = L1(w.b, kw), ra = L1(w.r_a, kw), rb = L1(w.r_b, kw), rc = L1(w.r_c, kw), vd = L1(d, kw), vrd = L1(r_d, kw);
+    std::vector<uint32_t> f(kw), z1(2 * kw), z2(2 * kw), ed(2 * kw), edb(2 * kw);
+    uint8_t status = 9;
+    e.check(zkp_mul_proof_prove_batch(e.ctx(), nb, 1, n.data(), 0, ea.data(), eb.data(), ec.data(), a.data(), b.data(), ra.data(), rb.data(), rc.data(),
+                                      vd.data(), vrd.data(), f.data(), z1.data(), z2.data(), ed.data(), edb.data(), &status, 0), "zkp_mul_proof_prove_batch");
+    if (status != 0) throw Panic("called `Option::unwrap()` on a `None` value (mod_inv, multiplication_proof.rs:95)");
+    return MulProof{BigInt::from_limbs(f.data(), kw), BigInt::from_limbs(z1.data(), 2 * kw), BigInt::from_limbs(z2.data(), 2 * kw),
+                    BigInt::from_limbs(ed.data(), 2 * kw), BigInt::from_limbs(edb.data(), 2 * kw)};
+  }
+  Result verify(const MulStatement& st) const {                         // :106-146
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(st.ek.n), kw = nb / 32;
+    auto L1 = [&](const BigInt& v, size_t n) { std::vector<uint32_t> o(n); v.to_limbs(o.data(), n); return o; };
+    auto n = L1(st.ek.n, kw), ea = L1(st.e_a, 2 * kw), eb = L1(st.e_b, 2 * kw), ec = L1(st.e_c, 2 * kw);
+    auto vf = L1(f, kw), vz1 = L1(z1, 2 * kw), vz2 = L1(z2, 2 * kw), ved = L1(e_d, 2 * kw), vedb = L1(e_db, 2 * kw);
+    uint8_t v = 9;
+    e.check(zkp_mul_proof_verify_batch(e.ctx(), nb, 1, n.data(), 0, ea.data(), eb.data(), ec.data(), vf.data(), vz1.data(), vz2.data(), ved.data(), vedb.data(),
+                                       &v, 0), "zkp_mul_proof_verify_batch");
+    if (v == ZKP_VERDICT_MALFORMED) throw Panic("called `Option::unwrap()` on a `None` value (mod_inv, multiplication_proof.rs:135)");
+    return Result(v == ZKP_VERDICT_ACCEPT);
+  }
+};
+
+// ------------------------------------------------------------------ CorrectMessageProof (src/zkproofs/correct_message.rs)
+class CorrectMessageProof {
+ public:
+  std::vector<BigInt> e_vec, z_vec, a_vec;
+  BigInt ciphertext;
+  std::vector<BigInt> valid_messages;
+  EncryptionKey ek;
+  static constexpr size_t B = 256;   // :19
+  static CorrectMessageProof prove(const EncryptionKey& ek, const std::vector<BigInt>& valid_messages, const BigInt& message_to_encrypt) {   // :35-123
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    const size_t K = valid_messages.size();
+    if (K == 0) throw Panic("attempt to subtract with overflow (num_of_message - 1, correct_message.rs:58)");
+    auto L1 = [&](const BigInt& v, size_t n) { std::vector<uint32_t> o(n); v.to_limbs(o.data(), n); return o; };
+    auto n = L1(ek.n, kw), msg = L1(message_to_encrypt, kw), r = L1(BigInt::sample_below(ek.n), kw), w = L1(BigInt::sample_below(ek.n), kw);   // :43, :65
+    std::vector<uint32_t> valid(K * kw), esim((K - 1) * 8 + 8), zsim((K - 1) * kw + kw);
+    for (size_t i = 0; i < K; i++) valid_messages[i].to_limbs(&valid[i * kw], kw);
+    for (size_t j = 0; j + 1 < K; j++) {
+      BigInt::sample(B).to_limbs(&esim[j * 8], 8);                       // :59-61
+      BigInt::sample_below(ek.n).to_limbs(&zsim[j * kw], kw);            // :62-64
+    }
+    std::vector<uint32_t> ct(2 * kw), ev(K * 8), zv(K * kw), av(K * 2 * kw);
+    uint8_t status = 9;
+    e.check(zkp_correct_message_prove_batch(e.ctx(), nb, 1, (uint32_t)K, n.data(), 0, valid.data(), msg.data(), r.data(), esim.data(), zsim.data(), w.data(),
+                                            ct.data(), ev.data(), zv.data(), av.data(), &status, 0), "zkp_correct_message_prove_batch");
+    if (status != 0) throw Panic("index out of bounds (correct_message.rs:72: no valid message equals the encrypted one)");
+    CorrectMessageProof p;
+    p.ciphertext = BigInt::from_limbs(ct.data(), 2 * kw); p.valid_messages = valid_messages; p.ek = ek;
+    for (size_t i = 0; i < K; i++) {
+      p.e_vec.push_back(BigInt::from_limbs(&ev[i * 8], 8)); p.z_vec.push_back(BigInt::from_limbs(&zv[i * kw], kw));
+      p.a_vec.push_back(BigInt::from_limbs(&av[i * 2 * kw], 2 * kw));
+    }
+    return p;
+  }
+  Result verify() const {                                                 // :124-162
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    const size_t K = valid_messages.size();
+    if (e_vec.size() < K || z_vec.size() < K || a_vec.size() < K) throw Panic("index out of bounds");
+    auto L1 = [&](const BigInt& v, size_t n) { std::vector<uint32_t> o(n); v.to_limbs(o.data(), n); return o; };
+    auto n = L1(ek.n, kw), ct = L1(ciphertext, 2 * kw);
+    std::vector<uint32_t> valid(K * kw), ev(K * 8), zv(K * kw), av(K * 2 * kw);
+    for (size_t i = 0; i < K; i++) {
+      valid_messages[i].to_limbs(&valid[i * kw], kw); e_vec[i].to_limbs(&ev[i * 8], 8); z_vec[i].to_limbs(&zv[i * kw], kw); a_vec[i].to_limbs(&av[i * 2 * kw], 2 * kw);
+    }
+    uint8_t v = 9;
+    e.check(zkp_correct_message_verify_batch(e.ctx(), nb, 1, (uint32_t)K, n.data(), 0, valid.data(), ct.data(), ev.data(), zv.data(), av.data(), &v, 0),
+            "zkp_correct_message_verify_batch");
+    if (v == ZKP_VERDICT_MALFORMED) throw Panic("assertion failed: `(left == right)` chal / ei_sum (correct_message.rs:132)");
     return Result(v == ZKP_VERDICT_ACCEPT);
   }
 };
