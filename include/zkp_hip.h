@@ -271,6 +271,46 @@ int32_t zkp_correct_message_verify_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t
                                          uint64_t n_stride, const uint32_t* valid_messages, const uint32_t* ciphertext, const uint32_t* e_vec,
                                          const uint32_t* z_vec, const uint32_t* a_vec, uint8_t* out_verdict, uint32_t flags);
 
+/* ------------------------------------------------------------------ wire format
+ * The reference serialises big integers as DECIMAL strings (src/serialize.rs:1-31 `bigint`, :33-78 `vecbigint`:
+ * BigInt::to_str_radix(10) / from_str_radix(s, 10) = GMP mpz_get_str / mpz_set_str).  The two L1 entry points below
+ * convert between that text and the fixed-width limb arrays of this ABI on the GPU, one number per lane.
+ *
+ * zkp_decimal_to_limbs_batch: item i is text[text_off .. text_off+len), converted into dst[dst_off .. dst_off+words)
+ * (little-endian words, zero extended).  Accepted exactly as mpz_set_str(s, 10): optional leading '-', white space
+ * anywhere.  out_status[i]: ZKP_DEC_OK; ZKP_DEC_INVALID (mpz_set_str fails: serde error / `unwrap()` panic at
+ * serialize.rs:66); ZKP_DEC_NEGATIVE, ZKP_DEC_OVERFLOW (a valid BigInt this fixed-width ABI cannot carry: the caller
+ * keeps that proof on its CPU path).  dst words of a failed item are zero.  words <= 528. */
+typedef struct zkp_dec_item { uint64_t text_off; uint64_t dst_off; uint32_t len; uint32_t words; } zkp_dec_item;
+#define ZKP_DEC_OK 0
+#define ZKP_DEC_INVALID 1
+#define ZKP_DEC_NEGATIVE 2
+#define ZKP_DEC_OVERFLOW 3
+int32_t zkp_decimal_to_limbs_batch(zkp_ctx* ctx, const char* text, uint64_t text_len, const zkp_dec_item* items, uint64_t count,
+                                   uint32_t* dst, uint64_t dst_words, uint8_t* out_status, uint32_t flags);
+/* zkp_limbs_to_decimal_batch: src[i*src_stride .. +words) -> the decimal string of item i, right aligned in row i of
+ * out_text (rows of `pitch` bytes, pitch >= zkp_decimal_pitch(words)): the string is out_text + i*pitch + pitch - out_len[i],
+ * out_len[i] bytes, no terminator, no leading zeros, "0" for zero. */
+uint32_t zkp_decimal_pitch(uint32_t words);
+int32_t zkp_limbs_to_decimal_batch(zkp_ctx* ctx, const uint32_t* src, uint64_t src_stride, uint32_t words, uint64_t count,
+                                   char* out_text, uint32_t pitch, uint32_t* out_len, uint32_t flags);
+
+/* serde_json documents of the reference's proof types -> the SoA batch (one document per proof, documents back to back or
+ * anywhere in `text`; doc_off/doc_len [B]).  Field layout = serde defaults for the derives at range_proof.rs:32-81
+ * (EncryptedPairs {"c1":[..],"c2":[..]}, Proof = [{"Open":{"w1","r1","w2","r2"}} | {"Mask":{"j","masked_x","masked_r"}} ..])
+ * and correct_key_ni.rs:35-39 ({"sigma_vec":[..]}); white space between tokens is accepted (to_string_pretty).
+ * The tokenising runs on the host (threads), every number is converted on the GPU into p->c1/c2 (pairs) or p->resp_*
+ * (proof); p->error_factor rows are expected.  out_status[b]: 0, or ZKP_VERDICT_MALFORMED when document b is not of the
+ * expected shape, has another row count, or holds a number the ABI cannot carry (see ZKP_DEC_*): those proofs stay on the
+ * caller's CPU path.  ZKP_F_DEVICE_PTRS applies to the p-> arrays and out_status; text and offsets are host memory. */
+int32_t zkp_json_encrypted_pairs_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len,
+                                       const zkp_range_ni_proofs* p, uint8_t* out_status, uint32_t flags);
+int32_t zkp_json_range_proof_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len,
+                                   const zkp_range_ni_proofs* p, uint8_t* out_status, uint32_t flags);
+/* {"sigma_vec":["..", x11]} -> sigma [B][11][n_bits/32] */
+int32_t zkp_json_correct_key_proof_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len, uint32_t n_bits,
+                                         uint64_t batch, uint32_t* out_sigma, uint8_t* out_status, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -980,3 +980,45 @@ int32_t oracle_correct_message_verify_batch(uint32_t n_bits, uint64_t batch, uin
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------ wire format: decimal strings (serialize.rs:1-78)
+ * BigInt::from_str_radix(s, 10) -> mpz_set_str; BigInt::to_str_radix(10) -> mpz_get_str. */
+int32_t oracle_decimal_to_limbs_batch(const char* text, const zkp_dec_item* items, uint64_t count, uint32_t* dst, uint8_t* out_status) {
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 16)
+  for (int64_t i = 0; i < (int64_t)count; i++) {
+    const zkp_dec_item it = items[i];
+    char* s = (char*)malloc((size_t)it.len + 1);
+    memcpy(s, text + it.text_off, it.len);
+    s[it.len] = 0;
+    mpz_t z;
+    mpz_init(z);
+    uint8_t st = ZKP_DEC_OK;
+    if (memchr(s, 0, it.len) != NULL) st = ZKP_DEC_INVALID;          /* CString::new fails on an interior NUL */
+    else if (mpz_set_str(z, s, 10) != 0) st = ZKP_DEC_INVALID;
+    else if (mpz_sgn(z) < 0) st = ZKP_DEC_NEGATIVE;
+    else if (mpz_sizeinbase(z, 2) > (size_t)it.words * 32) st = ZKP_DEC_OVERFLOW;
+    memset(dst + it.dst_off, 0, (size_t)it.words * 4);
+    if (st == ZKP_DEC_OK) mpz_to_limbs(dst + it.dst_off, it.words, z);
+    out_status[i] = st;
+    mpz_clear(z);
+    free(s);
+  }
+  return 0;
+}
+
+int32_t oracle_limbs_to_decimal_batch(const uint32_t* src, uint64_t src_stride, uint32_t words, uint64_t count, char* out_text, uint32_t pitch,
+                                      uint32_t* out_len) {
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 16)
+  for (int64_t i = 0; i < (int64_t)count; i++) {
+    mpz_t z;
+    mpz_init(z);
+    limbs_to_mpz(z, src + i * src_stride, words);
+    char* s = mpz_get_str(NULL, 10, z);
+    const size_t n = strlen(s);
+    memcpy(out_text + i * (uint64_t)pitch + pitch - n, s, n);
+    out_len[i] = (uint32_t)n;
+    free(s);
+    mpz_clear(z);
+  }
+  return 0;
+}

@@ -208,6 +208,27 @@ static void verlin_case(bool bad) {
 static void test_verlin_proof() { verlin_case(false); }
 static void test_bad_verlin_proof() { verlin_case(true); }   // #[should_panic]
 
+// ---- wire format: prove, write as serde_json text, read back, verify
+static void test_serde_round_trip() {
+  auto [ek, dk] = test_keypair().keys();
+  BigInt range = BigInt::sample(RANGE_BITS);
+  BigInt secret_r = BigInt::sample_below(ek.n);
+  BigInt secret_x = BigInt::sample_below(range.div_floor(BigInt(3)));
+  BigInt cipher_x = Paillier::encrypt_with_chosen_randomness(ek, secret_x, secret_r);
+  RangeProofNi proof = RangeProofNi::prove(ek, range, cipher_x, secret_x, secret_r);
+  const std::string pairs = serde_json::to_string(proof.encrypted_pairs, ek), resp = serde_json::to_string(proof.proof, ek);
+  ASSERT(pairs.rfind("{\"c1\":[\"", 0) == 0 && resp.rfind("[{\"", 0) == 0);
+  auto back = serde_json::range_from_str(ek, RangeProofNi::SECURITY_PARAMETER, {pairs}, {resp});
+  RangeProofNi copy = proof;
+  copy.encrypted_pairs = back[0].first; copy.proof = back[0].second;
+  ASSERT(copy.encrypted_pairs.c1 == proof.encrypted_pairs.c1 && copy.encrypted_pairs.c2 == proof.encrypted_pairs.c2);
+  ASSERT(serde_json::to_string(copy.proof, ek) == resp);
+  ASSERT(copy.verify(ek, cipher_x).is_ok());
+  NiCorrectKeyProof ck = NiCorrectKeyProof::proof(dk);
+  NiCorrectKeyProof ck2 = serde_json::correct_key_from_str(ek, serde_json::to_string(ck, ek));
+  ASSERT(ck2.sigma_vec == ck.sigma_vec && ck2.verify(ek).is_ok());
+}
+
 // ---- multiplication_proof.rs tests (:172-290)
 static void mul_case(bool honest) {
   auto [ek, dk] = test_keypair().keys();
@@ -290,6 +311,7 @@ static void test_range_proof_correct_proof() { interactive_case(true); }
 static void test_range_proof_incorrect_proof() { interactive_case(false); }
 
 int main() {
+  run("serde_json round trip (EncryptedPairs, Proof, NiCorrectKeyProof)", test_serde_round_trip);
   run("multiplication_proof::test_mul_proof", test_mul_proof);
   run("multiplication_proof::test_bad_mul_proof", test_bad_mul_proof, true);
   run("mod_inv batch", test_mod_inv);

@@ -194,3 +194,14 @@ class Oracle:
         self.lib.oracle_correct_message_verify_batch(C.c_uint32(n_bits), C.c_uint64(B), C.c_uint32(K), p(n), C.c_uint64(n_stride), p(valid), p(ct),
                                                      p(e_vec), p(z_vec), p(a_vec), p(v))
         return v
+
+    # ---- wire format: decimal strings (GMP mpz_set_str / mpz_get_str)
+    def decimal_to_limbs(self, text: bytes, items, dst, out_status):
+        buf = (C.c_char * len(text)).from_buffer_copy(text)
+        self.lib.oracle_decimal_to_limbs_batch(C.cast(buf, C.c_void_p), C.cast(items, C.c_void_p), C.c_uint64(len(items)), p(dst), p(out_status))
+
+    def limbs_to_decimal(self, src, pitch):
+        count, words = src.shape
+        out = np.zeros((count, pitch), np.uint8); ln = np.zeros(count, np.uint32)
+        self.lib.oracle_limbs_to_decimal_batch(p(src), C.c_uint64(words), C.c_uint32(words), C.c_uint64(count), p(out), C.c_uint32(pitch), p(ln))
+        return [bytes(out[i, pitch - ln[i]:]) for i in range(count)]

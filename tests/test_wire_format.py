@@ -1,0 +1,181 @@
+"""Wire format: decimal-string big integers (src/serialize.rs:1-78) and the serde_json documents of
+EncryptedPairs / Proof (range_proof.rs:32-81) and NiCorrectKeyProof (correct_key_ni.rs:35-39).
+CPU: the GMP oracle (mpz_set_str / mpz_get_str = what BigInt::from_str_radix / to_str_radix call) against Python ints.
+GPU: k_dec2bin / k_bin2dec against the oracle byte for byte; JSON ingestion against Python's json + int."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import pm, L, zkp
+
+
+def dec_cases(seed, words):
+    d = pm.Drbg(seed)
+    top = 1 << (32 * words)
+    vals = [0, 1, 9, 10, 10**9 - 1, 10**9, 10**9 + 1, 10**18, 2**32 - 1, 2**32, 2**64, top - 1, top // 10, top // 3]
+    vals += [d.bits(min(int(b), 32 * words)) for b in (1, 31, 32, 33, 63, 64, 65, 500, 1000, 32 * words - 1, 32 * words)]
+    vals += [d.below(top) for _ in range(40)]
+    texts = [str(v).encode() for v in vals]
+    expect = [zkp.DEC_OK] * len(vals)
+    # leading zeros, white space (mpz_set_str ignores it), a sign, empty / malformed strings, overflow
+    extra = [(b"000123", 123, zkp.DEC_OK), (b" 12 34\t5\n", 12345, zkp.DEC_OK), (b"-0", 0, zkp.DEC_OK), (b"-17", 0, zkp.DEC_NEGATIVE),
+             (b"", 0, zkp.DEC_INVALID), (b"-", 0, zkp.DEC_INVALID), (b"12a3", 0, zkp.DEC_INVALID), (b"+5", 0, zkp.DEC_INVALID), (b"1-2", 0, zkp.DEC_INVALID),
+             (b"0x10", 0, zkp.DEC_INVALID), (str(top).encode(), 0, zkp.DEC_OVERFLOW), (str(top * 10**9 + 5).encode(), 0, zkp.DEC_OVERFLOW),
+             (b"0" * 3000 + b"7", 7, zkp.DEC_OK)]
+    for t, v, e in extra:
+        texts.append(t); vals.append(v); expect.append(e)
+    return texts, vals, expect
+
+
+def pack(texts, words, gap=3):
+    """-> (text blob, ctypes DecItem array): strings separated by junk bytes, destinations in reverse order"""
+    blob = bytearray(); items = (zkp.DecItem * len(texts))()
+    for i, t in enumerate(texts):
+        blob += b"#" * gap
+        items[i].text_off = len(blob); items[i].len = len(t); items[i].words = words
+        items[i].dst_off = (len(texts) - 1 - i) * words
+        blob += t
+    return bytes(blob) + b"##", items
+
+
+@pytest.mark.parametrize("words", [8, 64, 128])
+def test_oracle_decimal_matches_python(oracle, words):
+    texts, vals, expect = dec_cases(b"dec-cpu-%d" % words, words)
+    blob, items = pack(texts, words)
+    dst = np.full((len(texts), words), 0xA5A5A5A5, np.uint32); st = np.full(len(texts), 9, np.uint8)
+    oracle.decimal_to_limbs(blob, items, dst, st)
+    assert list(st) == expect
+    for i, v in enumerate(vals):
+        row = dst[len(texts) - 1 - i]
+        assert L.limbs_to_int(row) == (v if expect[i] == zkp.DEC_OK else 0), i
+    ok = [i for i, e in enumerate(expect) if e == zkp.DEC_OK]
+    src = L.ints_to_limbs([vals[i] for i in ok], words)
+    out = oracle.limbs_to_decimal(src, 32 * words * 30103 // 100000 + 2)
+    assert out == [str(vals[i]).encode() for i in ok]
+
+
+# ------------------------------------------------------------------ serde_json documents, as serde_json::to_string writes them
+def pairs_json(c1, c2, pretty=False):
+    doc = {"c1": [str(v) for v in c1], "c2": [str(v) for v in c2]}
+    return (json.dumps(doc, indent=2) if pretty else json.dumps(doc, separators=(",", ":"))).encode()
+
+
+def proof_json(responses, pretty=False):
+    rows = []
+    for r in responses:
+        if r[0] == "open":
+            rows.append({"Open": {"w1": str(r[1]), "r1": str(r[2]), "w2": str(r[3]), "r2": str(r[4])}})
+        else:
+            rows.append({"Mask": {"j": r[1], "masked_x": str(r[2]), "masked_r": str(r[3])}})
+    return (json.dumps(rows, indent=2) if pretty else json.dumps(rows, separators=(",", ":"))).encode()
+
+
+def test_json_fixtures_are_what_the_python_model_reads():
+    """the document writers above produce JSON that round-trips through Python's json to the same integers"""
+    n = H.test_key(512)[2]
+    d = pm.Drbg(b"json-fixture")
+    w1, w2, r1, r2 = pm.sample_range_inputs(d, n, 1 << 255, 4)
+    c1, c2 = pm.generate_encrypted_pairs(n, w1, w2, r1, r2)
+    doc = json.loads(pairs_json(c1, c2, pretty=True))
+    assert [int(s) for s in doc["c1"]] == c1 and list(doc) == ["c1", "c2"]
+    resp = pm.generate_proof(n, 5, 7, b"\xa0", 1 << 255, w1, w2, r1, r2, 4)
+    rows = json.loads(proof_json(resp))
+    assert [list(r)[0] for r in rows] == ["Mask", "Open", "Mask", "Open"]
+
+
+# ================================================================== GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("words", [8, 64, 128, 256])
+def test_gpu_decimal_matches_oracle(ctx, oracle, words):
+    texts, vals, expect = dec_cases(b"dec-gpu-%d" % words, words)
+    blob, items = pack(texts, words)
+    do = np.full((len(texts), words), 0xA5A5A5A5, np.uint32); so = np.full(len(texts), 9, np.uint8)
+    dg = do.copy(); sg = so.copy()
+    oracle.decimal_to_limbs(blob, items, do, so)
+    ctx.decimal_to_limbs(blob, items, dg, sg)
+    assert list(so) == expect and np.array_equal(so, sg) and np.array_equal(do, dg)
+    ok = [i for i, e in enumerate(expect) if e == zkp.DEC_OK]
+    src = L.ints_to_limbs([vals[i] for i in ok], words)
+    assert ctx.limbs_to_decimal(src) == oracle.limbs_to_decimal(src, ctx.decimal_pitch(words)) == [str(vals[i]).encode() for i in ok]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pretty", [False, True])
+def test_gpu_json_ingestion_of_a_proved_batch(ctx, oracle, pretty):
+    """prove with the oracle, write every proof as serde_json text, read it back on the GPU: the SoA batch must be identical
+    and verify to the same verdicts"""
+    n_bits, B, ef = 1024, 6, 128
+    kw = n_bits // 32
+    n = H.test_key(512)[2]
+    cases = H.build_range_case(b"json-gpu", [n], n_bits, B)
+    po, wt = H.fill_batch(cases, n_bits, True, oracle)
+    oracle.range_ni_prove(po.struct(), wt.struct(), None, None, None)
+    pair_docs = [pairs_json([L.limbs_to_int(x) for x in po.c1[b]], [L.limbs_to_int(x) for x in po.c2[b]], pretty) for b in range(B)]
+    proof_docs = [proof_json(H.responses_from_batch(po, b), pretty) for b in range(B)]
+    pg = zkp.RangeBatch(n_bits, B, ef, shared_key=True)
+    pg.n[:] = po.n; pg.range[:] = po.range; pg.ciphertext[:] = po.ciphertext
+    for f in ("c1", "c2", "resp_w1", "resp_r1", "resp_w2", "resp_r2"):
+        getattr(pg, f)[:] = 0xA5A5A5A5
+    pg.resp_kind[:] = 9; pg.resp_j[:] = 9
+    s1 = np.full(B, 9, np.uint8); s2 = np.full(B, 9, np.uint8)
+    ctx.json_encrypted_pairs(pair_docs, pg.struct(), s1, device=False)
+    ctx.json_range_proof(proof_docs, pg.struct(), s2, device=False)
+    assert list(s1) == [0] * B and list(s2) == [0] * B
+    for f in ("c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2"):
+        assert np.array_equal(getattr(po, f), getattr(pg, f)), f
+    v = np.zeros(B, np.uint8)
+    ctx.range_ni_verify(pg.struct(), v, device=False)
+    assert list(v) == [1] * B
+
+
+@pytest.mark.gpu
+def test_gpu_json_malformed_documents(ctx, oracle):
+    n_bits, B, ef = 1024, 8, 4
+    kw = n_bits // 32
+    n = H.test_key(512)[2]
+    d = pm.Drbg(b"json-bad")
+    docs, expect = [], []
+    good_c = [d.below(n * n) for _ in range(ef)]
+    good = pairs_json(good_c, good_c)
+    variants = [good, good.replace(b'"c1"', b'"cx"'), good[:-1], good + b"x", pairs_json(good_c[:3], good_c), pairs_json(good_c + [1], good_c),
+                good.replace(b'["', b'["-', 1), pairs_json([1 << (64 * kw)] + good_c[1:], good_c)]
+    exp = [0, 2, 2, 2, 2, 2, 2, 2]
+    pg = zkp.RangeBatch(n_bits, B, ef, shared_key=True)
+    st = np.full(B, 9, np.uint8)
+    ctx.json_encrypted_pairs(variants, pg.struct(), st, device=False)
+    assert list(st) == exp
+    assert [L.limbs_to_int(x) for x in pg.c1[0]] == good_c
+    assert not pg.c1[1:6].any()                          # nothing of a malformed document is converted
+    assert [L.limbs_to_int(x) for x in pg.c1[6]] == [0] + good_c[1:]   # a number the ABI cannot carry: that entry is zero, the proof is flagged
+    # Proof documents: wrong variant name, j out of u8 range, missing field, key order
+    resp = [("open", 1, 2, 3, 4), ("mask", 2, 5, 6), ("open", 7, 8, 9, 10), ("mask", 1, 11, 12)]
+    g = proof_json(resp)
+    variants = [g, g.replace(b'"Open"', b'"Opem"', 1), g.replace(b'"j":2', b'"j":256'), g.replace(b'"r2":"4"', b'"r3":"4"'),
+                g.replace(b'"w1":"1","r1":"2"', b'"r1":"2","w1":"1"'), proof_json(resp[:3]), g.replace(b'"j":2', b'"j":"2"'), proof_json(resp, pretty=True)]
+    st = np.full(B, 9, np.uint8)
+    ctx.json_range_proof(variants, pg.struct(), st, device=False)
+    assert list(st) == [0, 2, 2, 2, 2, 2, 2, 0]
+    assert list(pg.resp_kind[0]) == [0, 1, 0, 1] and list(pg.resp_j[0]) == [0, 2, 0, 1]
+    assert [L.limbs_to_int(x) for x in pg.resp_w1[7]] == [1, 5, 7, 11] and [L.limbs_to_int(x) for x in pg.resp_w2[7]] == [3, 0, 9, 0]
+
+
+@pytest.mark.gpu
+def test_gpu_json_correct_key_proof(ctx, oracle):
+    n_bits, kw = 1024, 32
+    keys = [H.test_key(1024, tag=t) for t in range(3)]
+    sig = [pm.correct_key_proof(p_, q_, b"KZen") for p_, q_, _ in keys]
+    docs = [json.dumps({"sigma_vec": [str(v) for v in s]}, separators=(",", ":")).encode() for s in sig]
+    docs.append(docs[0].replace(b"sigma_vec", b"sigma"))
+    docs.append(json.dumps({"sigma_vec": [str(v) for v in sig[0][:10]]}).encode())
+    out = np.full((len(docs), 11, kw), 0xA5A5A5A5, np.uint32); st = np.full(len(docs), 9, np.uint8)
+    ctx.json_correct_key_proof(docs, n_bits, out, st)
+    assert list(st) == [0, 0, 0, 2, 2]
+    for b in range(3):
+        assert [L.limbs_to_int(x) for x in out[b]] == sig[b]
+    n_arr = L.ints_to_limbs([k[2] for k in keys], kw)
+    v = np.zeros(3, np.uint8)
+    ctx.correct_key_ni_verify(n_bits, 3, n_arr, np.ascontiguousarray(out[:3]), b"KZen", v)
+    assert list(v) == [1, 1, 1]

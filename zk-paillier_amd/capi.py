@@ -68,6 +68,12 @@ EXPORTS = {
     "zkp_mul_proof_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64] + [C.c_void_p] * 9 + [C.c_uint32]),
     "zkp_correct_message_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64] + [C.c_void_p] * 11 + [C.c_uint32]),
     "zkp_correct_message_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64] + [C.c_void_p] * 6 + [C.c_uint32]),
+    "zkp_decimal_to_limbs_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
+    "zkp_decimal_pitch": (C.c_uint32, [C.c_uint32]),
+    "zkp_limbs_to_decimal_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "zkp_json_encrypted_pairs_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_uint32]),
+    "zkp_json_range_proof_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_uint32]),
+    "zkp_json_correct_key_proof_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_correct_key_ni_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "zkp_dlog_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
@@ -111,6 +117,14 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+class DecItem(C.Structure):
+    """zkp_dec_item (include/zkp_hip.h)"""
+    _fields_ = [("text_off", C.c_uint64), ("dst_off", C.c_uint64), ("len", C.c_uint32), ("words", C.c_uint32)]
+
+
+DEC_OK, DEC_INVALID, DEC_NEGATIVE, DEC_OVERFLOW = 0, 1, 2, 3
 
 
 class ZkpError(RuntimeError):
@@ -269,3 +283,43 @@ class Context:
     def correct_message_verify(self, n_bits, batch, K, n, n_stride, valid, ct, e_vec, z_vec, a_vec, out_verdict):
         arrs = (valid, ct, e_vec, z_vec, a_vec, out_verdict)
         self.check(self.lib.zkp_correct_message_verify_batch(self.h, n_bits, batch, K, ptr(n), n_stride, *[ptr(x) for x in arrs], self._flags(n, *arrs)))
+
+    # ---- wire format: decimal strings <-> limbs, serde_json documents -> SoA batch
+    def decimal_to_limbs(self, text: bytes, items, dst, out_status):
+        """items: ctypes array of DecItem (host); dst / out_status: numpy (host) arrays"""
+        buf = (C.c_char * len(text)).from_buffer_copy(text)
+        self.check(self.lib.zkp_decimal_to_limbs_batch(self.h, C.cast(buf, C.c_void_p), len(text), C.cast(items, C.c_void_p), len(items), ptr(dst),
+                                                       dst.size, ptr(out_status), 0))
+
+    def decimal_pitch(self, words):
+        return self.lib.zkp_decimal_pitch(words)
+
+    def limbs_to_decimal(self, src):
+        """src: numpy [count][words] -> list of decimal strings (bytes)"""
+        count, words = src.shape
+        pitch = self.decimal_pitch(words)
+        out = np.zeros((count, pitch), np.uint8); ln = np.zeros(count, np.uint32)
+        self.check(self.lib.zkp_limbs_to_decimal_batch(self.h, ptr(src), words, words, count, ptr(out), pitch, ptr(ln), 0))
+        return [bytes(out[i, pitch - ln[i]:]) for i in range(count)]
+
+    def _json_docs(self, docs):
+        text = b"".join(docs)
+        off = np.zeros(len(docs), np.uint64); ln = np.array([len(d) for d in docs], np.uint64)
+        off[1:] = np.cumsum(ln)[:-1]
+        buf = (C.c_char * max(len(text), 1)).from_buffer_copy(text or b" ")
+        return buf, off, ln
+
+    def json_encrypted_pairs(self, docs, proofs, out_status, device: bool):
+        buf, off, ln = self._json_docs(docs)
+        self.check(self.lib.zkp_json_encrypted_pairs_batch(self.h, C.cast(buf, C.c_void_p), ptr(off), ptr(ln), C.byref(proofs), ptr(out_status),
+                                                           ZKP_F_DEVICE_PTRS if device else 0))
+
+    def json_range_proof(self, docs, proofs, out_status, device: bool):
+        buf, off, ln = self._json_docs(docs)
+        self.check(self.lib.zkp_json_range_proof_batch(self.h, C.cast(buf, C.c_void_p), ptr(off), ptr(ln), C.byref(proofs), ptr(out_status),
+                                                       ZKP_F_DEVICE_PTRS if device else 0))
+
+    def json_correct_key_proof(self, docs, n_bits, out_sigma, out_status):
+        buf, off, ln = self._json_docs(docs)
+        self.check(self.lib.zkp_json_correct_key_proof_batch(self.h, C.cast(buf, C.c_void_p), ptr(off), ptr(ln), n_bits, len(docs), ptr(out_sigma),
+                                                             ptr(out_status), self._flags(out_sigma, out_status)))

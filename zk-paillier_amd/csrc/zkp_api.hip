@@ -13,6 +13,7 @@
 #include "kernels_modexp.hpp"
 #include "kernels_proofs.hpp"
 #include "kernels_inv.hpp"
+#include "kernels_serde.hpp"
 
 using namespace zkp;
 
@@ -399,3 +400,4 @@ extern "C" int32_t zkp_paillier_enc_batch(zkp_ctx* c, uint32_t n_bits, uint64_t 
 
 #include "zkp_api_proofs.inc"
 #include "zkp_api_mul.inc"
+#include "zkp_api_serde.inc"

@@ -774,4 +774,107 @@ class CorrectMessageProof {
   }
 };
 
+// ------------------------------------------------------------------ wire format (src/serialize.rs + the serde derives)
+// Writers produce what serde_json::to_string produces for the reference's types; readers go through the batched
+// ingestion entry points of the C ABI (decimal strings are converted on the GPU).
+namespace serde_json {
+// BigInt::to_str_radix(10) for many values at once (zkp_limbs_to_decimal_batch)
+inline std::vector<std::string> to_decimal(const std::vector<BigInt>& v, uint32_t words) {
+  Engine& e = Engine::instance();
+  const size_t cnt = v.size();
+  const uint32_t pitch = zkp_decimal_pitch(words);
+  std::vector<uint32_t> src(cnt * words), len(cnt);
+  std::vector<char> txt(cnt * (size_t)pitch);
+  for (size_t i = 0; i < cnt; i++) v[i].to_limbs(&src[i * words], words);
+  if (cnt) e.check(zkp_limbs_to_decimal_batch(e.ctx(), src.data(), words, words, cnt, txt.data(), pitch, len.data(), 0), "zkp_limbs_to_decimal_batch");
+  std::vector<std::string> out;
+  for (size_t i = 0; i < cnt; i++) out.emplace_back(&txt[i * (size_t)pitch + pitch - len[i]], len[i]);
+  return out;
+}
+inline std::string vecbigint(const std::vector<std::string>& d, size_t lo, size_t n) {   // serialize.rs:33-46
+  std::string s = "[";
+  for (size_t i = 0; i < n; i++) { if (i) s += ","; s += "\"" + d[lo + i] + "\""; }
+  return s + "]";
+}
+inline std::string to_string(const EncryptedPairs& p, const EncryptionKey& ek) {          // range_proof.rs:32-39
+  const uint32_t w = 2 * width_for(ek.n) / 32;
+  std::vector<BigInt> all(p.c1); all.insert(all.end(), p.c2.begin(), p.c2.end());
+  auto d = to_decimal(all, w);
+  return "{\"c1\":" + vecbigint(d, 0, p.c1.size()) + ",\"c2\":" + vecbigint(d, p.c1.size(), p.c2.size()) + "}";
+}
+inline std::string to_string(const Proof& p, const EncryptionKey& ek) {                   // range_proof.rs:53-81
+  const uint32_t w = width_for(ek.n) / 32;
+  std::vector<BigInt> all;
+  for (const Response& r : p.responses) {
+    if (r.kind == Response::Open) { all.push_back(r.w1); all.push_back(r.r1); all.push_back(r.w2); all.push_back(r.r2); }
+    else { all.push_back(r.masked_x); all.push_back(r.masked_r); }
+  }
+  auto d = to_decimal(all, w);
+  std::string s = "[";
+  size_t k = 0;
+  for (size_t i = 0; i < p.responses.size(); i++) {
+    const Response& r = p.responses[i];
+    if (i) s += ",";
+    if (r.kind == Response::Open) { s += "{\"Open\":{\"w1\":\"" + d[k] + "\",\"r1\":\"" + d[k + 1] + "\",\"w2\":\"" + d[k + 2] + "\",\"r2\":\"" + d[k + 3] + "\"}}"; k += 4; }
+    else { s += "{\"Mask\":{\"j\":" + std::to_string((unsigned)r.j) + ",\"masked_x\":\"" + d[k] + "\",\"masked_r\":\"" + d[k + 1] + "\"}}"; k += 2; }
+  }
+  return s + "]";
+}
+inline std::string to_string(const NiCorrectKeyProof& p, const EncryptionKey& ek) {       // correct_key_ni.rs:35-39
+  auto d = to_decimal(p.sigma_vec, width_for(ek.n) / 32);
+  return "{\"sigma_vec\":" + vecbigint(d, 0, d.size()) + "}";
+}
+
+// serde_json::from_str for many documents of one shape; an Err (or a value the fixed-width ABI cannot carry) throws
+inline std::vector<std::pair<EncryptedPairs, Proof>> range_from_str(const EncryptionKey& ek, size_t error_factor, const std::vector<std::string>& pairs_docs,
+                                                                    const std::vector<std::string>& proof_docs) {
+  Engine& e = Engine::instance();
+  const uint32_t nb = width_for(ek.n), kw = nb / 32;
+  const size_t B = pairs_docs.size(), EF = error_factor, rows = B * EF;
+  if (proof_docs.size() != B) throw std::invalid_argument("range_from_str: one EncryptedPairs and one Proof document per proof");
+  std::vector<uint32_t> c1(rows * 2 * kw), c2(rows * 2 * kw), w1(rows * kw), r1(rows * kw), w2(rows * kw), r2(rows * kw);
+  std::vector<uint8_t> kind(rows), jj(rows), st1(B), st2(B);
+  zkp_range_ni_proofs p{};
+  p.n_bits = nb; p.error_factor = (uint32_t)EF; p.batch = B; p.c1 = c1.data(); p.c2 = c2.data(); p.resp_kind = kind.data(); p.resp_j = jj.data();
+  p.resp_w1 = w1.data(); p.resp_r1 = r1.data(); p.resp_w2 = w2.data(); p.resp_r2 = r2.data();
+  auto run = [&](const std::vector<std::string>& docs, bool proofs, std::vector<uint8_t>& st) {
+    std::string text; std::vector<uint64_t> off, len;
+    for (auto& d : docs) { off.push_back(text.size()); len.push_back(d.size()); text += d; }
+    if (proofs) e.check(zkp_json_range_proof_batch(e.ctx(), text.data(), off.data(), len.data(), &p, st.data(), 0), "zkp_json_range_proof_batch");
+    else e.check(zkp_json_encrypted_pairs_batch(e.ctx(), text.data(), off.data(), len.data(), &p, st.data(), 0), "zkp_json_encrypted_pairs_batch");
+  };
+  run(pairs_docs, false, st1); run(proof_docs, true, st2);
+  std::vector<std::pair<EncryptedPairs, Proof>> out(B);
+  for (size_t b = 0; b < B; b++) {
+    if (st1[b] || st2[b]) throw std::runtime_error("serde_json: document " + std::to_string(b) + " is not a valid EncryptedPairs / Proof of this width");
+    for (size_t i = 0; i < EF; i++) {
+      const size_t t = b * EF + i;
+      out[b].first.c1.push_back(BigInt::from_limbs(&c1[t * 2 * kw], 2 * kw)); out[b].first.c2.push_back(BigInt::from_limbs(&c2[t * 2 * kw], 2 * kw));
+      Response rs;
+      if (kind[t] == ZKP_RESP_OPEN) {
+        rs.kind = Response::Open;
+        rs.w1 = BigInt::from_limbs(&w1[t * kw], kw); rs.r1 = BigInt::from_limbs(&r1[t * kw], kw); rs.w2 = BigInt::from_limbs(&w2[t * kw], kw); rs.r2 = BigInt::from_limbs(&r2[t * kw], kw);
+      } else {
+        rs.kind = Response::Mask; rs.j = jj[t];
+        rs.masked_x = BigInt::from_limbs(&w1[t * kw], kw); rs.masked_r = BigInt::from_limbs(&r1[t * kw], kw);
+      }
+      out[b].second.responses.push_back(std::move(rs));
+    }
+  }
+  return out;
+}
+inline NiCorrectKeyProof correct_key_from_str(const EncryptionKey& ek, const std::string& doc) {
+  Engine& e = Engine::instance();
+  const uint32_t nb = width_for(ek.n), kw = nb / 32;
+  std::vector<uint32_t> sig(NiCorrectKeyProof::M2 * kw);
+  uint64_t off = 0, len = doc.size();
+  uint8_t st = 9;
+  e.check(zkp_json_correct_key_proof_batch(e.ctx(), doc.data(), &off, &len, nb, 1, sig.data(), &st, 0), "zkp_json_correct_key_proof_batch");
+  if (st) throw std::runtime_error("serde_json: not a NiCorrectKeyProof of this width");
+  NiCorrectKeyProof p;
+  for (size_t i = 0; i < NiCorrectKeyProof::M2; i++) p.sigma_vec.push_back(BigInt::from_limbs(&sig[i * kw], kw));
+  return p;
+}
+}  // namespace serde_json
+
 }  // namespace zkproofs
