@@ -59,16 +59,19 @@ template <int G> __device__ __forceinline__ uint32_t bcast0(uint32_t v) {
   else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x001C);
 }
 
-// lane j receives the value of lane j+1 of its group; the top lane receives 0
+// lane j receives the value of lane j+1 (one DPP move).  The top lane of a group receives the value of the NEXT group's
+// lane 0 (or 0 at the end of a DPP row): inside montmul that value is the low limb of lane 0's finished bottom column,
+// which the quotient digit has just made zero, so no select is needed to clear it (ZKP_SELECT_TOP=1 restores the select).
+#ifndef ZKP_SELECT_TOP
+#define ZKP_SELECT_TOP 0
+#endif
 template <int G> __device__ __forceinline__ uint32_t from_next(uint32_t v, int gl) {
-  if constexpr (G == 16) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
-  } else if constexpr (G == 8 || G == 4) {
-    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);
-    return gl == G - 1 ? 0u : t;
-  } else {
+  if constexpr (G == 32) {
     uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
-    return gl == G - 1 ? 0u : t;
+    return (ZKP_SELECT_TOP && gl == G - 1) ? 0u : t;
+  } else {
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
+    return (ZKP_SELECT_TOP && G != 16 && gl == G - 1) ? 0u : t;
   }
 }
 
