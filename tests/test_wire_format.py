@@ -4,12 +4,15 @@ CPU: the GMP oracle (mpz_set_str / mpz_get_str = what BigInt::from_str_radix / t
 GPU: k_dec2bin / k_bin2dec against the oracle byte for byte; JSON ingestion against Python's json + int."""
 import ctypes as C
 import json
+import sys
 
 import numpy as np
 import pytest
 
 import helpers as H
 from helpers import pm, L, zkp
+
+sys.set_int_max_str_digits(0)   # 512-word values have 4933 decimal digits
 
 
 def dec_cases(seed, words):
@@ -88,7 +91,7 @@ def test_json_fixtures_are_what_the_python_model_reads():
 
 # ================================================================== GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("words", [8, 64, 128, 256])
+@pytest.mark.parametrize("words", [8, 64, 128, 256, 512])
 def test_gpu_decimal_matches_oracle(ctx, oracle, words):
     texts, vals, expect = dec_cases(b"dec-gpu-%d" % words, words)
     blob, items = pack(texts, words)
