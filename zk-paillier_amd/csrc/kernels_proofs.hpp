@@ -430,16 +430,21 @@ __device__ __forceinline__ bool coprime_to_odd(const uint32_t* a, const uint32_t
     return one;
   }
   int nu = kw, nv = kw;             // live word counts (high words that became zero are skipped)
+  // word loops in chunks of CH: every load of a chunk is issued before its first store (u and v may alias as far as the
+  // compiler knows, a plain loop pays one LDS round trip per word); kw is a multiple of CH, words above a live count are zero
+  constexpr int CH = 8;
   for (;;) {
     // make u odd: drop whole zero words, then the remaining trailing zero bits at once
     int zw = 0;
     while (u[zw * stride] == 0) zw++;                 // u != 0 here
     const int zb = __builtin_ctz(u[zw * stride]);
     if (zw | zb) {
-      for (int w = 0; w < nu; w++) {
-        const int s0 = w + zw;
-        const uint32_t lo = s0 < nu ? u[s0 * stride] : 0u, hi = s0 + 1 < nu ? u[(s0 + 1) * stride] : 0u;
-        u[w * stride] = zb ? ((lo >> zb) | (hi << (32 - zb))) : lo;
+      for (int w0 = 0; w0 < nu; w0 += CH) {
+        uint32_t t[CH + 1];
+#pragma unroll
+        for (int k = 0; k <= CH; k++) { const int s0 = w0 + k + zw; t[k] = s0 < kw ? u[s0 * stride] : 0u; }
+#pragma unroll
+        for (int k = 0; k < CH; k++) u[(w0 + k) * stride] = zb ? ((t[k] >> zb) | (t[k + 1] << (32 - zb))) : t[k];
       }
     }
     while (nu > 1 && u[(nu - 1) * stride] == 0) nu--;
@@ -452,11 +457,17 @@ __device__ __forceinline__ bool coprime_to_odd(const uint32_t* a, const uint32_t
     }
     if (cmp == 0) break;            // gcd = u = v
     if (cmp < 0) { uint32_t* t = u; u = v; v = t; const int tn = nu; nu = nv; nv = tn; }
-    uint32_t borrow = 0;            // u -= v  (both odd -> u even, non-zero)
-    for (int w = 0; w < nu; w++) {
-      const uint64_t d = (uint64_t)u[w * stride] - (w < nv ? v[w * stride] : 0u) - borrow;
-      u[w * stride] = (uint32_t)d;
-      borrow = (uint32_t)(d >> 63);
+    uint32_t borrow = 0;            // u -= v  (both odd -> u even, non-zero; nv <= nu)
+    for (int w0 = 0; w0 < nu; w0 += CH) {
+      uint32_t p[CH], q[CH];
+#pragma unroll
+      for (int k = 0; k < CH; k++) { p[k] = u[(w0 + k) * stride]; q[k] = v[(w0 + k) * stride]; }
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
+        u[(w0 + k) * stride] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 63);
+      }
     }
   }
   bool one = v[0] == 1;
