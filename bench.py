@@ -204,6 +204,20 @@ def main():
         g = torch.Generator(device=dev); g.manual_seed(99 + rank)
         def rnd(shape):
             return torch.randint(-2**31, 2**31 - 1, shape, dtype=torch.int32, device=dev, generator=g)
+        # configs[0]: the reference's own bench shape (benches/all.rs:55-77): ONE proof under the fixture key, host buffers in
+        # and out (what a caller of the crate sees: staging and PCIe included); prove and verify timed separately
+        pb1 = pb.slice(0, 1).to(None); wt1 = wt.slice(0, 1).to(None)
+        if True:
+            v1 = np.zeros(1, np.uint8)
+            ctx.range_ni_prove(pb1.struct(), wt1.struct(), None, None, None, device=False)      # warm-up
+            t0 = time.perf_counter()
+            ctx.range_ni_prove(pb1.struct(), wt1.struct(), None, None, None, device=False)
+            t1 = time.perf_counter()
+            ctx.range_ni_verify(pb1.struct(), v1, device=False)
+            t2 = time.perf_counter()
+            ok = ok and bool(v1[0] == 1)
+            other["configs[0] one RangeProofNi, n=2048, host buffers (latency)"] = {
+                "prove_ms": 1e3 * (t1 - t0), "verify_ms": 1e3 * (t2 - t1), "prove_plus_verify_ms": 1e3 * (t2 - t0), "accepted": bool(v1[0] == 1)}
         # configs[3]: 65536 NiCorrectKeyProof verifies, n = 2048, 65536 distinct (pseudo-)moduli: pure throughput shape,
         # every record is expected to be rejected (random sigma); accept parity is covered by tests/test_gpu_fullsize.py
         Bk, kwk = 65536, 64

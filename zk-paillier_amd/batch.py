@@ -89,6 +89,14 @@ class RangeWitness:
             setattr(s, f, capi.ptr(getattr(self, f)))
         return s
 
+    def slice(self, lo, hi):
+        out = RangeWitness.__new__(RangeWitness)
+        out.__dict__.update(self.__dict__)
+        out.batch = hi - lo
+        for f in _WIT_FIELDS:
+            setattr(out, f, getattr(self, f)[lo:hi])
+        return out
+
     def to(self, device):
         out = RangeWitness.__new__(RangeWitness)
         out.__dict__.update(self.__dict__)
