@@ -14,6 +14,8 @@ MALFORMED = zkp.VERDICT_MALFORMED
 def inv_cases(mod, kw, seed, count):
     d = pm.Drbg(seed)
     vals = [0, 1, 2, mod - 1, mod - 2, (mod + 1) // 2, 1 << 31, 1 << 32, (1 << 64) - 1, 1 << (mod.bit_length() - 1)]
+    # a == M modulo 2^32 / 2^64 / 2^96: the first difference has whole zero low words (the unfused path of k_modinv)
+    vals += [mod - (3 << 32), mod - (5 << 64), mod - (7 << 96), mod - (d.below(1 << 200) << 64)]
     vals += [d.below(mod) for _ in range(count - len(vals))]
     return vals
 

@@ -12,7 +12,8 @@ namespace zkp {
 // Right-shift binary extended GCD with the cofactors kept modulo M:
 //   invariants u == x*a, v == y*a (mod M); u loses its trailing zero bits z at a time and x is divided by 2^z
 //   modulo M in ONE multiply-accumulate pass (x + ((x0 * -M^-1) mod 2^z) * M is divisible by 2^z); then the larger
-//   of (u, v) is reduced by the other.  gcd = v at the end; the inverse is y when gcd == 1.
+//   of (u, v) is reduced by the other — subtraction and the following shift fused into one pass per operand pair.
+//   gcd = v at the end; the inverse is y when gcd == 1.
 // u, v, x, y and a copy of M live in thread-interleaved LDS (word w of lane t at base[w * LANES + t]: conflict-free).  Data-dependent trip counts: lanes
 // of a wavefront wait for the slowest one.
 struct ModinvArgs {
@@ -110,38 +111,91 @@ __global__ void __launch_bounds__(64) k_modinv(ModinvArgs a) {
       t = x; x = y; y = t;
       const int tn = nu; nu = nv; nv = tn;
     }
-    uint32_t borrow = 0;                              // u -= v (both odd: the difference is even and not zero; nv <= nu)
-    for (int w0 = 0; w0 < nu; w0 += CH) {
-      uint32_t p[CH], q[CH];
-#pragma unroll
-      for (int k = 0; k < CH; k++) { p[k] = u[(w0 + k) * S]; q[k] = v[(w0 + k) * S]; }
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
-        u[(w0 + k) * S] = (uint32_t)d;
-        borrow = (uint32_t)(d >> 63);
-      }
-    }
-    // x = (x - y) mod M: x < y is decided from the top first, then ONE pass computes x - y (+ M)
+    // x < y is decided from the top first: x - y needs + M exactly then
     int lt = 0;
     for (int w = kw - 1; lt == 0 && w >= 0; w--) {
       const uint32_t p = x[w * S], q = y[w * S];
       if (p != q) lt = p < q ? 1 : -1;
     }
     const uint32_t addm = lt > 0 ? 0xFFFFFFFFu : 0u;
-    uint32_t cy = 0;
-    borrow = 0;
-    for (int w0 = 0; w0 < kw; w0 += CH) {
-      uint32_t p[CH], q[CH], m[CH];
+    // u - v is even; when its trailing zeros all sit in the low word (always, up to a 2^-32 chance) the subtraction and the
+    // next round's shift are ONE pass over u, and x = (x - y mod M) / 2^z mod M is ONE pass over x with three carry chains
+    const uint32_t d0 = u[0] - v[0];
+    const int z = d0 ? __builtin_ctz(d0) : 0;
+    uint32_t borrow = 0;
+    if (z) {
+      uint32_t prev = 0;
+      for (int w0 = 0; w0 < nu; w0 += CH) {           // u = (u - v) >> z   (nv <= nu)
+        uint32_t p[CH], q[CH], d[CH];
 #pragma unroll
-      for (int k = 0; k < CH; k++) { p[k] = x[(w0 + k) * S]; q[k] = y[(w0 + k) * S]; m[k] = Ml[(w0 + k) * S] & addm; }
+        for (int k = 0; k < CH; k++) { p[k] = u[(w0 + k) * S]; q[k] = v[(w0 + k) * S]; }
 #pragma unroll
-      for (int k = 0; k < CH; k++) {
-        const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
-        borrow = (uint32_t)(d >> 63);
-        const uint64_t sm = (uint64_t)(uint32_t)d + m[k] + cy;
-        cy = (uint32_t)(sm >> 32);
-        x[(w0 + k) * S] = (uint32_t)sm;
+        for (int k = 0; k < CH; k++) {
+          const uint64_t t = (uint64_t)p[k] - q[k] - borrow;
+          d[k] = (uint32_t)t;
+          borrow = (uint32_t)(t >> 63);
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const uint32_t below = k ? d[k - 1] : prev;
+          if (w0 + k > 0) u[(w0 + k - 1) * S] = (below >> z) | (d[k] << (32 - z));
+        }
+        prev = d[CH - 1];
+      }
+      u[(((nu + CH - 1) / CH) * CH - 1) * S] = prev >> z;
+      const uint32_t x0 = x[0] - y[0] + (Ml[0] & addm);
+      const uint32_t t = (x0 * minv) & ((1u << z) - 1);
+      uint32_t cy = 0;
+      uint64_t carry = 0;
+      borrow = 0; prev = 0;
+      for (int w0 = 0; w0 < kw; w0 += CH) {           // x = ((x - y + [M]) + t * M) >> z
+        uint32_t p[CH], q[CH], m[CH], lo[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { p[k] = x[(w0 + k) * S]; q[k] = y[(w0 + k) * S]; m[k] = Ml[(w0 + k) * S]; }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
+          borrow = (uint32_t)(d >> 63);
+          const uint64_t sm = (uint64_t)(uint32_t)d + (m[k] & addm) + cy;
+          cy = (uint32_t)(sm >> 32);
+          const uint64_t acc = (uint64_t)t * m[k] + (uint32_t)sm + carry;
+          lo[k] = (uint32_t)acc;
+          carry = acc >> 32;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const uint32_t below = k ? lo[k - 1] : prev;
+          if (w0 + k > 0) x[(w0 + k - 1) * S] = (below >> z) | (lo[k] << (32 - z));
+        }
+        prev = lo[CH - 1];
+      }
+      x[(kw - 1) * S] = (prev >> z) | ((uint32_t)carry << (32 - z));
+    } else {
+      for (int w0 = 0; w0 < nu; w0 += CH) {           // u -= v; the zero words are stripped at the top of the loop
+        uint32_t p[CH], q[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { p[k] = u[(w0 + k) * S]; q[k] = v[(w0 + k) * S]; }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
+          u[(w0 + k) * S] = (uint32_t)d;
+          borrow = (uint32_t)(d >> 63);
+        }
+      }
+      uint32_t cy = 0;
+      borrow = 0;
+      for (int w0 = 0; w0 < kw; w0 += CH) {           // x = x - y (+ M)
+        uint32_t p[CH], q[CH], m[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { p[k] = x[(w0 + k) * S]; q[k] = y[(w0 + k) * S]; m[k] = Ml[(w0 + k) * S] & addm; }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
+          borrow = (uint32_t)(d >> 63);
+          const uint64_t sm = (uint64_t)(uint32_t)d + m[k] + cy;
+          cy = (uint32_t)(sm >> 32);
+          x[(w0 + k) * S] = (uint32_t)sm;
+        }
       }
     }
   }
