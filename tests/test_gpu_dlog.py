@@ -40,6 +40,10 @@ def test_dlog_matches_oracle(ctx, oracle, n_bits):
     rows.append((N, rows[0][1], q * 3, rows[0][3], d.bits(512)))          # gcd(ni, N) != 1 (:73)
     rows.append(((1 << 128) - 159, 5, 7, 3, d.bits(512)))                 # N <= 2^128 (:69)
     rows.append((N, 0, rows[0][2], rows[0][3], d.bits(512)))              # g = 0: gcd(0, N) = N
+    # g == N modulo 2^64 (and a multiple of p next to it): the first difference of the binary GCD has zero low words
+    g_z = N - (d.bits(300) << 64); s_z = d.bits(256)
+    rows.append((N, g_z, pow(pow(g_z, -1, N), s_z, N), s_z, d.bits(512)))
+    rows.append((N, N - (p << 96), rows[0][2], rows[0][3], d.bits(512)))
     B = len(rows)
     N_, g_, ni_ = (L.ints_to_limbs([r[i] for r in rows], kw) for i in range(3))
     s_ = L.ints_to_limbs([r[3] for r in rows], 8); r_ = L.ints_to_limbs([r[4] for r in rows], 16)

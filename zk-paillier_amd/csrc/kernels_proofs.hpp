@@ -457,18 +457,34 @@ __device__ __forceinline__ bool coprime_to_odd(const uint32_t* a, const uint32_t
     }
     if (cmp == 0) break;            // gcd = u = v
     if (cmp < 0) { uint32_t* t = u; u = v; v = t; const int tn = nu; nu = nv; nv = tn; }
-    uint32_t borrow = 0;            // u -= v  (both odd -> u even, non-zero; nv <= nu)
+    // u -= v (both odd -> u even, non-zero; nv <= nu).  When the trailing zeros of the difference all sit in its low word
+    // (always, up to a 2^-32 chance) the subtraction and the next round's shift are one pass.
+    const uint32_t d0 = u[0] - v[0];
+    const int z = d0 ? __builtin_ctz(d0) : 0;
+    uint32_t borrow = 0, prev = 0;
     for (int w0 = 0; w0 < nu; w0 += CH) {
-      uint32_t p[CH], q[CH];
+      uint32_t p[CH], q[CH], d[CH];
 #pragma unroll
       for (int k = 0; k < CH; k++) { p[k] = u[(w0 + k) * stride]; q[k] = v[(w0 + k) * stride]; }
 #pragma unroll
       for (int k = 0; k < CH; k++) {
-        const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
-        u[(w0 + k) * stride] = (uint32_t)d;
-        borrow = (uint32_t)(d >> 63);
+        const uint64_t t = (uint64_t)p[k] - q[k] - borrow;
+        d[k] = (uint32_t)t;
+        borrow = (uint32_t)(t >> 63);
+      }
+      if (z) {
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const uint32_t below = k ? d[k - 1] : prev;
+          if (w0 + k > 0) u[(w0 + k - 1) * stride] = (below >> z) | (d[k] << (32 - z));
+        }
+        prev = d[CH - 1];
+      } else {
+#pragma unroll
+        for (int k = 0; k < CH; k++) u[(w0 + k) * stride] = d[k];
       }
     }
+    if (z) u[(((nu + CH - 1) / CH) * CH - 1) * stride] = prev >> z;
   }
   bool one = v[0] == 1;
   for (int w = 1; w < nv; w++) one = one && v[w * stride] == 0;
