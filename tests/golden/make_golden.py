@@ -143,9 +143,67 @@ def dlog():
     return out
 
 
+def next_rows():
+    """mod_inv, MulProof, CorrectMessageProof, ZeroProof / CiphertextProof, decimal wire format.
+    Small enough (n = 1024) for every value to be stored in full and recomputed by the pure-Python model."""
+    p, q, n = H.test_key(1024, tag=0)
+    nn = n * n
+    d = pm.Drbg(b"golden-next")
+    out = {"n": hx(n), "p": hx(p)}
+    # mod_inv mod n^2
+    vals = [3, d.below(nn), nn - 1, p, 0, d.below(1 << 64) << 128]
+    o, st = oracle.modinv(2048, L.ints_to_limbs(vals, 64), L.int_to_limbs(nn, 64)[None, :], 0)
+    inv = []
+    for v, r, s_ in zip(vals, L.limbs_to_ints(o), st):
+        e = pm.mod_inv(v, nn)
+        assert (e is None and s_ == zkp.INV_NONE and r == 0) or (e == r and s_ == zkp.INV_OK)
+        inv.append(dict(a=hx(v), inv=hx(r), status=int(s_)))
+    out["mod_inv"] = inv
+    # MulProof: honest, false statement
+    mul = []
+    for honest in (True, False):
+        a, b = d.below(n), d.below(n)
+        c = a * b % n if honest else (a * b + 1) % n
+        r_a, r_b, r_c, dd, r_d = (d.below(n) for _ in range(5))
+        e_a, e_b, e_c = pm.enc(n, a, r_a), pm.enc(n, b, r_b), pm.enc(n, c, r_c)
+        f, z1, z2, e_d, e_db = pm.mul_proof_prove(n, e_a, e_b, e_c, a, b, r_a, r_b, r_c, dd, r_d)
+        A = lambda v, w: L.ints_to_limbs([v], w)
+        of, oz1, oz2, oed, oedb, ost = oracle.mul_proof_prove(1024, A(n, 32), 0, A(e_a, 64), A(e_b, 64), A(e_c, 64), A(a, 32), A(b, 32), A(r_a, 32),
+                                                              A(r_b, 32), A(r_c, 32), A(dd, 32), A(r_d, 32))
+        assert [L.limbs_to_int(x[0]) for x in (of, oz1, oz2, oed, oedb)] == [f, z1, z2, e_d, e_db] and ost[0] == 0
+        v = int(oracle.mul_proof_verify(1024, A(n, 32), 0, A(e_a, 64), A(e_b, 64), A(e_c, 64), of, oz1, oz2, oed, oedb)[0])
+        assert (v == 1) == pm.mul_proof_verify(n, e_a, e_b, e_c, f, z1, z2, e_d, e_db) == honest
+        mul.append(dict(honest=honest, a=hx(a), b=hx(b), c=hx(c), r_a=hx(r_a), r_b=hx(r_b), r_c=hx(r_c), d=hx(dd), r_d=hx(r_d),
+                        e_a=hx(e_a), e_b=hx(e_b), e_c=hx(e_c), f=hx(f), z1=hx(z1), z2=hx(z2), e_d=hx(e_d), e_db=hx(e_db), verdict=v))
+    out["mul_proof"] = mul
+    # CorrectMessageProof, K = 4 as in the reference test (valid messages 3,4,5,6; message 4)
+    valid = [3, 4, 5, 6]
+    r, w = d.below(n), d.below(n)
+    e_sim = [d.bits(256) for _ in range(3)]; z_sim = [d.below(n) for _ in range(3)]
+    ct, e_vec, z_vec, a_vec = pm.correct_message_prove(n, valid, 4, r, e_sim, z_sim, w)
+    assert pm.correct_message_verify(n, valid, ct, e_vec, z_vec, a_vec)
+    octx = oracle.correct_message_prove(1024, 4, L.ints_to_limbs([n], 32), 0, L.ints_to_limbs(valid, 32)[None], L.ints_to_limbs([4], 32), L.ints_to_limbs([r], 32),
+                                        L.ints_to_limbs(e_sim, 8)[None], L.ints_to_limbs(z_sim, 32)[None], L.ints_to_limbs([w], 32))
+    assert L.limbs_to_int(octx[0][0]) == ct and L.limbs_to_ints(octx[3][0]) == a_vec and octx[4][0] == 0
+    out["correct_message"] = dict(valid=valid, message=4, r=hx(r), w=hx(w), e_sim=[hx(v) for v in e_sim], z_sim=[hx(v) for v in z_sim],
+                                  ciphertext=hx(ct), e_vec=[hx(v) for v in e_vec], z_vec=[hx(v) for v in z_vec], a_vec=[hx(v) for v in a_vec], verdict=1)
+    # ZeroProof / CiphertextProof
+    x, rr, xp, rp = d.below(n), d.below(n), d.below(n), d.below(n)
+    c0, cx = pm.enc(n, 0, rr), pm.enc(n, x, rr)
+    z, a_ = pm.zero_proof_prove(n, c0, rr, rp)
+    z1, z2, cp = pm.ciphertext_proof_prove(n, cx, x, rr, xp, rp)
+    assert pm.zero_proof_verify(n, c0, z, a_) and pm.ciphertext_proof_verify(n, cx, z1, z2, cp)
+    out["sigma"] = dict(x=hx(x), r=hx(rr), x_prime=hx(xp), r_prime=hx(rp), c0=hx(c0), cx=hx(cx), zero_z=hx(z), zero_a=hx(a_),
+                        ct_z1=hx(z1), ct_z2=hx(z2), ct_c_prime=hx(cp))
+    # wire format: decimal strings as serialize.rs writes them, with the limbs they must convert to
+    wire = [0, 1, 10**9, 10**18 + 7, d.bits(2048), nn - 1]
+    out["decimal"] = [dict(text=str(v), hex=hx(v)) for v in wire]
+    return out
+
+
 def main():
     files = dict(modexp_kat=modexp_kats(), enc_kat=enc_kats(), digest_kat=digest_kats(), range_ni_transcripts=range_transcripts(),
-                 correct_key_ni=correct_key(), dlog=dlog())
+                 correct_key_ni=correct_key(), dlog=dlog(), next_rows=next_rows())
     for name, obj in files.items():
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(obj, f, indent=1)

@@ -177,3 +177,87 @@ def test_gpu_correct_key_goldens(ctx, oracle):
         v = np.full(2, 9, np.uint8)
         ctx.correct_key_ni_verify(2048, 2, np.stack([nl, nl]), np.stack([sg, bad]), salt, v)
         assert list(v) == [g["verdict"], g["verdict_tampered_sigma5"]]
+
+
+# ------------------------------------------------------------------ SURVEY 8(f) rows (next_rows.json): one replay, two back ends
+class _OracleBackend:
+    """adapter: the same calls as zkp.Context, answered by the oracle"""
+    def __init__(self, o): self.o = o
+    def modinv(self, bits, cnt, a, m, ms, out, st): o, s = self.o.modinv(bits, a, m, ms); out[:] = o; st[:] = s
+    def mul_proof_prove(self, nb, B, n, ns, e_a, e_b, e_c, a, b, r_a, r_b, r_c, d, r_d, f, z1, z2, e_d, e_db, st):
+        r = self.o.mul_proof_prove(nb, n, ns, e_a, e_b, e_c, a, b, r_a, r_b, r_c, d, r_d)
+        for dst, src in zip((f, z1, z2, e_d, e_db, st), r): dst[:] = src
+    def mul_proof_verify(self, nb, B, n, ns, e_a, e_b, e_c, f, z1, z2, e_d, e_db, v): v[:] = self.o.mul_proof_verify(nb, n, ns, e_a, e_b, e_c, f, z1, z2, e_d, e_db)
+    def correct_message_prove(self, nb, B, K, n, ns, valid, msg, r, es, zs, w, ct, ev, zv, av, st):
+        res = self.o.correct_message_prove(nb, K, n, ns, valid, msg, r, es, zs, w)
+        for dst, src in zip((ct, ev, zv, av, st), res): dst[:] = src
+    def correct_message_verify(self, nb, B, K, n, ns, valid, ct, ev, zv, av, v): v[:] = self.o.correct_message_verify(nb, K, n, ns, valid, ct, ev, zv, av)
+    def zero_proof_prove(self, nb, B, n, ns, c, r, rp, z, a): zz, aa = self.o.zero_proof_prove(nb, n, ns, c, r, rp); z[:] = zz; a[:] = aa
+    def ciphertext_proof_prove(self, nb, B, n, ns, c, x, r, xp, rp, z1, z2, cp):
+        a, b, c_ = self.o.ciphertext_proof_prove(nb, n, ns, c, x, r, xp, rp); z1[:] = a; z2[:] = b; cp[:] = c_
+    def decimal_to_limbs(self, text, items, dst, st): self.o.decimal_to_limbs(text, items, dst, st)
+    def limbs_to_decimal(self, src): return self.o.limbs_to_decimal(src, 32 * src.shape[1] * 30103 // 100000 + 2)
+
+
+def replay_next_rows(be):
+    g = load("next_rows")
+    n = iv(g["n"]); kw = 32
+    A = lambda v, w: L.ints_to_limbs([v] if isinstance(v, int) else v, w)
+    nl = A(n, kw)
+    # mod_inv
+    vals = [iv(k["a"]) for k in g["mod_inv"]]
+    out = np.full((len(vals), 64), 7, np.uint32); st = np.full(len(vals), 9, np.uint8)
+    be.modinv(2048, len(vals), A(vals, 64), A(n * n, 64), 0, out, st)
+    assert [format(v, "x") for v in L.limbs_to_ints(out)] == [k["inv"] for k in g["mod_inv"]] and list(st) == [k["status"] for k in g["mod_inv"]]
+    # MulProof
+    for k in g["mul_proof"]:
+        ins = [A(iv(k[f]), 64 if f.startswith("e_") else kw) for f in ("e_a", "e_b", "e_c", "a", "b", "r_a", "r_b", "r_c", "d", "r_d")]
+        f = np.zeros((1, kw), np.uint32); z1, z2, e_d, e_db = (np.zeros((1, 64), np.uint32) for _ in range(4)); s1 = np.full(1, 9, np.uint8)
+        be.mul_proof_prove(1024, 1, nl, 0, *ins, f, z1, z2, e_d, e_db, s1)
+        assert [format(L.limbs_to_int(x[0]), "x") for x in (f, z1, z2, e_d, e_db)] == [k[q] for q in ("f", "z1", "z2", "e_d", "e_db")] and s1[0] == 0
+        v = np.full(1, 9, np.uint8)
+        be.mul_proof_verify(1024, 1, nl, 0, ins[0], ins[1], ins[2], f, z1, z2, e_d, e_db, v)
+        assert int(v[0]) == k["verdict"]
+    # CorrectMessageProof
+    c = g["correct_message"]
+    K = len(c["valid"])
+    ct = np.zeros((1, 64), np.uint32); ev = np.zeros((1, K, 8), np.uint32); zv = np.zeros((1, K, kw), np.uint32); av = np.zeros((1, K, 64), np.uint32)
+    s1 = np.full(1, 9, np.uint8)
+    valid = A(c["valid"], kw)[None]
+    be.correct_message_prove(1024, 1, K, nl, 0, valid, A(c["message"], kw), A(iv(c["r"]), kw), A([iv(v) for v in c["e_sim"]], 8)[None],
+                             A([iv(v) for v in c["z_sim"]], kw)[None], A(iv(c["w"]), kw), ct, ev, zv, av, s1)
+    assert format(L.limbs_to_int(ct[0]), "x") == c["ciphertext"] and s1[0] == 0
+    for arr, key in ((ev, "e_vec"), (zv, "z_vec"), (av, "a_vec")):
+        assert [format(v, "x") for v in L.limbs_to_ints(arr[0])] == c[key], key
+    v = np.full(1, 9, np.uint8)
+    be.correct_message_verify(1024, 1, K, nl, 0, valid, ct, ev, zv, av, v)
+    assert int(v[0]) == c["verdict"]
+    # ZeroProof / CiphertextProof provers
+    s = g["sigma"]
+    z = np.zeros((1, 64), np.uint32); a_ = np.zeros((1, 64), np.uint32)
+    be.zero_proof_prove(1024, 1, nl, 0, A(iv(s["c0"]), 64), A(iv(s["r"]), kw), A(iv(s["r_prime"]), kw), z, a_)
+    assert format(L.limbs_to_int(z[0]), "x") == s["zero_z"] and format(L.limbs_to_int(a_[0]), "x") == s["zero_a"]
+    z1 = np.zeros((1, kw + 16), np.uint32); z2 = np.zeros((1, 64), np.uint32); cp = np.zeros((1, 64), np.uint32)
+    be.ciphertext_proof_prove(1024, 1, nl, 0, A(iv(s["cx"]), 64), A(iv(s["x"]), kw), A(iv(s["r"]), kw), A(iv(s["x_prime"]), kw), A(iv(s["r_prime"]), kw), z1, z2, cp)
+    assert [format(L.limbs_to_int(q[0]), "x") for q in (z1, z2, cp)] == [s["ct_z1"], s["ct_z2"], s["ct_c_prime"]]
+    # decimal wire format, both directions
+    texts = [k["text"].encode() for k in g["decimal"]]
+    blob = b",".join(texts)
+    items = (zkp.DecItem * len(texts))()
+    pos = 0
+    for i, t in enumerate(texts):
+        items[i].text_off = pos; items[i].len = len(t); items[i].words = 64; items[i].dst_off = i * 64
+        pos += len(t) + 1
+    dst = np.full((len(texts), 64), 7, np.uint32); st = np.full(len(texts), 9, np.uint8)
+    be.decimal_to_limbs(blob, items, dst, st)
+    assert [format(v, "x") for v in L.limbs_to_ints(dst)] == [k["hex"] for k in g["decimal"]] and not st.any()
+    assert be.limbs_to_decimal(dst) == texts
+
+
+def test_oracle_next_rows_goldens(oracle):
+    replay_next_rows(_OracleBackend(oracle))
+
+
+@pytest.mark.gpu
+def test_gpu_next_rows_goldens(ctx):
+    replay_next_rows(ctx)
