@@ -199,7 +199,7 @@ def main():
 
     # ---- short legs for the other BASELINE.json configurations (rank-local, reported per GPU; not part of `value`)
     other = None
-    if not args.no_other_configs:
+    if not args.no_other_configs and world == 1:      # single-GPU shapes: reported at N=1 only
         other = {}
         g = torch.Generator(device=dev); g.manual_seed(99 + rank)
         def rnd(shape):
