@@ -99,7 +99,7 @@ template <int G> __device__ __forceinline__ void load_value(const Grp<G>& g, uin
 // Exact canonical residue of a Montgomery-domain-free value x <= M (limbs almost normalised):
 // normalise exactly, convert to NW words in LDS words(), and map x == M to 0.
 // Afterwards words()[0..NW) holds the canonical value (visible to the whole group).
-template <int G> __device__ __forceinline__ void canonical_words(const Grp<G>& g, uint32_t (&x)[W], const uint32_t* cstN /*global N29*/) {
+template <int G> __device__ __forceinline__ void canonical_words(const Grp<G>& g, uint32_t (&x)[W], const uint32_t* /*cstN: global N29, unused (g.N holds it)*/) {
   constexpr int NW = LdsLayout<G>::NW;
   normalize_exact<G>(x, g.gl);
   // x == M ?  (x <= M is guaranteed by the caller: x = montmul(., 1))
@@ -418,7 +418,7 @@ template <int G>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
-  constexpr int L = Geo<G>::L, NW = LL::NW;
+  constexpr int L = Geo<G>::L;
   extern __shared__ __align__(16) uint32_t lds_raw[];
   Grp<G> g;
   grp_init<G>(g, lds_raw);
@@ -467,7 +467,6 @@ template <int G>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_modmul(ModmulArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
-  constexpr int NW = LL::NW;
   extern __shared__ __align__(16) uint32_t lds_raw[];
   Grp<G> g;
   grp_init<G>(g, lds_raw);

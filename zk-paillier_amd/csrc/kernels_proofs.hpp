@@ -338,7 +338,7 @@ template <int G>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
-  constexpr int L = Geo<G>::L, NW = LL::NW;
+  constexpr int L = Geo<G>::L;
   extern __shared__ __align__(16) uint32_t lds_raw[];
   Grp<G> g;
   grp_init<G>(g, lds_raw);

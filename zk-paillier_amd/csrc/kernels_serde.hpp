@@ -33,14 +33,13 @@ __global__ void __launch_bounds__(SERDE_LANES) k_dec2bin(const char* __restrict_
     const uint32_t len = it.len;
     int n_live = 0;
     uint32_t group = 0, mult = 1;
-    int ndig = 0;
     bool neg = false, seen = false;
     for (uint32_t p = 0; p <= len && st == ZKP_DEC_OK; p++) {
       bool flush = p == len;
       if (!flush) {
         const char ch = s[p];
         if (ch >= '0' && ch <= '9') {
-          group = group * 10u + (uint32_t)(ch - '0'); mult *= 10u; ndig++; seen = true;
+          group = group * 10u + (uint32_t)(ch - '0'); mult *= 10u; seen = true;
           flush = mult == 1000000000u;
         } else if (ch == ' ' || (ch >= '\t' && ch <= '\r')) {
           continue;
