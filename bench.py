@@ -253,7 +253,7 @@ def main():
         del pb5, wt5
 
     if rank == 0:
-        out = {"metric": "RangeProofNi verifies/sec, n=2048, batch=4096 per GPU", "value": value, "unit": "verifies/s",
+        out = {"metric": "RangeProofNi proofs/sec + verifies/sec, n=2048, batch=4096 per GPU (value = verifies/sec; proofs/sec in prove.value)", "value": value, "unit": "verifies/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs, u64 accumulate)",
                "data": "synthetic", "verdicts_ok": ok,
