@@ -66,6 +66,13 @@ struct Stage {
   std::vector<Out> outs;
   int32_t st = ZKP_OK;
   Stage(zkp_ctx* c_, uint32_t flags) : c(c_), dev((flags & ZKP_F_DEVICE_PTRS) != 0) {}
+  Stage(const Stage&) = delete;
+  Stage& operator=(const Stage&) = delete;
+  ~Stage() {                       // an error return that skipped finish(): nothing is copied back, the staging memory is released
+    if (owned.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (void* p : owned) (void)hipFree(p);
+  }
   template <class T> const T* in(const T* p, size_t count) {
     if (dev || !p || st) return p;
     void* d = nullptr;
