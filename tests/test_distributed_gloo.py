@@ -42,10 +42,19 @@ def _worker(rank, world, port, n_bits, B, ret):
     counts = [shard.shard_range(B, world, r)[1] - shard.shard_range(B, world, r)[0] for r in range(world)]
     c1 = shard.all_gather_slabs(torch.from_numpy(pb.c1[lo:hi].view(np.int32)), world, counts)
     ok_c1 = bool(np.array_equal(c1.numpy().view(np.uint32), pb.c1))
+    # BASELINE configs[3]: NiCorrectKeyProof verification sharded by key index through the same helper
+    from helpers import pm, L
+    keys = [H.test_key(512, tag=t) for t in range(5)]
+    n_arr = L.ints_to_limbs([k[2] for k in keys], 32)
+    sig = np.stack([L.ints_to_limbs(pm.correct_key_proof(k[0], k[1], b"KZen"), 32) for k in keys])
+    sig[3, 7, 0] ^= 1                                    # one tampered proof
+    ck = shard.sharded_verify(lambda sl: torch.from_numpy(oracle.correct_key_ni_verify(1024, n_arr[sl], np.ascontiguousarray(sig[sl]), b"KZen")),
+                              len(keys), world, rank, lambda lo, hi: slice(lo, hi))
     if rank == 0:
         full = np.zeros(B, np.uint8)
         oracle.range_ni_verify(pb.struct(), full)
-        ret.put((out.numpy().tolist(), full.tolist(), ok_c1))
+        ck_full = oracle.correct_key_ni_verify(1024, n_arr, sig, b"KZen")
+        ret.put((out.numpy().tolist(), full.tolist(), ok_c1 and ck.numpy().tolist() == ck_full.tolist() == [1, 1, 1, 0, 1]))
     dist.barrier()
     dist.destroy_process_group()
 
