@@ -68,6 +68,9 @@ int32_t zkp_build_limbs_per_lane(void);           /* compile-time W of the kerne
 const char* zkp_last_error_string(zkp_ctx* ctx);  /* valid until the next call on ctx */
 void* zkp_ctx_stream(zkp_ctx* ctx);               /* the hipStream_t every launch uses */
 int32_t zkp_ctx_synchronize(zkp_ctx* ctx);
+/* Host-pointer calls stage their buffers through device blocks the ctx keeps between calls (no hipMalloc / hipFree per
+ * call once warm).  This frees the cached blocks (zkp_ctx_destroy does so too). */
+int32_t zkp_ctx_release_staging(zkp_ctx* ctx);
 
 /* Kernel timing of the dominant (modexp) kernels, measured with HIP events on the ctx
  * stream.  zkp_timing_reset clears the accumulators and arms event recording;
@@ -98,6 +101,18 @@ int32_t zkp_modmul_batch(zkp_ctx* ctx, uint32_t mod_bits, uint64_t count, const 
 int32_t zkp_paillier_enc_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t count, const uint32_t* n,
                                uint64_t n_stride, const uint32_t* m, const uint32_t* r,
                                uint32_t* out_c, uint32_t flags);
+
+/* ok[i] = (Enc(m[i], r[i]) == expected[i])                       when mulc_a == mulc_b == NULL
+ * ok[i] = (Enc(m[i], r[i]) == mulc_a[i] * mulc_b[i] mod n[i]^2)   when expected == NULL
+ * Replaces CorrectOpening::verify_opening (src/zkproofs/correct_opening.rs:17-30) and the verifier's two equality
+ * shapes: `expected_c1i != encrypted_pairs.c1[i]` (range_proof.rs:280-298: the stored value is compared as it is, so
+ * an expected[i] >= n^2 never matches) and `c_j[i] * cipher_x % nn` vs Enc(masked_x, masked_r) (range_proof.rs:324-337:
+ * the product is reduced, factors of any size up to 2*n_bits bits).  Exactly one of (expected) / (mulc_a, mulc_b)
+ * is given.  expected, mulc_a, mulc_b: [count][2kw]; out_ok: [count] bytes 0 / 1.  An even n gives ok = 0. */
+int32_t zkp_paillier_enc_check_batch(zkp_ctx* ctx, uint32_t n_bits, uint64_t count, const uint32_t* n,
+                                     uint64_t n_stride, const uint32_t* m, const uint32_t* r,
+                                     const uint32_t* mulc_a, const uint32_t* mulc_b, const uint32_t* expected,
+                                     uint8_t* out_ok, uint32_t flags);
 
 /* ------------------------------------------------------------------ RangeProofNi
  * Batch of B non-interactive range proofs, structure-of-arrays

@@ -209,6 +209,38 @@ int32_t oracle_paillier_enc_batch(uint32_t n_bits, uint64_t count, const uint32_
   return 0;
 }
 
+/* CorrectOpening::verify_opening (correct_opening.rs:25-28): `c == &d` on BigInts, i.e. the stored value is compared
+ * unreduced; with (mulc_a, mulc_b) the expected value is `a * b % nn` as at range_proof.rs:324-328. */
+int32_t oracle_paillier_enc_check_batch(uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m,
+                                        const uint32_t* r, const uint32_t* mulc_a, const uint32_t* mulc_b, const uint32_t* expected,
+                                        uint8_t* out_ok) {
+  size_t kw = n_bits / 32;
+#pragma omp parallel num_threads(n_threads)
+  {
+    mpz_t zn, znn, zm, zr, zc, t, e, f;
+    mpz_inits(zn, znn, zm, zr, zc, t, e, f, NULL);
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t i = 0; i < (int64_t)count; i++) {
+      limbs_to_mpz(zn, n + i * n_stride, kw);
+      mpz_mul(znn, zn, zn);
+      limbs_to_mpz(zm, m + i * kw, kw);
+      limbs_to_mpz(zr, r + i * kw, kw);
+      enc_mpz(zc, zn, znn, zm, zr, t);
+      if (mulc_a) {
+        limbs_to_mpz(e, mulc_a + i * 2 * kw, 2 * kw);
+        limbs_to_mpz(f, mulc_b + i * 2 * kw, 2 * kw);
+        mpz_mul(e, e, f);
+        mpz_tdiv_r(e, e, znn);
+      } else {
+        limbs_to_mpz(e, expected + i * 2 * kw, 2 * kw);
+      }
+      out_ok[i] = mpz_cmp(e, zc) == 0;
+    }
+    mpz_clears(zn, znn, zm, zr, zc, t, e, f, NULL);
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ RangeProofNi */
 
 /* range_proof_ni.rs:58-61 / 89-92 with utils.rs:9-22:

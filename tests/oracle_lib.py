@@ -60,6 +60,13 @@ class Oracle:
         self.lib.oracle_paillier_enc_batch(C.c_uint32(n_bits), C.c_uint64(count), p(n), C.c_uint64(n_stride), p(m), p(r), p(out))
         return out
 
+    def paillier_enc_check(self, n_bits, n, n_stride, m, r, mulc_a, mulc_b, expected):
+        count = m.shape[0]
+        ok = np.zeros(count, dtype=np.uint8)
+        self.lib.oracle_paillier_enc_check_batch(C.c_uint32(n_bits), C.c_uint64(count), p(n), C.c_uint64(n_stride), p(m), p(r),
+                                                 p(mulc_a), p(mulc_b), p(expected), p(ok))
+        return ok
+
     def range_ni_prove(self, proofs: RangeNiProofs, wit: RangeNiWitness, out_e, out_e_len, out_status):
         return self.lib.oracle_range_ni_prove_batch(C.byref(proofs), C.byref(wit), p(out_e), p(out_e_len), p(out_status))
 

@@ -1,5 +1,7 @@
 """GPU parity tests for the L1 boundary (modexp / modmul / Paillier Enc) through the C ABI,
 bit-exact against the C/GMP oracle on the same seeded inputs."""
+import math
+
 import numpy as np
 import pytest
 
@@ -99,3 +101,71 @@ def test_paillier_enc_per_item_keys_and_widths(ctx, oracle):
         out = np.zeros((count, 2 * kw), np.uint32)
         ctx.paillier_enc(n_bits, count, nl, kw, m, r, out)
         assert np.array_equal(out, oracle.paillier_enc(n_bits, nl, kw, m, r))
+
+
+@pytest.mark.parametrize("per_item_keys", [False, True])
+def test_paillier_enc_check(ctx, oracle, per_item_keys):
+    """zkp_paillier_enc_check_batch = CorrectOpening::verify_opening (correct_opening.rs:17-30) and the verifier's two
+    equality shapes (range_proof.rs:280-298 raw compare, :324-337 compare with c_j * cipher_x % nn)."""
+    n_bits, kw, count = 2048, 64, 24
+    d = pm.Drbg(b"gpu-enc-check-%d" % per_item_keys)
+    _, _, nfix = H.fixture_key()
+    ns = [d.bits(n_bits) | 1 | (1 << (n_bits - 1)) for _ in range(count)] if per_item_keys else [nfix]
+    stride = kw if per_item_keys else 0
+    key = lambda i: ns[i] if per_item_keys else nfix
+    ms = [d.bits(256) for _ in range(count)]
+    rs = [d.below(key(i)) for i in range(count)]
+    nl, m, r = L.ints_to_limbs(ns, kw), L.ints_to_limbs(ms, kw), L.ints_to_limbs(rs, kw)
+    cs = [pm.enc(key(i), ms[i], rs[i]) for i in range(count)]
+    # (a) expected given directly: honest, one flipped bit, c + n^2 (same residue, unreduced: the reference's == is false), zero
+    exp = list(cs)
+    exp[1] ^= 1 << 77
+    exp[2] = cs[2] + key(2) ** 2 if (cs[2] + key(2) ** 2).bit_length() <= 4096 else cs[2] ^ 1
+    exp[3] = 0
+    e = L.ints_to_limbs(exp, 2 * kw)
+    ok = np.full(count, 9, np.uint8)
+    ctx.paillier_enc_check(n_bits, count, nl, stride, m, r, None, None, e, ok)
+    ref = oracle.paillier_enc_check(n_bits, nl, stride, m, r, None, None, e)
+    assert np.array_equal(ok, ref)
+    assert list(ok[:4]) == [1, 0, 0, 0] and ok[4:].all()
+    # (b) expected = a * b mod n^2 with unreduced factors (a >= n^2 allowed: `%` reduces the product)
+    a_int, b_int = [], []
+    for i in range(count):
+        nn = key(i) ** 2
+        bv = d.below(nn)
+        while math.gcd(bv, nn) != 1:                                # invertible factor
+            bv = d.below(nn)
+        av = cs[i] * pow(bv, -1, nn) % nn
+        a_int.append(av); b_int.append(bv)
+    if a_int[5] + key(5) ** 2 < (1 << 4096):
+        a_int[5] += key(5) ** 2                                     # unreduced factor, same product residue: still equal
+    b_int[6] ^= 2                                                   # wrong product
+    a, b = L.ints_to_limbs(a_int, 2 * kw), L.ints_to_limbs(b_int, 2 * kw)
+    ok2 = np.full(count, 9, np.uint8)
+    ctx.paillier_enc_check(n_bits, count, nl, stride, m, r, a, b, None, ok2)
+    ref2 = oracle.paillier_enc_check(n_bits, nl, stride, m, r, a, b, None)
+    assert np.array_equal(ok2, ref2)
+    assert ok2[5] == 1 and ok2[6] == 0 and ok2[:5].all() and ok2[7:].all()
+
+
+def test_paillier_enc_check_argument_errors(ctx, zkp):
+    kw = 64
+    z = np.zeros((1, kw), np.uint32); c = np.zeros((1, 2 * kw), np.uint32); ok = np.zeros(1, np.uint8)
+    with pytest.raises(zkp.ZkpError):
+        ctx.paillier_enc_check(2048, 1, z, 0, z, z, c, None, None, ok)       # only one factor
+    with pytest.raises(zkp.ZkpError):
+        ctx.paillier_enc_check(2048, 1, z, 0, z, z, c, c, c, ok)             # both forms
+    with pytest.raises(zkp.ZkpError):
+        ctx.paillier_enc_check(2048, 1, z, 0, z, z, None, None, None, ok)    # neither
+
+
+def test_modexp_rejects_short_strides(ctx, zkp):
+    """a non-zero stride smaller than the element width would make the kernels read past the staged buffers"""
+    b = np.zeros((2, 64), np.uint32); b[:, 0] = 3
+    out = np.zeros_like(b)
+    with pytest.raises(zkp.ZkpError):
+        ctx.modexp(2048, 2048, 2, b, b, 32, b, 64, out)
+    with pytest.raises(zkp.ZkpError):
+        ctx.modexp(2048, 2048, 2, b, b, 64, b, 63, out)
+    with pytest.raises(zkp.ZkpError):
+        ctx.modmul(2048, 2, b, b, b, 1, out)

@@ -48,6 +48,7 @@ EXPORTS = {
     "zkp_last_error_string": (C.c_char_p, [C.c_void_p]),
     "zkp_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "zkp_ctx_synchronize": (C.c_int32, [C.c_void_p]),
+    "zkp_ctx_release_staging": (C.c_int32, [C.c_void_p]),
     "zkp_timing_reset": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_timing_get": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "zkp_modexp_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
@@ -56,6 +57,8 @@ EXPORTS = {
                                      C.c_uint64, C.c_void_p, C.c_uint32]),
     "zkp_paillier_enc_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkp_paillier_enc_check_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_range_ni_prove_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness),
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_range_ni_verify_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_uint32]),
@@ -201,6 +204,14 @@ class Context:
     def paillier_enc(self, n_bits, count, n, n_stride, m, r, out_c):
         self.check(self.lib.zkp_paillier_enc_batch(self.h, n_bits, count, ptr(n), n_stride, ptr(m), ptr(r), ptr(out_c),
                                                    self._flags(n, m, r, out_c)))
+
+    def paillier_enc_check(self, n_bits, count, n, n_stride, m, r, mulc_a, mulc_b, expected, out_ok):
+        """out_ok[i] = Enc(m, r) == expected[i]  (or == mulc_a[i]*mulc_b[i] mod n^2 when expected is None)"""
+        self.check(self.lib.zkp_paillier_enc_check_batch(self.h, n_bits, count, ptr(n), n_stride, ptr(m), ptr(r), ptr(mulc_a), ptr(mulc_b),
+                                                         ptr(expected), ptr(out_ok), self._flags(n, m, r, mulc_a, mulc_b, expected, out_ok)))
+
+    def release_staging(self):
+        self.check(self.lib.zkp_ctx_release_staging(self.h))
 
     def range_ni_prove(self, proofs: RangeNiProofs, wit: RangeNiWitness, out_e, out_e_len, out_status, device: bool):
         self.check(self.lib.zkp_range_ni_prove_batch(self.h, C.byref(proofs), C.byref(wit), ptr(out_e), ptr(out_e_len),

@@ -261,7 +261,7 @@ template <int G> __device__ __forceinline__ void stage_one(const Grp<G>& g) {
 // square != 0: the modulus is src^2 (Paillier n -> n^2; src_words = NW/2).
 template <int G>
 __global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src, uint64_t src_stride, int src_words, int square,
-                                               uint64_t count, uint32_t* __restrict__ consts) {
+                                               uint64_t count, uint32_t* __restrict__ consts, uint32_t* __restrict__ bad_flag) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
   constexpr int L = Geo<G>::L, NW = LL::NW, CAP = Geo<G>::CAPBITS;
@@ -392,6 +392,7 @@ __global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src,
     if (g.gl == 0) {
       cst[CL::OFF_NI] = g.n1;
       cst[CL::OFF_ST] = (uint32_t)status;
+      if (status && bad_flag) atomicOr(bad_flag, (uint32_t)status);
     }
   }
 }
@@ -514,7 +515,7 @@ struct EncArgs {
   uint32_t* table;
   uint64_t count;            // work items
   int n_bits;
-  int mode;
+  int mode;                  // 0 = Enc, 1 = RangeProofNi verify work list, 2 = flat Enc-and-compare (m, r, c1 = expected | factor a, cipher_x = factor b | null, verdict = ok bytes)
   // mode 0: item i -> m[i], r[i], out[i]; key index = i / items_per_key
   const uint32_t* m; const uint32_t* r; uint32_t* out; uint64_t items_per_key;
   int m_words, r_words;         // mode 0: words per m / r element (0 = n_bits/32; m may be null when m_words < 0: m = 0)
@@ -585,6 +586,14 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
       rw_ = a.r_words ? a.r_words : kw;
       pm = a.m + item * mw;
       pr = a.r + item * rw_;
+    } else if (a.mode == 2) {
+      // flat Enc-and-compare (zkp_paillier_enc_check_batch): expected = c1[item], or c1[item] * cipher_x[item] mod n^2
+      key = item / a.items_per_key;
+      b = item;
+      pm = a.m + item * kw;
+      pr = a.r + item * kw;
+      mask_row = a.cipher_x != nullptr;
+      pexp = a.c1 + item * 2 * kw;
     } else {
       b = a.item_proof[item];
       const uint32_t rw = a.item_row[item];
@@ -659,7 +668,9 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
           if (!mask_row && w < 2 * kw) same = same && (e == pexp[w]);
         }
         const unsigned long long mk = __ballot(same);
-        if (live && g.gl == 0 && !(valid && (mk & gmask) == gmask)) a.verdict[b] = ZKP_VERDICT_REJECT;
+        const bool pass = valid && (mk & gmask) == gmask;
+        if (a.mode == 2) { if (live && g.gl == 0) a.verdict[b] = pass ? 1 : 0; }
+        else if (live && g.gl == 0 && !pass) a.verdict[b] = ZKP_VERDICT_REJECT;
       }
     }
   }

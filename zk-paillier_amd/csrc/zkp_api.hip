@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <new>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,7 +23,14 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// staging blocks kept by the ctx between calls (host-pointer mode): a call takes the best-fitting cached block or
+// allocates one, and hands everything back when it returns; zkp_ctx_release_staging / zkp_ctx_destroy free them
+struct StageBlock { void* p; size_t cap; };
+
 struct zkp_ctx {
+  std::vector<StageBlock> stage_free;
+  uint32_t* setup_flag = nullptr;      // device word: k_setup ORs the status of every modulus it rejects into it
+  uint32_t* setup_flag_host = nullptr; // its pinned host mirror
   int device = 0;
   hipStream_t stream = nullptr;
   int cus = 0;
@@ -48,6 +56,16 @@ struct zkp_ctx {
     }                                                                                             \
   } while (0)
 
+// nothing may propagate through the C ABI: every extern "C" entry point is a function-try-block ending in ZKP_CATCH
+static int32_t zkp_caught(zkp_ctx* c, int32_t st, const char* what) noexcept {
+  if (c) { try { c->err = what; } catch (...) {} }
+  return st;
+}
+#define ZKP_CATCH(ctx)                                                                                         \
+  catch (const std::bad_alloc&) { return zkp_caught((ctx), ZKP_ENOMEM, "out of host memory"); }               \
+  catch (const std::exception& e_) { return zkp_caught((ctx), ZKP_EDEVICE, e_.what()); }                      \
+  catch (...) { return zkp_caught((ctx), ZKP_EDEVICE, "unknown exception"); }
+
 static int32_t ensure(zkp_ctx* c, DevBuf& b, size_t bytes) {
   if (b.cap >= bytes) return ZKP_OK;
   if (b.p) HIPCHK(c, hipFree(b.p));
@@ -61,31 +79,55 @@ static int32_t ensure(zkp_ctx* c, DevBuf& b, size_t bytes) {
 struct Stage {
   zkp_ctx* c;
   bool dev;
-  std::vector<void*> owned;
+  std::vector<StageBlock> owned;
   struct Out { void* d; void* h; size_t n; };
   std::vector<Out> outs;
   int32_t st = ZKP_OK;
   Stage(zkp_ctx* c_, uint32_t flags) : c(c_), dev((flags & ZKP_F_DEVICE_PTRS) != 0) {}
   Stage(const Stage&) = delete;
   Stage& operator=(const Stage&) = delete;
-  ~Stage() {                       // an error return that skipped finish(): nothing is copied back, the staging memory is released
+  ~Stage() {                       // an error return that skipped finish(): nothing is copied back, the blocks go back to the ctx
     if (owned.empty()) return;
     (void)hipStreamSynchronize(c->stream);
-    for (void* p : owned) (void)hipFree(p);
+    give_back();
+  }
+  void give_back() {
+    for (auto& b : owned) c->stage_free.push_back(b);
+    owned.clear();
+  }
+  // best fit among the cached blocks (no more than twice the size asked for), else a fresh allocation
+  void* take(size_t bytes) {
+    bytes = std::max<size_t>((bytes + 255) & ~size_t(255), 256);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < c->stage_free.size(); i++) {
+      const size_t cap = c->stage_free[i].cap;
+      if (cap >= bytes && cap <= 2 * bytes && (best == SIZE_MAX || cap < c->stage_free[best].cap)) best = i;
+    }
+    StageBlock b{nullptr, bytes};
+    if (best != SIZE_MAX) { b = c->stage_free[best]; c->stage_free[best] = c->stage_free.back(); c->stage_free.pop_back(); }
+    else if (hipMalloc(&b.p, bytes) != hipSuccess) { st = ZKP_ENOMEM; c->err = "hipMalloc (staging)"; return nullptr; }
+    owned.push_back(b);
+    return b.p;
   }
   template <class T> const T* in(const T* p, size_t count) {
     if (dev || !p || st) return p;
-    void* d = nullptr;
-    if (hipMalloc(&d, std::max<size_t>(count * sizeof(T), 16)) != hipSuccess) { st = ZKP_ENOMEM; c->err = "hipMalloc (stage in)"; return nullptr; }
-    owned.push_back(d);
+    void* d = take(count * sizeof(T));
+    if (!d) return nullptr;
+    if (hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) { st = ZKP_EDEVICE; c->err = "H2D copy"; }
+    return (const T*)d;
+  }
+  // a host buffer in BOTH memory modes (short byte strings such as a salt)
+  template <class T> const T* host_in(const T* p, size_t count) {
+    if (!p || st) return nullptr;
+    void* d = take(count * sizeof(T));
+    if (!d) return nullptr;
     if (hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) { st = ZKP_EDEVICE; c->err = "H2D copy"; }
     return (const T*)d;
   }
   template <class T> T* out(T* p, size_t count, bool copy_in = false) {
     if (dev || !p || st) return p;
-    void* d = nullptr;
-    if (hipMalloc(&d, std::max<size_t>(count * sizeof(T), 16)) != hipSuccess) { st = ZKP_ENOMEM; c->err = "hipMalloc (stage out)"; return nullptr; }
-    owned.push_back(d);
+    void* d = take(count * sizeof(T));
+    if (!d) return nullptr;
     if (copy_in) { if (hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) { st = ZKP_EDEVICE; c->err = "H2D copy"; } }
     else (void)hipMemsetAsync(d, 0, count * sizeof(T), c->stream);
     outs.push_back({d, (void*)p, count * sizeof(T)});
@@ -95,8 +137,8 @@ struct Stage {
     for (auto& o : outs)
       if (!st && hipMemcpyAsync(o.h, o.d, o.n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { st = ZKP_EDEVICE; c->err = "D2H copy"; }
     if (!dev || st) { if (hipStreamSynchronize(c->stream) != hipSuccess && !st) { st = ZKP_EDEVICE; c->err = "stream sync"; } }
-    for (void* p : owned) (void)hipFree(p);
-    owned.clear(); outs.clear();
+    give_back();
+    outs.clear();
     return st;
   }
 };
@@ -135,18 +177,20 @@ template <int G> static int32_t run_setup(zkp_ctx* c, const uint32_t* src, uint6
   int32_t st = ensure(c, buf, count * CL::WORDS * sizeof(uint32_t));
   if (st) return st;
   const unsigned blocks = (unsigned)((count + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK);
-  hipLaunchKernelGGL(k_setup<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, src, stride, src_words, square, count, (uint32_t*)buf.p);
+  hipLaunchKernelGGL(k_setup<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, src, stride, src_words, square, count, (uint32_t*)buf.p, c->setup_flag);
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
 }
 
-template <int G> static int32_t check_setup_status(zkp_ctx* c, uint64_t count, DevBuf& buf, bool* any_bad) {
-  using CL = ConstLayout<G>;
-  std::vector<uint32_t> st(count);
-  HIPCHK(c, hipMemcpy2DAsync(st.data(), 4, (const uint32_t*)buf.p + CL::OFF_ST, CL::WORDS * 4, 4, count, hipMemcpyDeviceToHost, c->stream));
+// "did any set-up since the last call reject its modulus": one word, reduced on the device by k_setup itself
+static int32_t clear_setup_flag(zkp_ctx* c) {
+  HIPCHK(c, hipMemsetAsync(c->setup_flag, 0, 4, c->stream));
+  return ZKP_OK;
+}
+static int32_t read_setup_flag(zkp_ctx* c, bool* any_bad) {
+  HIPCHK(c, hipMemcpyAsync(c->setup_flag_host, c->setup_flag, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  *any_bad = false;
-  for (uint32_t v : st) if (v) *any_bad = true;
+  *any_bad = *c->setup_flag_host != 0;
   return ZKP_OK;
 }
 
@@ -181,7 +225,7 @@ template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_
 }
 
 // ---- ctx ------------------------------------------------------------------------------------
-extern "C" int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out) {
+extern "C" int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out) try {
   if (!out) return ZKP_EINVAL;
   *out = nullptr;
   int n = 0;
@@ -195,11 +239,13 @@ extern "C" int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out) {
   c->cus = p.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKP_EDEVICE; }
   if (hipHostMalloc((void**)&c->pinned_counts, zkp_ctx::PINNED_SLOTS * sizeof(unsigned long long)) != hipSuccess) c->pinned_counts = nullptr;
+  if (hipMalloc((void**)&c->setup_flag, 64) != hipSuccess || hipHostMalloc((void**)&c->setup_flag_host, 64) != hipSuccess ||
+      hipMemset(c->setup_flag, 0, 64) != hipSuccess) { (void)zkp_ctx_destroy(c); return ZKP_EDEVICE; }
   *out = c;
   return ZKP_OK;
-}
+} ZKP_CATCH(nullptr)
 
-extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) {
+extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   if (!c) return ZKP_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
@@ -207,30 +253,42 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) {
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
+  for (auto& b : c->stage_free) (void)hipFree(b.p);
+  if (c->setup_flag) (void)hipFree(c->setup_flag);
+  if (c->setup_flag_host) (void)hipHostFree(c->setup_flag_host);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return ZKP_OK;
-}
+} ZKP_CATCH(c)
+
+extern "C" int32_t zkp_ctx_release_staging(zkp_ctx* c) try {
+  if (!c) return ZKP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& b : c->stage_free) (void)hipFree(b.p);
+  c->stage_free.clear();
+  return ZKP_OK;
+} ZKP_CATCH(c)
 
 extern "C" const char* zkp_backend_name(void) { return "hip-gfx950"; }
 extern "C" int32_t zkp_build_limbs_per_lane(void) { return W; }
 extern "C" const char* zkp_last_error_string(zkp_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 extern "C" void* zkp_ctx_stream(zkp_ctx* c) { return c ? (void*)c->stream : nullptr; }
-extern "C" int32_t zkp_ctx_synchronize(zkp_ctx* c) {
+extern "C" int32_t zkp_ctx_synchronize(zkp_ctx* c) try {
   if (!c) return ZKP_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ZKP_OK;
-}
+} ZKP_CATCH(c)
 
-extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) {
+extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) try {
   if (!c) return ZKP_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->timing = enable != 0;
   c->ev_used = 0; c->timed_launches = 0; c->timed_modexps = 0; c->pinned_used = 0;
   return ZKP_OK;
-}
+} ZKP_CATCH(c)
 
-extern "C" int32_t zkp_timing_get(zkp_ctx* c, double* ms, uint64_t* launches, uint64_t* modexps) {
+extern "C" int32_t zkp_timing_get(zkp_ctx* c, double* ms, uint64_t* launches, uint64_t* modexps) try {
   if (!c) return ZKP_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   double total = 0;
@@ -245,7 +303,7 @@ extern "C" int32_t zkp_timing_get(zkp_ctx* c, double* ms, uint64_t* launches, ui
   for (size_t i = 0; i < c->pinned_used; i++) extra += c->pinned_counts[i];
   if (modexps) *modexps = c->timed_modexps + extra;
   return ZKP_OK;
-}
+} ZKP_CATCH(c)
 
 // ---- L1 primitives --------------------------------------------------------------------------
 // modexp over constants that are already set up in c->consts (per-item when const_stride != 0)
@@ -275,22 +333,23 @@ static int32_t modexp_impl(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const 
                            const uint32_t* mod, uint64_t mod_stride, uint32_t* out) {
   using LL = LdsLayout<G>;
   const uint64_t nmod = mod_stride ? count : 1;
-  int32_t st = run_setup<G>(c, mod, mod_stride, LL::NW, 0, nmod, c->consts);
+  int32_t st = clear_setup_flag(c);
   if (st) return st;
+  if ((st = run_setup<G>(c, mod, mod_stride, LL::NW, 0, nmod, c->consts))) return st;
   bool bad = false;
-  if ((st = check_setup_status<G>(c, nmod, c->consts, &bad))) return st;
   if ((st = modexp_core<G>(c, exp_bits, count, base, exp, exp_stride, mod_stride != 0, out, LL::NW))) return st;
+  if ((st = read_setup_flag(c, &bad))) return st;
   if (bad) { c->err = "even or trivial modulus in batch (outputs of those items are untouched)"; return ZKP_ENONCANONICAL; }
   return ZKP_OK;
 }
 
 extern "C" int32_t zkp_modexp_batch(zkp_ctx* c, uint32_t mod_bits, uint32_t exp_bits, uint64_t count, const uint32_t* base,
                                     const uint32_t* exp, uint64_t exp_stride, const uint32_t* mod, uint64_t mod_stride, uint32_t* out,
-                                    uint32_t flags) {
+                                    uint32_t flags) try {
   if (!c) return ZKP_EINVAL;
   if (count == 0) return ZKP_OK;
   if (!base || !exp || !mod || !out || (mod_bits != 2048 && mod_bits != 4096 && mod_bits != 8192) || exp_bits == 0 || exp_bits % 32 ||
-      exp_bits > mod_bits || count > (1ull << 40)) { c->err = "zkp_modexp_batch: invalid argument"; return ZKP_EINVAL; }
+      exp_bits > mod_bits || count > (1ull << 40) || (exp_stride && exp_stride < exp_bits / 32) || (mod_stride && mod_stride < mod_bits / 32)) { c->err = "zkp_modexp_batch: invalid argument"; return ZKP_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t L = mod_bits / 32, E = exp_bits / 32;
   Stage s(c, flags);
@@ -308,30 +367,31 @@ extern "C" int32_t zkp_modexp_batch(zkp_ctx* c, uint32_t mod_bits, uint32_t exp_
   }
   const int32_t fin = s.finish();
   return st ? st : fin;
-}
+} ZKP_CATCH(c)
 
 template <int G>
 static int32_t modmul_impl(zkp_ctx* c, uint64_t count, const uint32_t* a, const uint32_t* b, const uint32_t* mod, uint64_t mod_stride, uint32_t* out) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
   const uint64_t nmod = mod_stride ? count : 1;
-  int32_t st = run_setup<G>(c, mod, mod_stride, LL::NW, 0, nmod, c->consts);
+  int32_t st = clear_setup_flag(c);
   if (st) return st;
+  if ((st = run_setup<G>(c, mod, mod_stride, LL::NW, 0, nmod, c->consts))) return st;
   bool bad = false;
-  if ((st = check_setup_status<G>(c, nmod, c->consts, &bad))) return st;
   ModmulArgs args{a, b, (const uint32_t*)c->consts.p, mod_stride ? (uint64_t)CL::WORDS : 0, out, count, LL::NW};
   const unsigned blocks = (unsigned)((count + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK);
   hipLaunchKernelGGL(k_modmul<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, args);
   HIPCHK(c, hipGetLastError());
+  if ((st = read_setup_flag(c, &bad))) return st;
   if (bad) { c->err = "even or trivial modulus in batch"; return ZKP_ENONCANONICAL; }
   return ZKP_OK;
 }
 
 extern "C" int32_t zkp_modmul_batch(zkp_ctx* c, uint32_t mod_bits, uint64_t count, const uint32_t* a, const uint32_t* b, const uint32_t* mod,
-                                    uint64_t mod_stride, uint32_t* out, uint32_t flags) {
+                                    uint64_t mod_stride, uint32_t* out, uint32_t flags) try {
   if (!c) return ZKP_EINVAL;
   if (count == 0) return ZKP_OK;
-  if (!a || !b || !mod || !out || (mod_bits != 2048 && mod_bits != 4096 && mod_bits != 8192) || count > (1ull << 31)) { c->err = "zkp_modmul_batch: invalid argument"; return ZKP_EINVAL; }
+  if (!a || !b || !mod || !out || (mod_bits != 2048 && mod_bits != 4096 && mod_bits != 8192) || count > (1ull << 31) || (mod_stride && mod_stride < mod_bits / 32)) { c->err = "zkp_modmul_batch: invalid argument"; return ZKP_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t L = mod_bits / 32;
   Stage s(c, flags);
@@ -349,7 +409,7 @@ extern "C" int32_t zkp_modmul_batch(zkp_ctx* c, uint32_t mod_bits, uint64_t coun
   }
   const int32_t fin = s.finish();
   return st ? st : fin;
-}
+} ZKP_CATCH(c)
 
 // Paillier contexts: modulus n^2, group size from 2*n_bits
 template <int G>
@@ -382,10 +442,10 @@ static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint3
 }
 
 extern "C" int32_t zkp_paillier_enc_batch(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m,
-                                          const uint32_t* r, uint32_t* out_c, uint32_t flags) {
+                                          const uint32_t* r, uint32_t* out_c, uint32_t flags) try {
   if (!c) return ZKP_EINVAL;
   if (count == 0) return ZKP_OK;
-  if (!n || !m || !r || !out_c || (n_bits != 1024 && n_bits != 2048 && n_bits != 4096) || count > (1ull << 40)) { c->err = "zkp_paillier_enc_batch: invalid argument"; return ZKP_EINVAL; }
+  if (!n || !m || !r || !out_c || (n_bits != 1024 && n_bits != 2048 && n_bits != 4096) || count > (1ull << 40) || (n_stride && n_stride < n_bits / 32)) { c->err = "zkp_paillier_enc_batch: invalid argument"; return ZKP_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t kw = n_bits / 32;
   Stage s(c, flags);
@@ -403,7 +463,62 @@ extern "C" int32_t zkp_paillier_enc_batch(zkp_ctx* c, uint32_t n_bits, uint64_t 
   }
   const int32_t fin = s.finish();
   return st ? st : fin;
+} ZKP_CATCH(c)
+
+// Enc-and-compare (CorrectOpening::verify_opening, correct_opening.rs:17-30; the verifier's equality tests range_proof.rs:280-298,324-337)
+template <int G>
+static int32_t enc_check_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m, const uint32_t* r,
+                              const uint32_t* exp_or_a, const uint32_t* mulc_b, uint8_t* out_ok) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  const uint64_t nkeys = n_stride ? count : 1;
+  int32_t st = enc_setup<G>(c, n_bits, n, n_stride, nkeys);
+  if (st) return st;
+  unsigned blocks = 0;
+  if ((st = table_for<G>(c, k_enc<G>, count, &blocks))) return st;
+  EncArgs a{};
+  a.n = n; a.n_stride = n_stride; a.consts = (const uint32_t*)c->consts.p; a.const_stride = n_stride ? (uint64_t)CL::WORDS : 0;
+  a.table = (uint32_t*)c->table.p; a.count = count; a.n_bits = (int)n_bits; a.mode = 2;
+  a.m = m; a.r = r; a.items_per_key = n_stride ? 1 : count;
+  a.c1 = exp_or_a; a.cipher_x = mulc_b; a.verdict = out_ok;
+  if (n_stride == 0 && (st = build_schedule(c, n, n_bits, &a.sched))) return st;
+  if ((st = fresh_work_counter(c, &a.work_counter))) return st;
+  {
+    TimedRegion tr(c, count);
+    hipLaunchKernelGGL(k_enc<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+  }
+  HIPCHK(c, hipGetLastError());
+  return ZKP_OK;
 }
+
+extern "C" int32_t zkp_paillier_enc_check_batch(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m,
+                                                const uint32_t* r, const uint32_t* mulc_a, const uint32_t* mulc_b, const uint32_t* expected,
+                                                uint8_t* out_ok, uint32_t flags) try {
+  if (!c) return ZKP_EINVAL;
+  if (count == 0) return ZKP_OK;
+  const bool product = mulc_a || mulc_b;
+  if (!n || !m || !r || !out_ok || (n_bits != 1024 && n_bits != 2048 && n_bits != 4096) || count > (1ull << 40) || (n_stride && n_stride != n_bits / 32) ||
+      (product ? (!mulc_a || !mulc_b || expected) : !expected)) { c->err = "zkp_paillier_enc_check_batch: invalid argument"; return ZKP_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t kw = n_bits / 32;
+  Stage s(c, flags);
+  const uint32_t* dn = s.in(n, n_stride ? count * n_stride : kw);
+  const uint32_t* dm = s.in(m, count * kw);
+  const uint32_t* dr = s.in(r, count * kw);
+  const uint32_t* da = s.in(product ? mulc_a : expected, count * 2 * kw);
+  const uint32_t* db = s.in(mulc_b, count * 2 * kw);
+  uint8_t* dok = s.out(out_ok, count);
+  int32_t st = s.st;
+  if (!st) {
+    switch (group_for_bits(2 * n_bits)) {
+      case GA: st = enc_check_impl<GA>(c, n_bits, count, dn, n_stride, dm, dr, da, db, dok); break;
+      case GB: st = enc_check_impl<GB>(c, n_bits, count, dn, n_stride, dm, dr, da, db, dok); break;
+      default: st = enc_check_impl<GC>(c, n_bits, count, dn, n_stride, dm, dr, da, db, dok); break;
+    }
+  }
+  const int32_t fin = s.finish();
+  return st ? st : fin;
+} ZKP_CATCH(c)
 
 #include "zkp_api_proofs.inc"
 #include "zkp_api_mul.inc"
