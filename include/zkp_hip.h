@@ -23,7 +23,8 @@
  *    an error code (mirrors Result<(), IncorrectProof>, src/zkproofs/errors.rs:5-13).
  *    Nothing aborts or throws across this boundary.
  *  - One ctx = one GPU + one HIP stream.  Calls on one ctx are serialised by the caller;
- *    different ctxs are independent (one per GPU / per rank).
+ *    different ctxs are independent (one per GPU / per rank) and may be driven from different
+ *    host threads at the same time (zkp_multi_* does exactly that).
  *  - There is NO CPU fallback: if no gfx950 device is present zkp_ctx_create fails with
  *    ZKP_EDEVICE.
  */
@@ -325,6 +326,27 @@ int32_t zkp_json_range_proof_batch(zkp_ctx* ctx, const char* text, const uint64_
 /* {"sigma_vec":["..", x11]} -> sigma [B][11][n_bits/32] */
 int32_t zkp_json_correct_key_proof_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len, uint32_t n_bits,
                                          uint64_t batch, uint32_t* out_sigma, uint8_t* out_status, uint32_t flags);
+
+/* ------------------------------------------------------------------ several GPUs behind one caller
+ * The reference spreads a proof's rows over a rayon pool (src/zkproofs/range_proof.rs:161-187,270-348); here a batch
+ * is cut into contiguous blocks of PROOF indices, one block per device context, one host thread per context
+ * (the only threads this library starts).  Host pointers only: every block reads its slice of the caller's arrays and
+ * writes its slab of the caller's output arrays, so the per-GPU D2H copy is the reassembly step and no collective is
+ * needed inside one process.  (One process per GPU with device-resident results on every GPU — the RCCL all-gather
+ * of north_star — is zk-paillier_amd/shard.py + bench.py.)  device_ids may repeat: two contexts on one GPU are two
+ * independent streams.  Results are identical to one call of the single-context entry point on the whole batch. */
+typedef struct zkp_multi zkp_multi;
+int32_t zkp_multi_create(const int32_t* device_ids, uint32_t n_devices, zkp_multi** out);
+int32_t zkp_multi_destroy(zkp_multi* m);
+uint32_t zkp_multi_size(zkp_multi* m);
+zkp_ctx* zkp_multi_ctx(zkp_multi* m, uint32_t i);            /* context i (owned by m), e.g. for zkp_timing_* */
+const char* zkp_multi_last_error_string(zkp_multi* m);
+int32_t zkp_multi_range_ni_prove_batch(zkp_multi* m, const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w,
+                                       uint8_t* out_e, uint8_t* out_e_len, uint8_t* out_status);
+int32_t zkp_multi_range_ni_verify_batch(zkp_multi* m, const zkp_range_ni_proofs* p, uint8_t* out_verdict);
+int32_t zkp_multi_correct_key_ni_verify_batch(zkp_multi* m, uint32_t n_bits, uint64_t batch, const uint32_t* n,
+                                              const uint32_t* sigma, const uint8_t* salt, uint32_t salt_len,
+                                              uint8_t* out_verdict);
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,12 @@
 """CPU test of the N>1 path: world_size 2 over gloo.  Each rank verifies its contiguous block of a
 proof batch (the per-rank compute is the ORACLE here — there is no GPU — the plumbing under test is
 zk-paillier_amd/shard.py: index partition + the single all-gather) and the gathered verdict vector must
-equal the single-process result."""
+equal the single-process result.  The second test drives bench.py's own step functions (bench.make_steps:
+prove / verify on the rank's block + the gather through shard.py) with an oracle-backed engine, i.e. the code
+`bench.py --gpus N` times, at world size 2."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -85,3 +88,84 @@ def test_world_size_2_gloo_verify_gather():
         assert p.exitcode == 0
     assert gathered == full == [zkp.VERDICT_ACCEPT, zkp.VERDICT_ACCEPT, zkp.VERDICT_REJECT]
     assert ok_c1
+
+
+class _OracleEngine:
+    """stands in for bench.GpuEngine on a CPU box: same interface, per-rank compute by the oracle on torch CPU tensors"""
+
+    def __init__(self, oracle):
+        self.oracle = oracle
+
+    def prove(self, pb, wt):
+        assert self.oracle.range_ni_prove(pb.struct(), wt.struct(), None, None, None) == 0
+
+    def verify(self, pb, verdict):
+        assert self.oracle.range_ni_verify(pb.struct(), verdict.numpy()) == 0
+
+    def before_collective(self):
+        pass
+
+    def after_collective(self):
+        pass
+
+
+def _rank_batch(rank, n_bits, B, oracle):
+    n = H.test_key(512)[2]
+    cases = H.build_range_case(b"bench-steps-%d" % rank, [n], n_bits, B)
+    if rank == 1:
+        cases[0] = H.build_range_case(b"bench-steps-bad", [n], n_bits, 1, honest=False)[0]
+    pb, wt = H.fill_batch(cases, n_bits, True, oracle)
+    return pb.to("cpu"), wt.to("cpu")
+
+
+def _bench_worker(rank, world, port, n_bits, B, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    sys.path.insert(0, H.ROOT)
+    import bench
+    oracle = oracle_lib.Oracle()
+    pb, wt = _rank_batch(rank, n_bits, B, oracle)
+    verdict = torch.zeros(B, dtype=torch.uint8)
+    prove_step, verify_step, out = bench.make_steps(_OracleEngine(oracle), pb, wt, verdict, world)
+    prove_step()
+    verify_step()
+    if rank == 0:
+        # single-process reference: both ranks' batches proved and verified here
+        exp_v, exp_c1 = [], []
+        for r in range(world):
+            qb, qw = _rank_batch(r, n_bits, B, oracle)
+            oracle.range_ni_prove(qb.struct(), qw.struct(), None, None, None)
+            v = np.zeros(B, np.uint8)
+            oracle.range_ni_verify(qb.struct(), v)
+            exp_v += v.tolist(); exp_c1.append(qb.c1)
+        ret.put((out["verdict"].tolist(), exp_v, bool(torch.equal(out["c1"], torch.cat(exp_c1, dim=0))), list(out["c2"].shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_functions_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    world, B, n_bits = 2, 2, 1024
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, n_bits, B, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered, expected, c1_ok, c2_shape = ret.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert gathered == expected == [zkp.VERDICT_ACCEPT, zkp.VERDICT_ACCEPT, zkp.VERDICT_REJECT, zkp.VERDICT_ACCEPT]
+    assert c1_ok and c2_shape == [world * B, 128, 2 * n_bits // 32]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """`--gpus 8` under a 1-rank launcher must not print a 1-GPU line: exit status 2 before any GPU work"""
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()

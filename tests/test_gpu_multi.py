@@ -1,0 +1,71 @@
+"""zkp_multi_*: one caller, several device contexts (include/zkp_hip.h).  The GPU box has ONE GPU, so the device list
+repeats device 0: two contexts = two independent streams / scratch sets, which is exactly what two GPUs would be to the
+host side (block partition, one thread per context, slabs written into the caller's arrays).  Results must equal the
+single-context entry points and the oracle."""
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import pm, L, zkp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_multi_range_prove_verify_equals_oracle(oracle, devices):
+    n_bits, B = 1024, 5
+    n = H.test_key(1024)[2]
+    cases = H.build_range_case(b"multi", [n], n_bits, B)
+    cases[3] = H.build_range_case(b"multi-bad", [n], n_bits, 1, honest=False)[0]
+    pb_o, wt = H.fill_batch(cases, n_bits, True, oracle)
+    pb_g = pb_o.to(None)
+    oracle.range_ni_prove(pb_o.struct(), wt.struct(), None, None, None)
+    m = zkp.MultiContext(devices)
+    assert m.size() == len(devices)
+    e = np.zeros((B, 32), np.uint8); elen = np.zeros(B, np.uint8); st = np.full(B, 9, np.uint8)
+    m.range_ni_prove(pb_g.struct(), wt.struct(), e, elen, st)
+    for f in ("c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2"):
+        assert np.array_equal(getattr(pb_o, f), getattr(pb_g, f)), f
+    assert not st.any() and (elen > 0).all()
+    vg = np.full(B, 9, np.uint8); vo = np.full(B, 9, np.uint8)
+    pb_g.resp_r2[1, 5, 3] ^= 4; pb_o.resp_r2[1, 5, 3] ^= 4           # tamper one proof after proving
+    m.range_ni_verify(pb_g.struct(), vg)
+    oracle.range_ni_verify(pb_o.struct(), vo)
+    assert list(vg) == list(vo)
+    assert zkp.VERDICT_REJECT in vg and zkp.VERDICT_ACCEPT in vg
+    m.close()
+
+
+def test_multi_per_proof_keys_and_more_contexts_than_proofs(oracle):
+    n_bits, B = 1024, 2
+    ns = [H.test_key(1024, tag=t)[2] for t in range(B)]
+    cases = H.build_range_case(b"multi-keys", ns, n_bits, B, shared=False)
+    pb_o, wt = H.fill_batch(cases, n_bits, False, oracle)
+    pb_g = pb_o.to(None)
+    oracle.range_ni_prove(pb_o.struct(), wt.struct(), None, None, None)
+    m = zkp.MultiContext([0, 0, 0])                                   # one context gets an empty block
+    m.range_ni_prove(pb_g.struct(), wt.struct())
+    assert np.array_equal(pb_o.c1, pb_g.c1) and np.array_equal(pb_o.resp_r1, pb_g.resp_r1)
+    v = np.full(B, 9, np.uint8)
+    m.range_ni_verify(pb_g.struct(), v)
+    assert list(v) == [zkp.VERDICT_ACCEPT] * B
+    m.close()
+
+
+def test_multi_correct_key_verify(oracle):
+    keys = [H.test_key(1024, tag=t) for t in range(7)]
+    n_arr = L.ints_to_limbs([k[2] for k in keys], 32)
+    sig = np.stack([L.ints_to_limbs(pm.correct_key_proof(k[0], k[1], b"KZen"), 32) for k in keys])
+    sig[4, 2, 1] ^= 8
+    m = zkp.MultiContext([0, 0])
+    v = np.full(len(keys), 9, np.uint8)
+    m.correct_key_ni_verify(1024, len(keys), n_arr, sig, b"KZen", v)
+    assert list(v) == list(oracle.correct_key_ni_verify(1024, n_arr, sig, b"KZen")) == [1, 1, 1, 1, 0, 1, 1]
+    m.close()
+
+
+def test_multi_create_rejects_bad_device_list(zkp):
+    with pytest.raises(zkp.ZkpError):
+        zkp.MultiContext([0, 99])
+    with pytest.raises(zkp.ZkpError):
+        zkp.MultiContext([])

@@ -93,6 +93,14 @@ EXPORTS = {
                                                       C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_verlin_proof_prove_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64] + [C.c_void_p] * 16 + [C.c_uint32]),
     "zkp_verlin_proof_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64] + [C.c_void_p] * 9 + [C.c_uint32]),
+    "zkp_multi_create": (C.c_int32, [C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "zkp_multi_destroy": (C.c_int32, [C.c_void_p]),
+    "zkp_multi_size": (C.c_uint32, [C.c_void_p]),
+    "zkp_multi_ctx": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "zkp_multi_last_error_string": (C.c_char_p, [C.c_void_p]),
+    "zkp_multi_range_ni_prove_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zkp_multi_range_ni_verify_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p]),
+    "zkp_multi_correct_key_ni_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
 }
 
 Z1_EXTRA_LIMBS = 16
@@ -145,6 +153,43 @@ def ptr(a):
         assert a.is_contiguous()
         return a.data_ptr()
     raise TypeError(type(a))
+
+
+class MultiContext:
+    """zkp_multi: several device contexts behind one caller (host buffers only)."""
+
+    def __init__(self, device_ids):
+        self.lib = load()
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        st = self.lib.zkp_multi_create(ids, len(device_ids), C.byref(h))
+        if st != ZKP_OK:
+            raise ZkpError(f"zkp_multi_create({list(device_ids)}) failed with status {st} (no CPU fallback)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zkp_multi_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def check(self, st):
+        if st != ZKP_OK:
+            msg = self.lib.zkp_multi_last_error_string(self.h)
+            raise ZkpError(f"status {st}: {msg.decode() if msg else ''}")
+
+    def size(self):
+        return self.lib.zkp_multi_size(self.h)
+
+    def range_ni_prove(self, proofs, wit, out_e=None, out_e_len=None, out_status=None):
+        self.check(self.lib.zkp_multi_range_ni_prove_batch(self.h, C.byref(proofs), C.byref(wit), ptr(out_e), ptr(out_e_len), ptr(out_status)))
+
+    def range_ni_verify(self, proofs, out_verdict):
+        self.check(self.lib.zkp_multi_range_ni_verify_batch(self.h, C.byref(proofs), ptr(out_verdict)))
+
+    def correct_key_ni_verify(self, n_bits, batch, n, sigma, salt: bytes, out_verdict):
+        self.check(self.lib.zkp_multi_correct_key_ni_verify_batch(self.h, n_bits, batch, ptr(n), ptr(sigma), salt, len(salt), ptr(out_verdict)))
 
 
 class Context:

@@ -523,3 +523,4 @@ extern "C" int32_t zkp_paillier_enc_check_batch(zkp_ctx* c, uint32_t n_bits, uin
 #include "zkp_api_proofs.inc"
 #include "zkp_api_mul.inc"
 #include "zkp_api_serde.inc"
+#include "zkp_api_multi.inc"

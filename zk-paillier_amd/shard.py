@@ -16,8 +16,8 @@ def all_gather_slabs(local, world: int, counts=None):
     With `counts` (rows per rank, unequal) slabs are padded to max(counts) and trimmed after the gather."""
     import torch
     import torch.distributed as dist
-    if world == 1:
-        return local
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local            # no process group: nothing to exchange (with one, the degenerate gather still runs: same code at every N)
     if counts is None:
         out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())

@@ -15,6 +15,31 @@ BENCH_Q = 1587415744370072456544635981399278987304769247364616544639759667877193
 BENCH_N = BENCH_P * BENCH_Q
 
 
+def bench_key_4096():
+    """(p, q, n): the 4096-bit Paillier modulus of BASELINE.json configs[4] (tools/make_bench_keys.py; the reference
+    fixes only a 2048-bit keypair)"""
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_keys.json")))["key4096"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    return p, q, p * q
+
+
+def distinct_keys_2048(count: int):
+    """`count` distinct 2048-bit RSA moduli: products p_i * p_j (i < j) of the 92 pooled 1024-bit primes of
+    bench_keys.json ("4096 distinct eks")"""
+    import json
+    import os
+    pool = [int(v, 16) for v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_keys.json")))["pool1024"]]
+    out = []
+    for j in range(1, len(pool)):
+        for i in range(j):
+            out.append(pool[i] * pool[j])
+            if len(out) == count:
+                return out
+    raise ValueError(f"the prime pool yields {len(out)} moduli, {count} asked for")
+
+
 def _rand_limbs(torch, gen, shape, device):
     v = torch.randint(0, 1 << 32, shape, dtype=torch.int64, device=device, generator=gen)
     return v
@@ -25,16 +50,23 @@ def _to_i32(torch, v):
     return torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32)
 
 
-def synth_range_inputs(n: int, n_bits: int, batch: int, seed: int, device="cuda", ef: int = 128, range_bits: int = 256):
-    """-> (RangeBatch with n/range filled [ciphertext still zero], RangeWitness), all on `device`."""
+def synth_range_inputs(n, n_bits: int, batch: int, seed: int, device="cuda", ef: int = 128, range_bits: int = 256):
+    """-> (RangeBatch with n/range filled [ciphertext still zero], RangeWitness), all on `device`.
+    n: one int (shared key) or a list of `batch` ints (one key per proof, n_stride = kw)."""
     import torch
     kw = n_bits // 32
     rl = range_bits // 32
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    pb = RangeBatch(n_bits, batch, ef, shared_key=True, device=device)
+    shared = isinstance(n, int)
+    pb = RangeBatch(n_bits, batch, ef, shared_key=shared, device=device)
     wt = RangeWitness(n_bits, batch, ef, device=device)
-    pb.n.copy_(torch.from_numpy(L.int_to_limbs(n, kw).view(np.int32)).to(device).view(1, kw))
+    if shared:
+        pb.n.copy_(torch.from_numpy(L.int_to_limbs(n, kw).view(np.int32)).to(device).view(1, kw))
+    else:
+        assert len(n) == batch
+        pb.n.copy_(torch.from_numpy(L.ints_to_limbs(list(n), kw).view(np.int32)).to(device))
+        n = min(n)
     # range: range_bits with the top bit set
     rng = _rand_limbs(torch, gen, (batch, rl), device)
     rng[:, rl - 1] |= 1 << 31
