@@ -288,7 +288,11 @@ def main():
                                       f"128 rows/proof, 1/64 of the proofs tampered; prove leg = configs[2]",
                           "parallelism": f"proof-index sharding x{world}, one RCCL all-gather per step of verdicts (verify) and c1/c2 slabs (prove) via zk-paillier_amd/shard.py"},
                "prove": prove, "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "other_configs": other}
-        print(json.dumps(out))
+        # RCCL writes a version banner through C stdio when the communicator is created; push it out first so that the
+        # JSON line is the LAST line on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     if not ok:

@@ -257,6 +257,44 @@ def correct_key_verify(sigma, n: int, salt: bytes) -> bool:
     return rho == derived and gcd_test == 1
 
 
+# ----------------------------------------------------------------------------- interactive CorrectKey
+
+CK_ERRORS = {1: "SniNotCoprimeWithN", 2: "ZiNotCoprimeWithN", 3: "RniNotCoprimeWithN", 4: "EWasntComputedCorrectly"}
+
+
+def correct_key_challenge(n: int, s, r):
+    """correct_key.rs:64-102 with the sampled s_i, r_i (:67-70, :80-83) injected.  -> (sn, e, z, s_digest)"""
+    sn = [pow(si, n, n) for si in s]
+    rn = [pow(ri, n, n) for ri in r]
+    e = compute_digest([n] + sn + rn)
+    z = [(ri * pow(si, e, n)) % n for ri, si in zip(r, s)]
+    return sn, e, z, compute_digest(s)
+
+
+def correct_key_prove(p: int, q: int, sn, e: int, z):
+    """correct_key.rs:104-162.  -> (0, s_digest) or (error code of CK_ERRORS, None)"""
+    import math
+    n = q * p
+    if any(math.gcd(n, v) != 1 for v in sn):
+        return 1, None
+    if any(math.gcd(n, v) != 1 for v in z):
+        return 2, None
+    phi = (q - 1) * (p - 1)
+    phimine = phi - (e % phi)
+    rn = [(pow(zi, n, n) * pow(sni, phimine, n)) % n for zi, sni in zip(z, sn)]
+    if any(math.gcd(n, v) != 1 for v in rn):
+        return 3, None
+    if e != compute_digest([n] + list(sn) + rn):
+        return 4, None
+    d = pow(n, -1, phi)                                   # [upstream] extract_nroot
+    return 0, compute_digest([pow(v, d, n) for v in sn])
+
+
+def correct_key_verify_interactive(proof_digest: int, aid_digest: int) -> bool:
+    """correct_key.rs:164-171"""
+    return proof_digest == aid_digest
+
+
 # ----------------------------------------------------------------------------- composite dlog
 
 def dlog_prove(N, g, ni, secret, r):

@@ -573,6 +573,94 @@ int32_t oracle_correct_key_rho(uint32_t n_bits, const uint32_t* n, const uint8_t
   return 0;
 }
 
+/* ------------------------------------------------------------------ interactive CorrectKey (correct_key.rs:64-171)
+ * The reference samples s_i, r_i < n from the OS RNG (:67-70,80-83); here they are inputs.
+ * K = STATISTICAL_ERROR_FACTOR rows (40 in the reference, :26).  n: kw words; s, r, sn, z: [K][kw]; e, s_digest: 8 words
+ * (a SHA-256 value). */
+int32_t oracle_correct_key_challenge(uint32_t n_bits, uint32_t K, const uint32_t* n, const uint32_t* s, const uint32_t* r,
+                                     uint32_t* out_sn, uint32_t* out_e, uint32_t* out_z, uint32_t* out_s_digest) {
+  const size_t kw = n_bits / 32;
+  mpz_t zn, e, t, dg;
+  mpz_inits(zn, e, t, dg, NULL);
+  limbs_to_mpz(zn, n, kw);
+  mpz_t* items = (mpz_t*)malloc(sizeof(mpz_t) * (2 * K + 1));
+  mpz_t* sv = (mpz_t*)malloc(sizeof(mpz_t) * K);
+  mpz_init_set(items[0], zn);
+  for (uint32_t i = 0; i < K; i++) {
+    mpz_init(sv[i]); mpz_init(items[1 + i]); mpz_init(items[1 + K + i]);
+    limbs_to_mpz(sv[i], s + i * kw, kw);
+    mpz_powm(items[1 + i], sv[i], zn, zn);                 /* sn_i = s_i^n mod n  :73-76 */
+    limbs_to_mpz(t, r + i * kw, kw);
+    mpz_powm(items[1 + K + i], t, zn, zn);                 /* rn_i = r_i^n mod n  :86-89 */
+    mpz_to_limbs(out_sn + i * kw, kw, items[1 + i]);
+  }
+  compute_digest(e, (const mpz_t*)items, (int)(2 * K + 1));   /* e = H(n, sn.., rn..)  :91 */
+  mpz_to_limbs(out_e, 8, e);
+  for (uint32_t i = 0; i < K; i++) {
+    mpz_powm(t, sv[i], e, zn);                              /* z_i = r_i * s_i^e % n  :93-97 */
+    limbs_to_mpz(dg, r + i * kw, kw);
+    mpz_mul(t, dg, t);
+    mpz_tdiv_r(t, t, zn);
+    mpz_to_limbs(out_z + i * kw, kw, t);
+  }
+  compute_digest(dg, (const mpz_t*)sv, (int)K);               /* s_digest = H(s..)  :100 */
+  mpz_to_limbs(out_s_digest, 8, dg);
+  for (uint32_t i = 0; i < K; i++) { mpz_clear(sv[i]); mpz_clear(items[1 + i]); mpz_clear(items[1 + K + i]); }
+  mpz_clear(items[0]);
+  free(items); free(sv);
+  mpz_clears(zn, e, t, dg, NULL);
+  return 0;
+}
+
+/* CorrectKey::prove (correct_key.rs:104-162).  Returns 0 = Ok (out_s_digest written) or the CorrectKeyProveError:
+ * 1 SniNotCoprimeWithN (:110-116), 2 ZiNotCoprimeWithN (:119-125), 3 RniNotCoprimeWithN (:143-148), 4 EWasntComputedCorrectly (:151-156).
+ * e: e_words words (the challenge's e is attacker-chosen, any size); extract_nroot [upstream]: sn_i^(n^-1 mod phi) mod n. */
+int32_t oracle_correct_key_prove(uint32_t n_bits, uint32_t K, const uint32_t* p, const uint32_t* q, const uint32_t* sn, const uint32_t* e,
+                                 uint32_t e_words, const uint32_t* z, uint32_t* out_s_digest) {
+  const size_t kw = n_bits / 32;
+  int32_t rc = 0;
+  mpz_t zp, zq, zn, phi, phimine, ze, t, u, g, d;
+  mpz_inits(zp, zq, zn, phi, phimine, ze, t, u, g, d, NULL);
+  limbs_to_mpz(zp, p, kw / 2); limbs_to_mpz(zq, q, kw / 2);
+  mpz_mul(zn, zq, zp);                                        /* dk_n = q * p  :108 */
+  limbs_to_mpz(ze, e, e_words);
+  mpz_t* items = (mpz_t*)malloc(sizeof(mpz_t) * (2 * K + 1));
+  mpz_init_set(items[0], zn);
+  for (uint32_t i = 0; i < K; i++) { mpz_init(items[1 + i]); mpz_init(items[1 + K + i]); limbs_to_mpz(items[1 + i], sn + i * kw, kw); }
+  for (uint32_t i = 0; i < K && !rc; i++) { mpz_gcd(g, zn, items[1 + i]); if (mpz_cmp_ui(g, 1) != 0) rc = 1; }
+  for (uint32_t i = 0; i < K && !rc; i++) { limbs_to_mpz(t, z + i * kw, kw); mpz_gcd(g, zn, t); if (mpz_cmp_ui(g, 1) != 0) rc = 2; }
+  if (!rc) {
+    mpz_sub_ui(phi, zq, 1); mpz_sub_ui(t, zp, 1); mpz_mul(phi, phi, t);   /* :128 */
+    mpz_tdiv_r(t, ze, phi); mpz_sub(phimine, phi, t);                      /* phi - (e % phi)  :130 */
+    for (uint32_t i = 0; i < K; i++) {
+      limbs_to_mpz(t, z + i * kw, kw);
+      mpz_powm(t, t, zn, zn);                                             /* zn  :135 */
+      mpz_powm(u, items[1 + i], phimine, zn);                             /* snphi  :136 */
+      mpz_mul(t, t, u); mpz_tdiv_r(items[1 + K + i], t, zn);              /* :137 */
+    }
+    for (uint32_t i = 0; i < K && !rc; i++) { mpz_gcd(g, zn, items[1 + K + i]); if (mpz_cmp_ui(g, 1) != 0) rc = 3; }
+  }
+  if (!rc) {
+    compute_digest(t, (const mpz_t*)items, (int)(2 * K + 1));              /* :151 */
+    if (mpz_cmp(t, ze) != 0) rc = 4;
+  }
+  if (!rc) {
+    mpz_invert(d, zn, phi);
+    for (uint32_t i = 0; i < K; i++) mpz_powm(items[1 + K + i], items[1 + i], d, zn);   /* extract_nroot(dk, sn_i)  :159 */
+    compute_digest(t, (const mpz_t*)(items + 1 + K), (int)K);
+    mpz_to_limbs(out_s_digest, 8, t);
+  }
+  for (uint32_t i = 0; i < 2 * K + 1; i++) mpz_clear(items[i]);
+  free(items);
+  mpz_clears(zp, zq, zn, phi, phimine, ze, t, u, g, d, NULL);
+  return rc;
+}
+
+/* CorrectKey::verify (correct_key.rs:164-171): proof.s_digest == va.s_digest */
+int32_t oracle_correct_key_verify(const uint32_t* proof_s_digest, const uint32_t* aid_s_digest) {
+  return memcmp(proof_s_digest, aid_s_digest, 32) == 0 ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
+}
+
 /* ------------------------------------------------------------------ CompositeDLogProof */
 int32_t oracle_dlog_prove_batch(uint32_t n_bits, uint32_t y_bits, uint64_t batch, const uint32_t* N, const uint32_t* g,
                                 const uint32_t* ni, const uint32_t* secret, const uint32_t* r, uint32_t* out_x,

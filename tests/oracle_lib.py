@@ -88,6 +88,20 @@ class Oracle:
         assert rc == 0
         return n, sigma
 
+    def correct_key_challenge(self, n_bits, n, s, r):
+        K, kw = s.shape[0], n_bits // 32
+        sn = np.zeros((K, kw), np.uint32); z = np.zeros((K, kw), np.uint32); e = np.zeros(8, np.uint32); sd = np.zeros(8, np.uint32)
+        self.lib.oracle_correct_key_challenge(C.c_uint32(n_bits), C.c_uint32(K), p(n), p(s), p(r), p(sn), p(e), p(z), p(sd))
+        return sn, e, z, sd
+
+    def correct_key_prove(self, n_bits, pp, qq, sn, e, z):
+        sd = np.zeros(8, np.uint32)
+        rc = self.lib.oracle_correct_key_prove(C.c_uint32(n_bits), C.c_uint32(sn.shape[0]), p(pp), p(qq), p(sn), p(e), C.c_uint32(e.shape[0]), p(z), p(sd))
+        return rc, sd
+
+    def correct_key_verify(self, a, b):
+        return self.lib.oracle_correct_key_verify(p(a), p(b))
+
     def correct_key_rho(self, n_bits, n, salt: bytes):
         rho = np.zeros((11, n_bits // 32), dtype=np.uint32)
         self.lib.oracle_correct_key_rho(C.c_uint32(n_bits), p(n), salt, C.c_uint32(len(salt)), p(rho))

@@ -169,3 +169,67 @@ def test_modexp_rejects_short_strides(ctx, zkp):
         ctx.modexp(2048, 2048, 2, b, b, 64, b, 63, out)
     with pytest.raises(zkp.ZkpError):
         ctx.modmul(2048, 2, b, b, b, 1, out)
+
+
+def test_enc_decrypts_with_the_fixture_secret_key(ctx):
+    """Pins Enc to the standard g = 1+n Paillier definition WITHOUT the oracle: ciphertexts made by the GPU decrypt, with
+    the secret key of the reference's fixture (range_proof_ni.rs:141-145), to the plaintext, c = r^n (mod n), and
+    Paillier::open's randomness recovery (the reference's own test: correct_opening.rs:47-57) returns r."""
+    p, q, n = H.fixture_key()
+    nn, kw = n * n, 64
+    lam = (p - 1) * (q - 1) // math.gcd(p - 1, q - 1)
+    phi = (p - 1) * (q - 1)
+    d = pm.Drbg(b"gpu-enc-decrypt")
+    count = 12
+    ms = [d.below(n) for _ in range(count)]; ms[0] = 0; ms[1] = 10; ms[2] = n - 1
+    rs = [d.below(n) for _ in range(count)]; rs[3] = 1
+    out = np.zeros((count, 2 * kw), np.uint32)
+    ctx.paillier_enc(2048, count, L.ints_to_limbs([n], kw), 0, L.ints_to_limbs(ms, kw), L.ints_to_limbs(rs, kw), out)
+    ok = np.zeros(count, np.uint8)
+    ctx.paillier_enc_check(2048, count, L.ints_to_limbs([n], kw), 0, L.ints_to_limbs(ms, kw), L.ints_to_limbs(rs, kw), None, None, out, ok)
+    assert ok.all()                                                      # verify_opening(ek, m, r, c)
+    for m, r, c in zip(ms, rs, L.limbs_to_ints(out)):
+        assert 0 <= c < nn
+        u = pow(c, lam, nn)
+        assert (u - 1) % n == 0
+        assert ((u - 1) // n) * pow(lam, -1, n) % n == m                 # Dec(c) = L(c^lambda mod n^2) * mu mod n
+        assert c % n == pow(r, n, n)                                     # c = (1 + m n) r^n  ->  c = r^n (mod n)
+        assert pow(c % n, pow(n, -1, phi), n) == r                       # Paillier::open: the n-th root of c mod n
+
+
+def test_even_modulus_deviation_is_pinned(ctx, oracle, zkp):
+    """DOCUMENTED DEVIATION: Montgomery arithmetic needs an odd modulus.  For an even modulus the reference
+    (GMP) still computes; the engine reports ZKP_ENONCANONICAL and leaves the outputs of those items untouched / zero, and
+    proof-level entry points answer MALFORMED.  This test pins both behaviours next to each other."""
+    kw = 64
+    d = pm.Drbg(b"even-modulus")
+    mod_even = (d.bits(2048) | (1 << 2047)) & ~1
+    mod_odd = mod_even | 1
+    base = [d.bits(2040), d.bits(2040)]; e = [d.bits(2048), d.bits(2048)]
+    b, ee, m = L.ints_to_limbs(base, kw), L.ints_to_limbs(e, kw), L.ints_to_limbs([mod_even, mod_odd], kw)
+    ref = oracle.modexp(2048, 2048, b, ee, kw, m, kw)
+    assert L.limbs_to_ints(ref) == [pow(base[0], e[0], mod_even), pow(base[1], e[1], mod_odd)]      # what the reference returns
+    out = np.full_like(b, 0xA5A5A5A5)
+    with pytest.raises(zkp.ZkpError, match="status 2"):
+        ctx.modexp(2048, 2048, 2, b, ee, kw, m, kw, out)
+    # (host-pointer mode copies nothing back on an error status: the odd item is recomputed on its own)
+    out1 = np.zeros((1, kw), np.uint32)
+    ctx.modexp(2048, 2048, 1, b[1:], ee[1:], kw, m[1:], kw, out1)
+    assert np.array_equal(out1[0], ref[1])
+    # Enc under an even n: GMP computes a value, the engine writes zeros for that item
+    n_even = (d.bits(1024) | (1 << 1023)) & ~1
+    mm, rr = d.bits(256), d.bits(1000)
+    nl, ml, rl = L.ints_to_limbs([n_even], 32), L.ints_to_limbs([mm], 32), L.ints_to_limbs([rr], 32)
+    c_ref = oracle.paillier_enc(1024, nl, 0, ml, rl)
+    assert L.limbs_to_int(c_ref[0]) == pm.enc(n_even, mm, rr) != 0
+    c = np.full((1, 64), 7, np.uint32)
+    ctx.paillier_enc(1024, 1, nl, 0, ml, rl, c)
+    assert not c.any()
+    # a RangeProofNi under an even key: the oracle (reference behaviour) evaluates it, the engine answers MALFORMED
+    cases = H.build_range_case(b"even-key", [n_even], 1024, 1)
+    pb, wt = H.fill_batch(cases, 1024, True, oracle)
+    oracle.range_ni_prove(pb.struct(), wt.struct(), None, None, None)
+    vo = np.full(1, 9, np.uint8); vg = np.full(1, 9, np.uint8)
+    oracle.range_ni_verify(pb.struct(), vo)
+    ctx.range_ni_verify(pb.struct(), vg, device=False)
+    assert vo[0] == zkp.VERDICT_ACCEPT and vg[0] == zkp.VERDICT_MALFORMED

@@ -1,0 +1,144 @@
+//! Runs the REAL zk-paillier crate (and the curv / kzen-paillier versions it pins) and writes everything this
+//! repository's oracle can only restate: byte conventions, the Enc formula, Fiat-Shamir challenges, full
+//! RangeProofNi transcripts, NiCorrectKeyProof sigma vectors, CompositeDLogProof transcripts.
+//!
+//! What can and cannot be pinned from OUTSIDE the crate:
+//!  * `RangeProof::generate_encrypted_pairs` draws (w1, w2, r1, r2) from the OS RNG and `DataRandomnessPairs`
+//!    has private fields and is not exported, so a prover run cannot be replayed from a seed.  Instead whole proofs
+//!    are dumped: every Open row reveals (w1, r1, w2, r2) next to (c1, c2) — a known-answer test of Enc —, the
+//!    Open / Mask pattern IS the bit string of the Fiat-Shamir challenge — a known-answer test of compute_digest,
+//!    BigInt::to_bytes and the MSB-first bit order —, and the verdicts pin the verifier.
+//!  * `NiCorrectKeyProof::proof(dk, None)` is deterministic: its sigma vector is a direct known answer.
+//!
+//! Output schema (all big integers as decimal strings, the crate's own wire format):
+//! { "generator": ..., "to_bytes": [{"x","hex"}], "compute_digest": [{"items":[..],"digest"}],
+//!   "enc": {"n", "items":[{"m","r","c"}]},
+//!   "range_ni": [{"n","range","ciphertext","x","r","honest", "encrypted_pairs": <serde>, "proof": <serde>,
+//!                 "error_factor", "verify_self": "ok"|"err", "raw": <serde_json of the whole RangeProofNi>}],
+//!   "correct_key_ni": [{"p","q","n","salt_hex","sigma_vec":[..],"verify":"ok"|"err"}],
+//!   "dlog": [{"N","g","ni","secret","x","y","verify":"ok"|"err"}] }
+use std::env;
+use std::fs;
+
+use curv::arithmetic::traits::*;
+use curv::BigInt;
+use paillier::{
+    DecryptionKey, EncryptWithChosenRandomness, EncryptionKey, KeyGeneration, Keypair, Paillier,
+    Randomness, RawCiphertext, RawPlaintext,
+};
+use serde_json::{json, Value};
+use zk_paillier::zkproofs::{compute_digest, CompositeDLogProof, DLogStatement, NiCorrectKeyProof, RangeProofNi};
+
+const P: &str = "148677972634832330983979593310074301486537017973460461278300587514468301043894574906886127642530475786889672304776052879927627556769456140664043088700743909632312483413393134504352834240399191134336344285483935856491230340093391784574980688823380828143810804684752914935441384845195613674104960646037368551517";
+const Q: &str = "158741574437007245654463598139927898730476924736461654463975966787719309357536545869203069369466212089132653564188443272208127277664424448947476335413293018778018615899291704693105620242763173357203898195318179150836424196645745308205164116144020613415407736216097185962171301808761138424668335445923774195463";
+
+fn dec(x: &BigInt) -> String {
+    x.to_str_radix(10)
+}
+fn hex(b: &[u8]) -> String {
+    b.iter().map(|v| format!("{:02x}", v)).collect()
+}
+fn big(s: &str) -> BigInt {
+    BigInt::from_str_radix(s, 10).unwrap()
+}
+
+/// the fixed keypair of the crate's own tests (src/zkproofs/range_proof_ni.rs:141-145)
+fn test_keypair() -> Keypair {
+    Keypair { p: big(P), q: big(Q) }
+}
+
+fn enc(ek: &EncryptionKey, m: &BigInt, r: &BigInt) -> BigInt {
+    let c: RawCiphertext = Paillier::encrypt_with_chosen_randomness(ek, RawPlaintext::from(m), &Randomness::from(r));
+    c.0.into_owned()
+}
+
+fn range_case(ek: &EncryptionKey, honest: bool) -> Value {
+    // same shapes as the crate's tests (range_proof_ni.rs:163-199)
+    let range = BigInt::sample(256);
+    let secret_r = BigInt::sample_below(&ek.n);
+    let secret_x = if honest {
+        BigInt::sample_below(&range.div_floor(&BigInt::from(3)))
+    } else {
+        BigInt::sample_range(&(BigInt::from(100) * &range), &(BigInt::from(10000) * &range))
+    };
+    let cipher_x = enc(ek, &secret_x, &secret_r);
+    let proof = RangeProofNi::prove(ek, &range, &cipher_x, &secret_x, &secret_r);
+    let verdict = if proof.verify_self().is_ok() { "ok" } else { "err" };
+    let raw = serde_json::to_value(&proof).unwrap();
+    json!({
+        "n": dec(&ek.n), "range": dec(&range), "ciphertext": dec(&cipher_x), "x": dec(&secret_x), "r": dec(&secret_r),
+        "honest": honest, "encrypted_pairs": raw["encrypted_pairs"].clone(), "proof": raw["proof"].clone(),
+        "error_factor": raw["error_factor"].clone(), "verify_self": verdict, "raw": raw,
+    })
+}
+
+fn main() {
+    let out_path = env::args().nth(1).unwrap_or_else(|| "reference_vectors.json".to_string());
+    let (ek, dk): (EncryptionKey, DecryptionKey) = test_keypair().keys();
+
+    // BigInt::to_bytes conventions: zero, one byte, a value with a zero low byte
+    let to_bytes: Vec<Value> = [BigInt::zero(), BigInt::from(255), BigInt::from(256), BigInt::from(65536)]
+        .iter()
+        .map(|x| json!({"x": dec(x), "hex": hex(&x.to_bytes())}))
+        .collect();
+
+    // compute_digest (src/zkproofs/utils.rs:9-22) incl. zero elements
+    let lists: Vec<Vec<BigInt>> = vec![
+        vec![BigInt::zero()],
+        vec![BigInt::zero(), BigInt::zero(), BigInt::one()],
+        vec![ek.n.clone(), BigInt::from(255), ek.nn.clone()],
+        vec![BigInt::from(256), BigInt::from(255), BigInt::from(65536)],
+    ];
+    let digests: Vec<Value> = lists
+        .iter()
+        .map(|l| json!({"items": l.iter().map(dec).collect::<Vec<_>>(), "digest": dec(&compute_digest(l.iter()))}))
+        .collect();
+
+    // Paillier::encrypt_with_chosen_randomness incl. m >= n and r >= n (arbitrary-precision inputs are legal)
+    let full = BigInt::from(2).pow(2048) - BigInt::one();
+    let ms = vec![BigInt::zero(), BigInt::one(), BigInt::sample(256), &ek.n - BigInt::one(), full.clone()];
+    let rs = vec![BigInt::sample_below(&ek.n), BigInt::sample_below(&ek.n), BigInt::sample_below(&ek.n), BigInt::one(), full];
+    let enc_items: Vec<Value> = ms
+        .iter()
+        .zip(rs.iter())
+        .map(|(m, r)| json!({"m": dec(m), "r": dec(r), "c": dec(&enc(&ek, m, r))}))
+        .collect();
+
+    // RangeProofNi transcripts: two honest proofs, one with an out-of-range witness (rejected)
+    let range_ni: Vec<Value> = vec![range_case(&ek, true), range_case(&ek, true), range_case(&ek, false)];
+
+    // NiCorrectKeyProof (deterministic): the fixture key and a fresh 2048-bit key
+    let mut ck: Vec<Value> = Vec::new();
+    let fresh = Paillier::keypair_with_modulus_size(2048);
+    for kp in vec![test_keypair(), fresh] {
+        let (ek2, dk2) = kp.keys();
+        let proof = NiCorrectKeyProof::proof(&dk2, None);
+        let v = if proof.verify(&ek2, zk_paillier::zkproofs::SALT_STRING).is_ok() { "ok" } else { "err" };
+        ck.push(json!({"p": dec(&dk2.p), "q": dec(&dk2.q), "n": dec(&ek2.n), "salt_hex": hex(zk_paillier::zkproofs::SALT_STRING),
+                       "sigma_vec": proof.sigma_vec.iter().map(dec).collect::<Vec<_>>(), "verify": v}));
+    }
+    let _ = &dk;
+
+    // CompositeDLogProof (src/zkproofs/wi_dlog_proof.rs:117-137): honest statement ni = g^-s
+    let mut dlog: Vec<Value> = Vec::new();
+    {
+        let n_tilde = ek.n.clone();
+        let one = BigInt::one();
+        let h1 = BigInt::sample_below(&(&n_tilde - &one));
+        let s = BigInt::sample(256);
+        let h1_inv = BigInt::mod_inv(&h1, &n_tilde).unwrap();
+        let ni = BigInt::mod_pow(&h1_inv, &s, &n_tilde);
+        let st = DLogStatement { N: n_tilde, g: h1, ni };
+        let proof = CompositeDLogProof::prove(&st, &s);
+        let v = if proof.verify(&st).is_ok() { "ok" } else { "err" };
+        dlog.push(json!({"N": dec(&st.N), "g": dec(&st.g), "ni": dec(&st.ni), "secret": dec(&s), "x": dec(&proof.x), "y": dec(&proof.y), "verify": v}));
+    }
+
+    let doc = json!({
+        "generator": "tools/reference_vectors (zk-paillier 0.4.4 + curv-kzen 0.10 / rust-gmp-kzen + kzen-paillier 0.4.3)",
+        "to_bytes": to_bytes, "compute_digest": digests, "enc": {"n": dec(&ek.n), "items": enc_items},
+        "range_ni": range_ni, "correct_key_ni": ck, "dlog": dlog,
+    });
+    fs::write(&out_path, serde_json::to_string(&doc).unwrap()).unwrap();
+    println!("wrote {}", out_path);
+}

@@ -496,13 +496,19 @@ struct CorrectKey {
   static std::pair<Challenge, VerificationAid> challenge(const EncryptionKey& ek) {
     std::vector<BigInt> s, r;
     for (size_t i = 0; i < STATISTICAL_ERROR_FACTOR; i++) { s.push_back(BigInt::sample_below(ek.n)); r.push_back(BigInt::sample_below(ek.n)); }
+    return challenge_with(ek, s, r);
+  }
+  // the same with the values the reference samples (:67-70, :80-83) supplied by the caller (parity tests)
+  static std::pair<Challenge, VerificationAid> challenge_with(const EncryptionKey& ek, const std::vector<BigInt>& s, const std::vector<BigInt>& r) {
+    if (s.size() != r.size()) throw std::invalid_argument("CorrectKey::challenge_with: |s| != |r|");
+    const size_t K = s.size();
     std::vector<BigInt> both = s; both.insert(both.end(), r.begin(), r.end());
     std::vector<BigInt> pw = mod_pow_batch(both, {ek.n}, ek.n);                               // sn, rn  (:73-76, :86-89)
-    std::vector<BigInt> sn(pw.begin(), pw.begin() + STATISTICAL_ERROR_FACTOR), rn(pw.begin() + STATISTICAL_ERROR_FACTOR, pw.end());
+    std::vector<BigInt> sn(pw.begin(), pw.begin() + K), rn(pw.begin() + K, pw.end());
     BigInt e = digest_chain(&ek.n, sn, &rn);                                                  // :91
     std::vector<BigInt> se = mod_pow_batch(s, {e}, ek.n);                                     // s_i^e  (:96)
     std::vector<BigInt> z;
-    for (size_t i = 0; i < STATISTICAL_ERROR_FACTOR; i++) z.push_back((r[i] * se[i]) % ek.n);
+    for (size_t i = 0; i < K; i++) z.push_back((r[i] * se[i]) % ek.n);
     return {Challenge{sn, e, z}, VerificationAid{digest_chain(nullptr, s)}};                  // :100-102
   }
   // :104-162 — returns the proof or the error
