@@ -1,13 +1,23 @@
 """CPU model of the wave-group Montgomery multiplication of csrc/bigint29.hpp (word-level CIOS on G lanes x W
 limbs of 29 bits, circular column window, optional Orup multiple), checked against Python integers.  It documents
-the invariants the kernel relies on: no 64-bit column overflow, lane 0's bottom limb always zero (so the DPP
-pass-down needs no masking between groups), result < 2M without any conditional subtraction, <= M when B == 1."""
+the invariants the kernel relies on:
+  * no 64-bit column overflow.  W <= 31: for any operands.  W = 36 (72 products per column life): the SAFE product moves a
+    column's upper word into the next column at half of its life and is exact for any operands; the FAST product is exact
+    for any A and B provided every lane's limb sum of the modulus operand is <= COL_FAST_SN_LIMIT (k_setup tests the
+    Orup multiple of every key and the ladders pick the product accordingly);
+  * lane 0's bottom limb always zero (so the DPP pass-down needs no masking between groups);
+  * result < 2M without any conditional subtraction, <= M when B == 1."""
 import random
 
 import pytest
 
 B = 29
 MASK = (1 << B) - 1
+
+
+def fast_sn_limit(W):
+    """bigint29.hpp COL_FAST_SN_LIMIT"""
+    return ((1 << 64) - 1 - (1 << 36) - ((1 << B) + 16) * (W * (1 << B) + 16)) >> B
 
 
 def to_limbs(x, n):
@@ -18,8 +28,8 @@ def from_limbs(l):
     return sum(v << (B * i) for i, v in enumerate(l))
 
 
-def montmul(N, n1, G, W, A, Bv, orup, stats):
-    """mirror of montmul<G, ORUP>: N = limbs of M (or of M~ = M*n1 when orup), n1 = -M^-1 mod 2^29"""
+def montmul(N, n1, G, W, A, Bv, orup, stats, safe=True, check=True):
+    """mirror of montmul<G, ORUP, SAFE>: N = limbs of M (or of M~ = M*n1 when orup), n1 = -M^-1 mod 2^29"""
     c = [[0] * W for _ in range(G)]
     for s in range(G):
         for t in range(W):
@@ -37,9 +47,16 @@ def montmul(N, n1, G, W, A, Bv, orup, stats):
                 v = c[j][t]
                 lo[j] = v & MASK
                 c[j][(t + 1) % W] += v >> B
-            assert lo[0] == 0                      # the value lane G-1 of the previous group would receive
+                stats["maxcol"] = max(stats["maxcol"], c[j][(t + 1) % W])
+            if check:
+                assert lo[0] == 0                  # the value lane G-1 of the previous group would receive
             for j in range(G):
                 c[j][t] = lo[j + 1] if j + 1 < G else 0
+                if safe and 2 * W > 63:
+                    km, kn = (t + W // 2) % W, (t + W // 2 + 1) % W
+                    c[j][kn] += (c[j][km] >> 32) << 3
+                    c[j][km] &= 0xFFFFFFFF
+                    stats["maxcol"] = max(stats["maxcol"], c[j][kn])
     out, carries = [], []
     for j in range(G):
         cy, r = 0, []
@@ -51,14 +68,15 @@ def montmul(N, n1, G, W, A, Bv, orup, stats):
         carries.append(cy)
     for j in range(1, G):
         out[j][0] += carries[j - 1]
-        assert out[j][0] < (1 << B) + 64
-    assert carries[G - 1] == 0
+        assert not check or out[j][0] < (1 << B) + 64
+    assert not check or carries[G - 1] == 0
     return [v for r in out for v in r]
 
 
-@pytest.mark.parametrize("bits,G,W", [(2048, 4, 18), (4096, 8, 18), (2048, 8, 9), (4096, 16, 9), (300, 4, 18)])
+@pytest.mark.parametrize("bits,G,W", [(2048, 2, 36), (4096, 4, 36), (8192, 8, 36), (300, 2, 36), (2048, 4, 18), (4096, 8, 18), (2048, 8, 9), (300, 4, 18)])
 @pytest.mark.parametrize("orup", [False, True])
-def test_word_level_cios_model(bits, G, W, orup):
+@pytest.mark.parametrize("safe", [True, False])
+def test_word_level_cios_model(bits, G, W, orup, safe):
     rnd = random.Random(bits * 31 + G + W + orup)
     M = rnd.getrandbits(bits) | 1 | (1 << (bits - 1))
     L = G * W
@@ -72,12 +90,50 @@ def test_word_level_cios_model(bits, G, W, orup):
     stats = {"maxcol": 0}
     for _ in range(2):
         a, b = rnd.randrange(bound), rnd.randrange(bound)
-        r = montmul(N, n1, G, W, to_limbs(a, L), to_limbs(b, L), orup, stats)
+        r = montmul(N, n1, G, W, to_limbs(a, L), to_limbs(b, L), orup, stats, safe)
         v = from_limbs(r)
         assert v % M == a * b * Rinv % M and v < bound
-        r2 = montmul(N, n1, G, W, r, r, orup, stats)           # feed the almost-normalised output straight back
+        r2 = montmul(N, n1, G, W, r, r, orup, stats, safe)     # feed the almost-normalised output straight back
         assert from_limbs(r2) % M == v * v * Rinv % M
     if not orup:
-        one = montmul(N, n1, G, W, to_limbs(rnd.randrange(2 * M), L), to_limbs(1, L), orup, stats)
+        one = montmul(N, n1, G, W, to_limbs(rnd.randrange(2 * M), L), to_limbs(1, L), orup, stats, safe)
         assert from_limbs(one) <= M                            # montmul(x, 1) <= M: one equality test canonicalises
     assert stats["maxcol"] < (1 << 64)
+
+
+def worst_operands(G, W):
+    """every limb at its maximum, plus the slack of almost-normalised operands (limb 0 of a lane's block may reach 2^29 + 16)"""
+    big = [MASK] * (G * W)
+    for j in range(G):
+        big[j * W] = MASK + 17
+    return big
+
+
+@pytest.mark.parametrize("G,W", [(4, 36), (2, 36), (8, 36), (8, 18)])
+def test_safe_product_cannot_overflow_for_any_operands(G, W):
+    stats = {"maxcol": 0}
+    big = worst_operands(G, W)
+    montmul([MASK] * (G * W), 1, G, W, big, big, True, stats, safe=True, check=False)
+    assert (1 << 62) < stats["maxcol"] < (1 << 64)
+    # analytic: at most W products before the hand-over and W after it (plus what the column kept, a carry and a digit)
+    assert W * (MASK + 17) ** 2 + (1 << 32) + (1 << 36) < (1 << 64)
+
+
+@pytest.mark.parametrize("G,W", [(4, 36), (2, 36)])
+def test_fast_product_bound(G, W):
+    """the FAST product (no hand-over) with A, B at their maximum: exact as long as every lane's limb sum of the modulus
+    operand is within COL_FAST_SN_LIMIT; beyond it (an all-ones modulus) a column can exceed 64 bits in the model."""
+    L = G * W
+    lim = fast_sn_limit(W)
+    assert 27 * (1 << B) < lim < 28 * (1 << B)
+    big = worst_operands(G, W)
+    # a modulus operand exactly at the limit: 27 limbs at the maximum, one partial, the rest zero, in every lane
+    lane = [MASK] * 27 + [lim - 27 * MASK] + [0] * (W - 28)
+    assert sum(lane) == lim and all(0 <= v <= MASK for v in lane)
+    stats = {"maxcol": 0}
+    montmul(lane * G, 1, G, W, big, big, True, stats, safe=False, check=False)
+    assert stats["maxcol"] < (1 << 64)
+    # analytic bound used by bigint29.hpp: max(b) * S_A + max(q) * S_N + carry/digit
+    assert ((1 << B) + 16) * (W * (1 << B) + 16) + MASK * lim + (1 << 36) < (1 << 64)
+    # ... and the bound is not vacuous: with an all-ones modulus operand the analytic bound fails
+    assert ((1 << B) + 16) * (W * (1 << B) + 16) + MASK * (W * MASK) + (1 << 36) > (1 << 64)

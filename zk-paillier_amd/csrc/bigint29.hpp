@@ -27,19 +27,19 @@
 namespace zkp {
 
 #ifndef ZKP_W
-#define ZKP_W 18
+#define ZKP_W 36
 #endif
 constexpr int LB = 29;                      // bits per limb
-constexpr int W = ZKP_W;                    // limbs per lane (9 or 18)
+constexpr int W = ZKP_W;                    // limbs per lane (36; 18 and 9 still build: -DZKP_W=18)
 constexpr uint32_t LMASK = (1u << LB) - 1;
 constexpr int BLK = (W + 3) & ~3;           // LDS words per W-limb block (16-B multiple: keeps ds_read_b128 aligned)
-static_assert(W == 9 || W == 18, "limbs per lane");
+static_assert(W == 9 || W == 18 || W == 36, "limbs per lane");
 // minimum waves per SIMD requested from the register allocator for the modexp-class kernels: the hot
 // loop (montmul) needs ~70 VGPRs at W = 9 and ~150 at W = 18; values that live across an exponentiation
 // may spill around it.  Measured on MI355X (Enc/s at n = 2048): W=9 @5 waves 251 K, W=18 @2 waves 269 K,
 // W=18 @3 waves 265 K — the larger window halves the per-limb overhead instructions per multiply.
 #ifndef ZKP_WPE
-#define ZKP_WPE (ZKP_W == 9 ? 5 : 2)
+#define ZKP_WPE (ZKP_W == 9 ? 5 : 2)   /* W = 36 also runs 2 waves per SIMD (256 VGPRs) */
 #endif
 
 template <int G> struct Geo {
@@ -52,8 +52,9 @@ template <int G> struct Geo {
 // value held by lane 0 of the group -> every lane of the group (ds_swizzle, bit-mask mode:
 // lane' = lane & and_mask inside each 32-lane half)
 template <int G> __device__ __forceinline__ uint32_t bcast0(uint32_t v) {
-  static_assert(G == 4 || G == 8 || G == 16 || G == 32, "group size");
-  if constexpr (G == 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0000);
+  static_assert(G == 2 || G == 4 || G == 8 || G == 16 || G == 32, "group size");
+  if constexpr (G == 2) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x001E);
+  else if constexpr (G == 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0000);
   else if constexpr (G == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0010);
   else if constexpr (G == 8) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0018);
   else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x001C);
@@ -79,7 +80,7 @@ template <int G> __device__ __forceinline__ uint32_t from_next(uint32_t v, int g
 template <int G> __device__ __forceinline__ uint32_t from_prev(uint32_t v, int gl) {
   if constexpr (G == 16) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
-  } else if constexpr (G == 8 || G == 4) {
+  } else if constexpr (G == 8 || G == 4 || G == 2) {
     uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
     return gl == 0 ? 0u : t;
   } else {
@@ -119,6 +120,22 @@ __device__ __forceinline__ void lds_store_block(uint32_t* p, const uint32_t (&v)
   }
 }
 
+// ---------------------------------------------------------------- column capacity (W = 36)
+// A column accumulator lives for W sub-steps and takes two products per sub-step, A_k*b and N_k*q, every k exactly once
+// over its life.  With 29-bit limbs a product is < 2^58, so 64 of them fit a 64-bit register: W <= 31 is safe for any
+// operands (W = 18: 36 products), W = 36 is not (72 products).  Over a column's life
+//     sum  <=  max(b) * S_A  +  max(q) * S_N  + carry + digit,     S_A = sum of this lane's limbs of A (<= 36 * 2^29 + 16),
+//                                                                   S_N = sum of this lane's limbs of the modulus operand,
+// so the plain W = 36 loop is exact for ANY A and B as long as every lane's S_N <= COL_FAST_SN_LIMIT (mean limb <= 0.777 *
+// 2^29; a random modulus has mean 0.5 +- 0.05 per lane).  k_setup measures S_N of the modulus operand of the ladders (the
+// Orup multiple M~) once per key and records whether the FAST product may be used; otherwise, and for the few general
+// products around the ladders (whose modulus operand is M itself), the SAFE product runs: at half of a column's life it
+// moves the column's upper 32-bit word up into the next column (2^32 = 8 * 2^29: one multiply-add and one move per
+// sub-step, about 7 % slower), after which no column can exceed 2^63.2 whatever the operands are.
+// tests/test_lane_model.py states both bounds executably.
+constexpr bool COL_NEEDS_CARE = 2 * W > 63;
+constexpr uint64_t COL_FAST_SN_LIMIT = ((~0ull) - (1ull << 36) - ((1ull << LB) + 16) * (W * (1ull << LB) + 16)) >> LB;
+
 // ---------------------------------------------------------------- Montgomery multiplication
 // R = A * B / 2^(29*G*W) mod M.  A: this lane's block of A (registers); B: staged in LDS as G
 // blocks of BLK words; N: this lane's block of the modulus; n1 = -M^-1 mod 2^29.
@@ -131,18 +148,20 @@ __device__ __forceinline__ void lds_store_block(uint32_t* p, const uint32_t (&v)
 // lane adds N_j*q, then the bottom column is finished: its low 29 bits go to lane j-1 (one DPP
 // move) where they open a fresh top column, its high bits carry into the next column.  Only
 // ONE column is normalised per sub-step and no carry flag is ever used: 2W v_mad_u64_u32 per
-// ~9 other VALU instructions.  The window is a circular register file: after W sub-steps
+// ~6 other VALU instructions.  The window is a circular register file: after W sub-steps
 // (fully unrolled) the register assignment repeats, so the loop over blocks stays rolled.
 //
 // ORUP = true: the caller passes N := M~ = M * n1 (a multiple of M with M~ == -1 mod 2^29, Orup's trick):
 // the quotient digit is then just the low limb of the bottom column, one multiply less per sub-step.  The
 // result is correct modulo M (not reduced below M~): used inside exponentiation ladders only.
-template <int G, bool ORUP = false>
+// SAFE: see "column capacity" above (no effect for W <= 31).
+template <int G, bool ORUP = false, bool SAFE = true>
 __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W], const uint32_t* ldsB,
                                         const uint32_t (&N)[W], uint32_t n1, int gl) {
   uint64_t c[W];
 #pragma unroll
   for (int k = 0; k < W; k++) c[k] = 0;
+  [[maybe_unused]] uint64_t sink;   // carry-out operand of the explicit v_mad_u64_u32 below (never set: the sums stay below 2^64)
 
 #pragma unroll 1
   for (int s = 0; s < G; s++) {
@@ -157,6 +176,13 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
       const uint64_t v = c[t];
       c[(t + 1) % W] += v >> LB;
       c[t] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+      if constexpr (SAFE && COL_NEEDS_CARE) {
+        constexpr int H = W / 2;
+        const uint32_t hi = (uint32_t)(c[(t + H) % W] >> 32);
+        // (written as the instruction: the compiler would expand hi * 8 into a 64-bit shift-and-add over a temporary register pair)
+        asm("v_mad_u64_u32 %0, %1, %2, 8, %0" : "+v"(c[(t + H + 1) % W]), "=s"(sink) : "v"(hi));
+        c[(t + H) % W] &= 0xFFFFFFFFull;
+      }
     }
   }
 

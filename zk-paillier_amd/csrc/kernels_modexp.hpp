@@ -21,35 +21,56 @@ template <int G> struct ConstLayout {
 };
 
 // ---- per-group LDS carve-up (uint32 words)
+// Compact layout of the hot kernels (k_enc, k_modexp, k_modmul, k_ck_check: 256-thread workgroups, two per CU): only what
+// a Montgomery product needs stays resident per group — the staged B operand.  The two conversion areas are transient:
+// `words` (32-bit word staging of a value on its way in or out) and `scr` (29-bit limb scratch of words_from_limbs), and
+// `scr` ALIASES the B operand: it is only written by the final conversion of a result, when no product is pending.
+// Exponents are read from global memory (one window per 5-6 products), never staged.
+//   W = 36: G = 4 -> 1152 B per group, 72 KB per workgroup of 64 groups: two workgroups fill the 160 KB of a CU.
 template <int G> struct LdsLayout {
   static constexpr int L = Geo<G>::L;
   static constexpr int NW = (L / 72) * 64;               // 32-bit words of the modulus width (2048/4096/8192 bits)
   static constexpr int OFF_B = 0;                        // B operand blocks           [G*BLK]
-  static constexpr int OFF_WORDS = OFF_B + G * BLK;       // 32-bit word staging        [NW+8]
-  static constexpr int OFF_SCR = OFF_WORDS + NW + 8;      // 29-bit limb scratch        [L+8]
-  static constexpr int OFF_EXP = OFF_SCR + L + 8;         // exponent words             [NW+8]
-  static constexpr int WORDS = ((OFF_EXP + NW + 8 + 3) / 4) * 4;   // 16-byte multiple
-  static constexpr int GROUPS_PER_BLOCK = 256 / G;
+  static constexpr int OFF_SCR = 0;                      // 29-bit limb scratch        [L+8]   (aliases B)
+  static constexpr int OFF_WORDS = (G * BLK > L + 8 ? G * BLK : L + 8);   // 32-bit word staging [NW+8]
+  static constexpr int WORDS = ((OFF_WORDS + NW + 8 + 3) / 4) * 4;   // 16-byte multiple
+  static constexpr int THREADS = 256;
+  static constexpr int GROUPS_PER_BLOCK = THREADS / G;
+  static constexpr int BYTES_PER_BLOCK = WORDS * 4 * GROUPS_PER_BLOCK;
+};
+// Full layout of the kernels that are not throughput critical (k_setup, k_range_responses): all four areas separate,
+// 64-thread workgroups so that a workgroup's LDS stays small whatever G is.
+template <int G> struct LdsLayoutFull {
+  static constexpr int L = Geo<G>::L;
+  static constexpr int NW = (L / 72) * 64;
+  static constexpr int OFF_B = 0;
+  static constexpr int OFF_WORDS = OFF_B + G * BLK;
+  static constexpr int OFF_SCR = OFF_WORDS + NW + 8;
+  static constexpr int OFF_EXP = OFF_SCR + L + 8;         // a second word area (modulus words in set-up, sums in k_range_responses)
+  static constexpr int WORDS = ((OFF_EXP + NW + 8 + 3) / 4) * 4;
+  static constexpr int THREADS = 64;
+  static constexpr int GROUPS_PER_BLOCK = THREADS / G;
   static constexpr int BYTES_PER_BLOCK = WORDS * 4 * GROUPS_PER_BLOCK;
 };
 
-template <int G> struct Grp {
+template <int G, class LL = LdsLayout<G>> struct Grp {
+  using Layout = LL;
   uint32_t N[W];
   uint32_t n1;       // -M^-1 mod 2^29
   int gl;            // lane inside the group
   uint32_t* lds;     // group's LDS base
-  __device__ __forceinline__ uint32_t* B() const { return lds + LdsLayout<G>::OFF_B; }
-  __device__ __forceinline__ uint32_t* words() const { return lds + LdsLayout<G>::OFF_WORDS; }
-  __device__ __forceinline__ uint32_t* scr() const { return lds + LdsLayout<G>::OFF_SCR; }
-  __device__ __forceinline__ uint32_t* expw() const { return lds + LdsLayout<G>::OFF_EXP; }
+  __device__ __forceinline__ uint32_t* B() const { return lds + LL::OFF_B; }
+  __device__ __forceinline__ uint32_t* words() const { return lds + LL::OFF_WORDS; }
+  __device__ __forceinline__ uint32_t* scr() const { return lds + LL::OFF_SCR; }
+  __device__ __forceinline__ uint32_t* expw() const { return lds + LL::OFF_EXP; }     // full layout only
 };
 
-template <int G> __device__ __forceinline__ void grp_init(Grp<G>& g, uint32_t* lds_base) {
+template <int G, class LL> __device__ __forceinline__ void grp_init(Grp<G, LL>& g, uint32_t* lds_base) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   g.gl = lane & (G - 1);
   const int gib = wave * (64 / G) + lane / G;   // group in block
-  g.lds = lds_base + gib * LdsLayout<G>::WORDS;
+  g.lds = lds_base + gib * LL::WORDS;
 }
 
 template <int G> __device__ __forceinline__ void load_limbs_global(uint32_t (&v)[W], const uint32_t* p, int gl) {
@@ -61,48 +82,41 @@ template <int G> __device__ __forceinline__ void store_limbs_global(uint32_t* p,
   for (int k = 0; k < W; k++) p[gl * W + k] = v[k];
 }
 
-template <int G> __device__ __forceinline__ void load_modulus_consts(Grp<G>& g, const uint32_t* cst) {
+template <int G, class LL> __device__ __forceinline__ void load_modulus_consts(Grp<G, LL>& g, const uint32_t* cst) {
   using CL = ConstLayout<G>;
   load_limbs_global<G>(g.N, cst + CL::OFF_N, g.gl);
   g.n1 = cst[CL::OFF_NI];
 }
 
 // stage the B operand (this lane's block) into LDS
-template <int G> __device__ __forceinline__ void stageB(const Grp<G>& g, const uint32_t (&v)[W]) {
+template <int G, class LL> __device__ __forceinline__ void stageB(const Grp<G, LL>& g, const uint32_t (&v)[W]) {
   wave_lds_fence();
   lds_store_block(g.B() + g.gl * BLK, v);
   wave_lds_fence();
 }
 
-template <int G> __device__ __forceinline__ void mm(const Grp<G>& g, uint32_t (&R)[W], const uint32_t (&A)[W]) {
-  montmul<G, false>(R, A, g.B(), g.N, g.n1, g.gl);
+// general product (not on the ladders): modulus operand M itself, the SAFE column handling (bigint29.hpp)
+template <int G, class LL> __device__ __forceinline__ void mm(const Grp<G, LL>& g, uint32_t (&R)[W], const uint32_t (&A)[W]) {
+  montmul<G, false, true>(R, A, g.B(), g.N, g.n1, g.gl);
 }
-// ladder variant: NT = this lane's block of M~ (ConstLayout::OFF_MT)
-template <int G> __device__ __forceinline__ void mmo(const Grp<G>& g, const uint32_t (&NT)[W], uint32_t (&R)[W], const uint32_t (&A)[W]) {
-  montmul<G, true>(R, A, g.B(), NT, 1u, g.gl);
-}
-
 // cooperative copy of `nwords` 32-bit words global -> LDS words area, zero padded to NW+8
-template <int G> __device__ __forceinline__ void fetch_words(const Grp<G>& g, uint32_t* dst, const uint32_t* src, int nwords) {
-  constexpr int NW = LdsLayout<G>::NW;
+template <int G, class LL> __device__ __forceinline__ void fetch_words(const Grp<G, LL>& g, uint32_t* dst, const uint32_t* src, int nwords) {
+  constexpr int NW = LL::NW;
   wave_lds_fence();
   for (int w = g.gl; w < NW + 8; w += G) dst[w] = (w < nwords) ? src[w] : 0u;
   wave_lds_fence();
 }
 
 // value (32-bit words in global memory) -> this lane's limbs
-template <int G> __device__ __forceinline__ void load_value(const Grp<G>& g, uint32_t (&v)[W], const uint32_t* src, int nwords) {
+template <int G, class LL> __device__ __forceinline__ void load_value(const Grp<G, LL>& g, uint32_t (&v)[W], const uint32_t* src, int nwords) {
   fetch_words<G>(g, g.words(), src, nwords);
   limbs_from_words(v, g.words(), g.gl);
 }
 
-// Exact canonical residue of a Montgomery-domain-free value x <= M (limbs almost normalised):
-// normalise exactly, convert to NW words in LDS words(), and map x == M to 0.
-// Afterwards words()[0..NW) holds the canonical value (visible to the whole group).
-template <int G> __device__ __forceinline__ void canonical_words(const Grp<G>& g, uint32_t (&x)[W], const uint32_t* /*cstN: global N29, unused (g.N holds it)*/) {
-  constexpr int NW = LdsLayout<G>::NW;
+// Exact canonical residue of a Montgomery-domain-free value x <= M (limbs almost normalised), as limbs:
+// normalise exactly and map x == M to 0 (x <= M is guaranteed by the caller: x = montmul(., 1)).
+template <int G, class LL> __device__ __forceinline__ void canonical_limbs(const Grp<G, LL>& g, uint32_t (&x)[W]) {
   normalize_exact<G>(x, g.gl);
-  // x == M ?  (x <= M is guaranteed by the caller: x = montmul(., 1))
   bool eq = true;
 #pragma unroll
   for (int k = 0; k < W; k++) eq = eq && (x[k] == g.N[k]);
@@ -114,71 +128,84 @@ template <int G> __device__ __forceinline__ void canonical_words(const Grp<G>& g
 #pragma unroll
     for (int k = 0; k < W; k++) x[k] = 0;
   }
-  words_from_limbs<G, NW>(g.words(), g.scr(), x, g.gl);
+}
+// ... and as NW 32-bit words in LDS words() (visible to the whole group).  Clobbers scr(), which in the compact layout
+// is the B operand: only for results, when no product is pending.
+template <int G, class LL> __device__ __forceinline__ void canonical_words(const Grp<G, LL>& g, uint32_t (&x)[W], const uint32_t* /*cstN: global N29, unused (g.N holds it)*/) {
+  canonical_limbs<G>(g, x);
+  words_from_limbs<G, LL::NW>(g.words(), g.scr(), x, g.gl);
 }
 
 // ------------------------------------------------------------------------------------------
-// Exponentiation ladders.  In: X = base in Montgomery form (regs), exponent words in g.expw()
-// (valid words + zero padding).  Out: X = base^exp in Montgomery form (value < 2M~), also staged in B().
+// Exponentiation ladders.  In: X = base in Montgomery form (regs); the exponent words stay in global memory.  Out: X = base^exp in Montgomery form (value < 2M~), also staged in B().
 // tab: this group's TAB*L-word table in global memory; cst: the modulus' constant record.
 // Both ladders run on M~ (Orup), work IN PLACE on X (the B operand of every product is the staged copy of X
 // in LDS, so a table product just loads the table entry over X's registers) and keep ONE montmul call site
 // in their main loop.
 
-// in-place product on the Orup multiple: X = X * B() / R
-template <int G> __device__ __forceinline__ void mmo_ip(const Grp<G>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
-  montmul<G, true>(X, X, g.B(), NT, 1u, g.gl);
+// in-place product on the Orup multiple: X = X * B() / R.  SAFE selects the column handling (bigint29.hpp "column capacity"):
+// the fast product is exact whenever the key's M~ passed the digit-sum test of k_setup (ConstLayout::OFF_ST + 1).
+template <int G, bool SAFE, class LL> __device__ __forceinline__ void mmo_ip(const Grp<G, LL>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
+  montmul<G, true, SAFE>(X, X, g.B(), NT, 1u, g.gl);
 }
 
 // (a) per-item exponents (sigma^n mod n with a different n per proof, DLog): fixed 5-bit windows, uniform
-//     control flow whatever the exponents are.  1.2 t + 30 products.
-template <int G>
-__device__ __forceinline__ void powm_fixed(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst) {
+//     control flow whatever the exponents are.  1.2 t + 30 products, ONE montmul call site: the table T[0] = R mod M
+//     (Montgomery one), T[1] = X, T[k] = T[k-1]*X is built by the first TAB-2 rounds of the same loop that then runs
+//     (nwin-1) rounds of [5 squarings, 1 table product].
+template <int G, bool SAFE, class LL>
+__device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst,
+                                           const uint32_t* __restrict__ ew /* exponent words in GLOBAL memory, exp_bits/32 of them */) {
   using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
   uint32_t NT[W];
   load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
-  // table: T[0] = R mod M (Montgomery one), T[1] = X, T[k] = T[k-1]*X  (B() = X throughout)
   {
     uint32_t T[W];
     load_limbs_global<G>(T, cst + CL::OFF_R1, g.gl);
     store_limbs_global<G>(tab, T, g.gl);
   }
   store_limbs_global<G>(tab + L, X, g.gl);
-  stageB<G>(g, X);
-#pragma unroll 1
-  for (int e = 2; e < TAB; e++) {
-    mmo_ip<G>(g, NT, X);
-    store_limbs_global<G>(tab + e * L, X, g.gl);
-  }
-  const uint32_t* ew = g.expw();
-  const int nwin = (exp_bits + WIN - 1) / WIN;
+  stageB<G>(g, X);                                  // B() = X throughout the table rounds
+  const int nwin = (exp_bits + WIN - 1) / WIN, ewords = exp_bits >> 5;
+  // one window every WIN + 1 products: two words straight from global memory (the same address for every lane of the group)
   auto window = [&](int wi) -> int {
     const int bit = wi * WIN;
     const int w0 = bit >> 5, off = bit & 31;
-    const uint64_t x = (uint64_t)ew[w0] | ((uint64_t)ew[w0 + 1] << 32);
+    const uint64_t x = (uint64_t)ew[w0] | ((uint64_t)(w0 + 1 < ewords ? ew[w0 + 1] : 0u) << 32);
     return (int)((x >> off) & (TAB - 1));
   };
+  constexpr int TROUNDS = TAB - 2;
+  const int total = TROUNDS + (nwin - 1) * (WIN + 1);
   // the table stores of this lane are re-read by this lane only: program order suffices
-  load_limbs_global<G>(X, tab + window(nwin - 1) * L, g.gl);
-  stageB<G>(g, X);
-  // (nwin-1) rounds of [5 squarings, 1 table product] as one loop with one montmul call site
 #pragma unroll 1
-  for (int step = 0; step < (nwin - 1) * (WIN + 1); step++) {
-    if (step % (WIN + 1) == WIN) load_limbs_global<G>(X, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
-    mmo_ip<G>(g, NT, X);
-    stageB<G>(g, X);
+  for (int i = 0; i < total; i++) {
+    const int step = i - TROUNDS;
+    if (step >= 0 && step % (WIN + 1) == WIN) load_limbs_global<G>(X, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
+    mmo_ip<G, SAFE>(g, NT, X);
+    if (step < 0) {
+      store_limbs_global<G>(tab + (i + 2) * L, X, g.gl);
+      if (i == TROUNDS - 1) { load_limbs_global<G>(X, tab + window(nwin - 1) * L, g.gl); stageB<G>(g, X); }
+    } else {
+      stageB<G>(g, X);
+    }
   }
 }
 
 // (b) ONE exponent for the whole launch (Paillier Enc under a shared key: exponent n): sliding windows of
-//     up to 6 bits over a table of the 32 odd powers.  The schedule depends on the exponent only; it is
-//     computed once per launch by k_sliding_schedule and read here as one byte per product:
-//       0x80|e  first op: X = tab[e]          0x00  square          0x40|e  multiply by tab[e] = X0^(2e+1)
-//       0xFE    exponent is zero: X = R1       0xFF  end
+//     up to 6 bits over a table of the 32 odd powers tab[e] = X0^(2e+1).  The whole ladder, table construction included, is a
+//     script that depends on the exponent only; k_sliding_schedule writes it once per launch, one byte per step
+//     (type in the upper 3 bits, table index e in the lower 5), and ONE loop with ONE montmul call site executes it:
+//       0x60     X = X * B ; B = X ; X = tab[0]        (X0^2, staged as the multiplier of the table rounds)
+//       0x20|e   X = X * B ; tab[e] = X                (table rounds e = 1..31)
+//       0x80|e   X = tab[e] ; B = X                    (first window, no product)
+//       0x00     X = X * B ; B = X                     (square)
+//       0x40|e   X = tab[e] ; X = X * B ; B = X        (multiply the running value, still staged, by X0^(2e+1))
+//       0xFE     exponent is zero: X = R1              0xFF  end
 //     ~ t + t/7 + 33 products.
 constexpr int SWIN = 6;
-constexpr uint8_t OP_END = 0xFF, OP_ZERO = 0xFE, OP_FIRST = 0x80, OP_MUL = 0x40;
+constexpr uint8_t OP_END = 0xFF, OP_ZERO = 0xFE, OP_FIRST = 0x80, OP_MUL = 0x40, OP_TAB = 0x20, OP_SQ0 = 0x60;
+constexpr int SCHED_BYTES_PER_EXP_BIT = 2, SCHED_EXTRA_BYTES = 128;
 
 __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int exp_bits, uint8_t* __restrict__ ops) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -186,6 +213,8 @@ __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int e
   int n = 0, i = exp_bits - 1;
   while (i >= 0 && !bit(i)) i--;
   if (i < 0) { ops[0] = OP_ZERO; ops[1] = OP_END; return; }
+  ops[n++] = OP_SQ0;
+  for (int e = 1; e < TAB; e++) ops[n++] = (uint8_t)(OP_TAB | e);
   bool started = false;
   while (i >= 0) {
     if (!bit(i)) { ops[n++] = 0; i--; continue; }
@@ -200,55 +229,52 @@ __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int e
   ops[n] = OP_END;
 }
 
-template <int G>
-__device__ __forceinline__ void powm_sliding(const Grp<G>& g, uint32_t (&X)[W], const uint8_t* __restrict__ ops, uint32_t* tab, const uint32_t* cst) {
+template <int G, bool SAFE, class LL>
+__device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[W], const uint8_t* __restrict__ ops, uint32_t* tab, const uint32_t* cst) {
   using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
   static_assert((1 << (SWIN - 1)) == TAB, "table size");
   uint32_t NT[W];
   load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
-  // odd powers: tab[e] = X0^(2e+1);  X0^2 staged in B() while the table is built
-  store_limbs_global<G>(tab, X, g.gl);
-  stageB<G>(g, X);
-  {
-    uint32_t S[W];
-#pragma unroll
-    for (int k = 0; k < W; k++) S[k] = X[k];
-    mmo_ip<G>(g, NT, S);
-    stageB<G>(g, S);
-  }
-#pragma unroll 1
-  for (int e = 1; e < TAB; e++) {
-    mmo_ip<G>(g, NT, X);
-    store_limbs_global<G>(tab + e * L, X, g.gl);
-  }
-  int i = 0;
   int op = __builtin_amdgcn_readfirstlane((int)ops[0]);
   if (op == OP_ZERO) {
     load_limbs_global<G>(X, cst + CL::OFF_R1, g.gl);
     stageB<G>(g, X);
     return;
   }
-  load_limbs_global<G>(X, tab + (op & (TAB - 1)) * L, g.gl);     // OP_FIRST
+  store_limbs_global<G>(tab, X, g.gl);
   stageB<G>(g, X);
 #pragma unroll 1
-  for (i = 1;; i++) {
+  for (int i = 0;; i++) {
     op = __builtin_amdgcn_readfirstlane((int)ops[i]);
     if (op == OP_END) break;
-    if (op & OP_MUL) load_limbs_global<G>(X, tab + (op & (TAB - 1)) * L, g.gl);   // B() still holds the running value
-    mmo_ip<G>(g, NT, X);
-    stageB<G>(g, X);
+    const int type = op >> 5, e = op & (TAB - 1);
+    if (type == (OP_MUL >> 5) || type == (OP_FIRST >> 5)) load_limbs_global<G>(X, tab + e * L, g.gl);   // B() still holds the running value
+    if (type != (OP_FIRST >> 5)) mmo_ip<G, SAFE>(g, NT, X);
+    if (type == (OP_TAB >> 5)) store_limbs_global<G>(tab + e * L, X, g.gl);
+    else stageB<G>(g, X);
+    if (type == (OP_SQ0 >> 5)) load_limbs_global<G>(X, tab, g.gl);
   }
 }
 
-template <int G>
-__device__ __forceinline__ void powm(const Grp<G>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst, const uint8_t* sched) {
-  if (sched) powm_sliding<G>(g, X, sched, tab, cst);
-  else powm_fixed<G>(g, X, exp_bits, tab, cst);
+// The fast product needs the key's M~ to have passed k_setup's digit-sum test; a wavefront takes the fast ladder only when
+// every one of its groups may (uniform control flow; per-key batches mix keys inside a wavefront).
+template <int G, class LL>
+__device__ __forceinline__ void powm(const Grp<G, LL>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst, const uint8_t* sched,
+                                     const uint32_t* __restrict__ exp_words_global) {
+  using CL = ConstLayout<G>;
+  const bool fast = !COL_NEEDS_CARE || __all(cst[CL::OFF_ST + 1] != 0);
+  if (sched) {
+    if (fast) powm_sliding<G, false>(g, X, sched, tab, cst);
+    else powm_sliding<G, true>(g, X, sched, tab, cst);
+  } else {
+    if (fast) powm_fixed<G, false>(g, X, exp_bits, tab, cst, exp_words_global);
+    else powm_fixed<G, true>(g, X, exp_bits, tab, cst, exp_words_global);
+  }
 }
 
 // B() := the integer 1
-template <int G> __device__ __forceinline__ void stage_one(const Grp<G>& g) {
+template <int G, class LL> __device__ __forceinline__ void stage_one(const Grp<G, LL>& g) {
   uint32_t one[W];
 #pragma unroll
   for (int k = 0; k < W; k++) one[k] = 0;
@@ -260,13 +286,13 @@ template <int G> __device__ __forceinline__ void stage_one(const Grp<G>& g) {
 // Set-up: one group per modulus.  src: modulus words (src_words each, stride src_stride words);
 // square != 0: the modulus is src^2 (Paillier n -> n^2; src_words = NW/2).
 template <int G>
-__global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src, uint64_t src_stride, int src_words, int square,
-                                               uint64_t count, uint32_t* __restrict__ consts, uint32_t* __restrict__ bad_flag) {
+__global__ void __launch_bounds__(LdsLayoutFull<G>::THREADS) k_setup(const uint32_t* __restrict__ src, uint64_t src_stride, int src_words, int square,
+                                                                     uint64_t count, uint32_t* __restrict__ consts, uint32_t* __restrict__ bad_flag) {
   using CL = ConstLayout<G>;
-  using LL = LdsLayout<G>;
+  using LL = LdsLayoutFull<G>;
   constexpr int L = Geo<G>::L, NW = LL::NW, CAP = Geo<G>::CAPBITS;
   extern __shared__ __align__(16) uint32_t lds_raw[];
-  Grp<G> g;
+  Grp<G, LL> g;
   grp_init<G>(g, lds_raw);
   const uint64_t gid = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
   const uint64_t item = gid < count ? gid : count - 1;   // idle groups redo the last modulus (keeps wave ops uniform)
@@ -383,6 +409,13 @@ __global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src,
     load_value<G>(g, nl, ms, src_words);     // overwrites words(): modulus words no longer needed
     mm<G>(g, NR, nl);                        // B() holds R2
   }
+  // may the ladders use the fast W = 36 product with this M~ ?  (bigint29.hpp "column capacity": every lane's limb sum)
+  uint64_t sn = 0;
+#pragma unroll
+  for (int k = 0; k < W; k++) sn += MT[k];
+  const int lane = threadIdx.x & 63;
+  const unsigned long long gmk = ((1ull << G) - 1) << (lane & ~(G - 1));
+  const bool fast_ok = (__ballot(sn <= COL_FAST_SN_LIMIT) & gmk) == gmk;
   if (gid < count) {
     store_limbs_global<G>(cst + CL::OFF_N, g.N, g.gl);
     store_limbs_global<G>(cst + CL::OFF_R2, X, g.gl);
@@ -392,6 +425,7 @@ __global__ void __launch_bounds__(256) k_setup(const uint32_t* __restrict__ src,
     if (g.gl == 0) {
       cst[CL::OFF_NI] = g.n1;
       cst[CL::OFF_ST] = (uint32_t)status;
+      cst[CL::OFF_ST + 1] = fast_ok ? 1u : 0u;
       if (status && bad_flag) atomicOr(bad_flag, (uint32_t)status);
     }
   }
@@ -425,7 +459,6 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
   grp_init<G>(g, lds_raw);
   const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
   uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
-  const int exp_words = a.exp_bits / 32;
   // wavefronts claim 64/G consecutive items at a time; surplus groups recompute the last item and skip the store
   const int lane = threadIdx.x & 63;
   for (;;) {
@@ -439,14 +472,12 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
     const uint32_t* cst = a.consts + item * a.const_stride;
     load_modulus_consts<G>(g, cst);
     uint32_t X[W], R[W], T[W];
-    // exponent words -> LDS
-    fetch_words<G>(g, g.expw(), a.exp + item * a.exp_stride, exp_words);
     // base -> Montgomery form: X = base * R2 / R
     load_value<G>(g, T, a.base + item * a.io_words, a.io_words);
     load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
     stageB<G>(g, X);
     mm<G>(g, X, T);
-    powm<G>(g, X, a.exp_bits, tab, cst, a.sched);
+    powm<G>(g, X, a.exp_bits, tab, cst, a.sched, a.exp + item * a.exp_stride);
     // leave the Montgomery domain: montmul(X, 1) <= M
     stage_one<G>(g);
     mm<G>(g, R, X);
@@ -533,7 +564,7 @@ struct EncArgs {
 };
 
 // stage a constant (this lane's block of a limb array in global memory) as the B operand
-template <int G> __device__ __forceinline__ void stage_const(const Grp<G>& g, const uint32_t* limbs) {
+template <int G, class LL> __device__ __forceinline__ void stage_const(const Grp<G, LL>& g, const uint32_t* limbs) {
   uint32_t t[W];
   load_limbs_global<G>(t, limbs, g.gl);
   stageB<G>(g, t);
@@ -552,7 +583,7 @@ template <int G>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
-  constexpr int L = Geo<G>::L, NW = LL::NW;
+  constexpr int L = Geo<G>::L;
   extern __shared__ __align__(16) uint32_t lds_raw[];
   Grp<G> g;
   grp_init<G>(g, lds_raw);
@@ -610,14 +641,13 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
     const uint32_t* pn = a.n + key * a.n_stride;
     load_modulus_consts<G>(g, cst);
     const bool valid = cst[CL::OFF_ST] == 0;
-    uint32_t X[W], Y[W], A[W], R[W];
+    uint32_t X[W], Y[W], A[W], R[W], C[W];
 #pragma unroll
-    for (int k = 0; k < W; k++) { X[k] = 0; Y[k] = 0; }
+    for (int k = 0; k < W; k++) { X[k] = 0; Y[k] = 0; C[k] = 0; }
 #pragma unroll 1
     for (int s = 0; s < nsteps; s++) {
       if (s == 1) {
-        fetch_words<G>(g, g.expw(), pn, kw);                         // exponent = n
-        powm<G>(g, X, a.n_bits, tab, cst, a.sched);
+        powm<G>(g, X, a.n_bits, tab, cst, a.sched, pn);                 // exponent = n (read from global memory by the fixed-window ladder)
         continue;
       }
       // ---- operands
@@ -647,30 +677,37 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
       for (int k = 0; k < W; k++) Y[k] = R[k];
       if (s == 2 && g.gl == 0) Y[0] += 1;                              // gm = 1 + m*n (limb 0 stays < 2^29 + 17)
       if (s == 5) {
-        canonical_words<G>(g, Y, cst + CL::OFF_N);                     // words()[0..NW) = c
         if (a.mode == 0) {
+          canonical_words<G>(g, Y, cst + CL::OFF_N);                   // words()[0..NW) = c
           if (live) for (int w = g.gl; w < 2 * kw; w += G) a.out[item * 2 * kw + w] = valid ? g.words()[w] : 0u;
         } else {
-          // keep c in the (now free) exponent area for the final comparison
-          wave_lds_fence();
-          for (int w = g.gl; w < NW; w += G) g.expw()[w] = g.words()[w];
-          wave_lds_fence();
+          canonical_limbs<G>(g, Y);                                    // keep c (exact limbs of the canonical residue) for the final comparison
+#pragma unroll
+          for (int k = 0; k < W; k++) C[k] = Y[k];
         }
       }
       if (s == 9) {
-        canonical_words<G>(g, Y, cst + CL::OFF_N);                     // words() = canonical residue of the expected value
-        // The reference compares c with c_j[i] itself on Open rows (no reduction): a non-canonical c_j >= n^2 can
-        // never equal a residue, so besides residue equality the raw words of c_j must equal their own residue.
+        canonical_limbs<G>(g, Y);                                      // exact limbs of the canonical residue of the expected value
+        // Both sides are canonical residues in exact limb form: equal limbs <=> equal values.
+        // The reference compares c with c_j[i] ITSELF on Open rows (no reduction): a non-canonical c_j >= n^2 can never equal a
+        // residue, so besides residue equality the raw value of c_j must equal its own residue (exact limbs of the raw words).
         bool same = true;
-        for (int w = g.gl; w < NW; w += G) {
-          const uint32_t e = g.words()[w];
-          same = same && (e == g.expw()[w]);
-          if (!mask_row && w < 2 * kw) same = same && (e == pexp[w]);
+#pragma unroll
+        for (int k = 0; k < W; k++) same = same && (Y[k] == C[k]);
+        if (!mask_row) {
+          load_value<G>(g, A, pexp, 2 * kw);
+#pragma unroll
+          for (int k = 0; k < W; k++) same = same && (A[k] == Y[k]);
         }
         const unsigned long long mk = __ballot(same);
         const bool pass = valid && (mk & gmask) == gmask;
         if (a.mode == 2) { if (live && g.gl == 0) a.verdict[b] = pass ? 1 : 0; }
-        else if (live && g.gl == 0 && !pass) a.verdict[b] = ZKP_VERDICT_REJECT;
+        else if (live && g.gl == 0) {
+          // an even key is outside the engine's domain (Montgomery needs an odd modulus): every row of such a proof says
+          // MALFORMED, so that the caller can tell "not computed here" from "rejected"
+          if (!valid) a.verdict[b] = ZKP_VERDICT_MALFORMED;
+          else if (!pass) a.verdict[b] = ZKP_VERDICT_REJECT;
+        }
       }
     }
   }

@@ -182,11 +182,11 @@ struct ResponseArgs {
 };
 
 template <int G>
-__global__ void __launch_bounds__(256, ZKP_WPE) k_range_responses(ResponseArgs a) {
+__global__ void __launch_bounds__(LdsLayoutFull<G>::THREADS) k_range_responses(ResponseArgs a) {
   using CL = ConstLayout<G>;
-  using LL = LdsLayout<G>;
+  using LL = LdsLayoutFull<G>;
   extern __shared__ __align__(16) uint32_t lds_raw[];
-  Grp<G> g;
+  Grp<G, LL> g;
   grp_init<G>(g, lds_raw);
   const uint64_t rows = a.batch * a.ef;
   const uint64_t gid = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
@@ -392,12 +392,11 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
 #pragma unroll
     for (int k = 0; k < W; k++) RHO[k] = R[k];           // canonical rho limbs
     // sigma^n mod n
-    fetch_words<G>(g, g.expw(), a.n + b * kw, kw);
     load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
     stageB<G>(g, T);
     load_value<G>(g, T, a.sigma + item * kw, kw);
     mm<G>(g, X, T);
-    powm_fixed<G>(g, X, a.n_bits, tab, cst);
+    powm<G>(g, X, a.n_bits, tab, cst, nullptr, a.n + b * kw);
     stage_one<G>(g);
     mm<G>(g, R, X);
     normalize_exact<G>(R, g.gl);

@@ -173,11 +173,11 @@ template <int G, class K> static int resident_blocks(zkp_ctx* c, K kernel) {
 
 template <int G> static int32_t run_setup(zkp_ctx* c, const uint32_t* src, uint64_t stride, int src_words, int square, uint64_t count, DevBuf& buf) {
   using CL = ConstLayout<G>;
-  using LL = LdsLayout<G>;
+  using LL = LdsLayoutFull<G>;
   int32_t st = ensure(c, buf, count * CL::WORDS * sizeof(uint32_t));
   if (st) return st;
   const unsigned blocks = (unsigned)((count + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK);
-  hipLaunchKernelGGL(k_setup<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, src, stride, src_words, square, count, (uint32_t*)buf.p, c->setup_flag);
+  hipLaunchKernelGGL(k_setup<G>, dim3(blocks), dim3(LL::THREADS), LL::BYTES_PER_BLOCK, c->stream, src, stride, src_words, square, count, (uint32_t*)buf.p, c->setup_flag);
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
 }
@@ -197,7 +197,7 @@ static int32_t read_setup_flag(zkp_ctx* c, bool* any_bad) {
 // sliding-window schedule for a launch-uniform exponent (device resident, ctx scratch slot 15)
 static int32_t build_schedule(zkp_ctx* c, const uint32_t* exp_words, uint32_t exp_bits, const uint8_t** out) {
   DevBuf& b = c->scratch[15];
-  int32_t st = ensure(c, b, (size_t)exp_bits + 64);
+  int32_t st = ensure(c, b, (size_t)exp_bits * SCHED_BYTES_PER_EXP_BIT + SCHED_EXTRA_BYTES);
   if (st) return st;
   hipLaunchKernelGGL(k_sliding_schedule, dim3(1), dim3(64), 0, c->stream, exp_words, (int)exp_bits, (uint8_t*)b.p);
   HIPCHK(c, hipGetLastError());
