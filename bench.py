@@ -27,9 +27,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# measured on MI355X (profiles/valu_rates_long_r01.jsonl, 16 ms kernels so that the clock has settled):
-# v_mad_u64_u32, 16 independent accumulators, 8 waves/SIMD, 256 CUs -> 3.474e13 lane-MAC/s (4.53 cycles per wave64 issue)
-PEAK_LIMB_MAC_PER_S = 3.474e13
+# The VALU roofline is measured, the guides list no integer peak: v_mad_u64_u32, 16 independent accumulators, 8 waves/SIMD,
+# 256 CUs (csrc/microbench).  profiles/mad_sustained_r02.jsonl: kernels of 0.13 s, 1 s and 4 s all issue 3.354-3.361e13
+# lane-MAC/s (4.68 cycles per wave64 instruction at the nominal 2.4 GHz): that SUSTAINED rate is the peak the launches of this
+# bench (1.6-19 s each) are priced against.  Kernels of 16 ms read 3.474e13 (profiles/valu_rates_long_r01.jsonl; round 1 used
+# that figure), kernels of 1 ms 3.19e13: the shader clock is not constant.  Both fractions are reported.
+PEAK_LIMB_MAC_PER_S = 3.361e13
+PEAK_LIMB_MAC_PER_S_16MS_KERNELS = 3.474e13
 HBM_PEAK_GBS = 8000.0
 
 
@@ -141,7 +145,7 @@ def parse_args(argv=None):
     ap.add_argument("--big-batch", type=int, default=4096, help="proofs of the n=4096 leg (configs[4]); 0 = skip")
     ap.add_argument("--distinct-batch", type=int, default=4096, help="proofs of the distinct-keys leg (SURVEY 8(d) config 3); 0 = skip")
     ap.add_argument("--no-pcie-leg", action="store_true")
-    ap.add_argument("--pmc-shape", choices=["enc8", "enc16", "ck4"], default=None,
+    ap.add_argument("--pmc-shape", choices=["enc2048", "enc4096", "ck2048"], default=None,
                     help="run ONE short launch shape only (for rocprofv3 --pmc passes, profiles/collect_pmc.sh)")
     return ap.parse_args(argv)
 
@@ -216,6 +220,8 @@ def main():
         per_launch = modexps / max(launches, 1)
         bytes_per_enc = 4 * (nb // 32) * 4 + 8          # r, m (kw words each) + expected ciphertext (2kw) + 8 B work item
         return {"bound": "valu", "achieved": ach / 1e12, "peak": PEAK_LIMB_MAC_PER_S / 1e12, "unit": "Tlimb-MAC/s", "frac": ach / PEAK_LIMB_MAC_PER_S,
+                "peak_note": "sustained v_mad_u64_u32 issue rate measured with 1-4 s kernels (profiles/mad_sustained_r02.jsonl)",
+                "frac_vs_16ms_kernel_peak": ach / PEAK_LIMB_MAC_PER_S_16MS_KERNELS, "peak_16ms_kernels": PEAK_LIMB_MAC_PER_S_16MS_KERNELS / 1e12,
                 "traffic": per * per_launch if per else None,
                 "traffic_note": (f"bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 per Enc from {src} (separate rocprofv3 --pmc passes of this build; FETCH_SIZE doubled "
                                  f"per the guide's gfx950 note) x Enc of the launch; algorithmic operand bytes are ~{bytes_per_enc} B per Enc" if per else
@@ -443,10 +449,10 @@ def other_configs(args, ctx, synth, torch, dev, sync, pb, wt, rank, enc_roofline
 def run_pmc_shape(args, ctx, synth, torch, dev, sync):
     """ONE dominant-kernel launch of a fixed, small shape; prints the modexp count of that launch (stdout, JSON)"""
     shape = args.pmc_shape
-    if shape in ("enc8", "enc16"):
-        nb = 2048 if shape == "enc8" else 4096
-        Bx = 512 if shape == "enc8" else 128
-        nkey = synth.BENCH_N if shape == "enc8" else synth.bench_key_4096()[2]
+    if shape in ("enc2048", "enc4096"):
+        nb = 2048 if shape == "enc2048" else 4096
+        Bx = 512 if shape == "enc2048" else 128
+        nkey = synth.BENCH_N if shape == "enc2048" else synth.bench_key_4096()[2]
         pbx, wtx = synth.synth_range_inputs(nkey, nb, Bx, seed=5, device=dev)
         sync()
         ctx.paillier_enc(nb, Bx, pbx.n, 0, wtx.x, wtx.r, pbx.ciphertext); sync()

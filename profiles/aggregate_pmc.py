@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Sum the rocprofv3 --pmc passes written by profiles/collect_pmc.sh per kernel and derive the per-Enc figures quoted in
-DESIGN.md section 8:  python profiles/aggregate_pmc.py <dir with pass*/...counter_collection.csv> <modexps in the k_enc dispatches>"""
+"""Sum the rocprofv3 --pmc passes written by profiles/collect_pmc.sh per kernel and derive the per-modexp figures quoted in
+DESIGN.md and read by bench.py (`roofline.traffic`):
+    python profiles/aggregate_pmc.py <dir with pass*/...counter_collection.csv> <kernel name substring, e.g. "k_enc<4>"> [modexps]
+modexps = exponentiations done by ALL dispatches of that kernel in one pass (default: "all_modexps_of_the_kernel" of <dir>/shape.json)."""
 import csv
 import glob
 import json
@@ -10,8 +12,11 @@ from collections import defaultdict
 
 
 def main():
-    root = sys.argv[1]
-    modexps = float(sys.argv[2]) if len(sys.argv) > 2 else None
+    root, kernel = sys.argv[1], sys.argv[2]
+    if len(sys.argv) > 3:
+        modexps = float(sys.argv[3])
+    else:
+        modexps = float(json.load(open(os.path.join(root, "shape.json")))["all_modexps_of_the_kernel"])
     agg = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(set)
     for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
@@ -28,12 +33,13 @@ def main():
         passes = len({f for f, _ in disp[k]})
         rec["dispatches"] = len(disp[k]) // max(passes, 1)
         out[k] = rec
-    enc = next((k for k in out if "k_enc<8>" in k), None)
-    if enc and modexps:
-        r = out[enc]
-        d = {"modexps_in_these_dispatches": modexps}
+    name = next((k for k in out if kernel in k), None)
+    if name and modexps:
+        r = out[name]
+        lanes = 64 // int(kernel.split("<")[1].split(">")[0]) if "<" in kernel else 1      # modexps per wavefront
+        d = {"modexps_in_these_dispatches": modexps, "modexps_per_wavefront": lanes}
         if "SQ_INSTS_VALU" in r:
-            d["valu_wave_instr_per_wave_modexp (8 modexps per wave)"] = r["SQ_INSTS_VALU"] / (modexps / 8)
+            d["valu_wave_instr_per_wave_modexp"] = r["SQ_INSTS_VALU"] / (modexps / lanes)
             if "GRBM_GUI_ACTIVE" in r:   # summed over the 8 XCDs: x 1024 SIMDs / 8 = busy cycles of all SIMDs
                 d["simd_cycles_per_valu_instr"] = r["GRBM_GUI_ACTIVE"] * 128 / r["SQ_INSTS_VALU"]
             d["valu_active_fraction_of_wave_cycles"] = r["SQ_ACTIVE_INST_VALU"] / r["SQ_WAVE_CYCLES"]
@@ -41,6 +47,8 @@ def main():
             d["fetch_bytes_per_modexp (FETCH_SIZE in KB x 1024, uncorrected)"] = r["FETCH_SIZE"] * 1024 / modexps
         if "WRITE_SIZE" in r:
             d["write_bytes_per_modexp (WRITE_SIZE in KB x 1024)"] = r["WRITE_SIZE"] * 1024 / modexps
+        if "FETCH_SIZE" in r and "WRITE_SIZE" in r:
+            d["hbm_bytes_per_modexp (gfx950 correction: 2 x FETCH_SIZE + WRITE_SIZE)"] = (2 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024 / modexps
         if "SQ_LDS_BANK_CONFLICT" in r and r.get("SQ_ACTIVE_INST_LDS"):
             d["lds_bank_conflict_cycles_over_lds_active"] = r["SQ_LDS_BANK_CONFLICT"] / r["SQ_ACTIVE_INST_LDS"]
         r["_derived"] = d

@@ -233,3 +233,39 @@ def test_even_modulus_deviation_is_pinned(ctx, oracle, zkp):
     oracle.range_ni_verify(pb.struct(), vo)
     ctx.range_ni_verify(pb.struct(), vg, device=False)
     assert vo[0] == zkp.VERDICT_ACCEPT and vg[0] == zkp.VERDICT_MALFORMED
+
+
+def test_structured_moduli_safe_and_fast_products(ctx, oracle):
+    """W = 36: keys whose Orup multiple has lanes full of large digits fail k_setup's digit-sum test and run the SAFE Montgomery
+    product (csrc/bigint29.hpp "column capacity"); operands with every digit at its maximum are the worst case for the FAST one.
+    Both against the oracle, shared key (sliding-window ladder) and per-item keys (fixed windows, mixed in one wavefront)."""
+    d = pm.Drbg(b"structured-moduli")
+    # --- modexp, 2048 and 4096 bits: all-ones style moduli and bases / exponents of all ones
+    for bits in (2048, 4096):
+        nl = bits // 32
+        mods = [(1 << bits) - 1, (1 << (bits - 1)) - 1, (1 << bits) - (1 << (bits // 2)) - 1, ((1 << bits) - 1) // 3 | 1,
+                d.bits(bits) | 1 | (1 << (bits - 1)), (1 << bits) - 1 - (1 << 29), int("f" * (bits // 4 - 9) + "e" + "f" * 8, 16)]
+        count = len(mods)
+        bases = [(1 << bits) - 2, (1 << (bits - 1)) - 2, d.bits(bits), (1 << (bits - 2)) - 1, (1 << bits) - 1, d.bits(bits), (1 << bits) - 3]
+        exps = [(1 << bits) - 1, d.bits(bits), (1 << bits) - 1, d.bits(bits), (1 << bits) - 1, d.bits(bits), d.bits(bits)]
+        b, e, m = (L.ints_to_limbs(v, nl) for v in (bases, exps, mods))
+        out = np.zeros_like(b)
+        ctx.modexp(bits, bits, count, b, e, nl, m, nl, out)                      # per-item moduli
+        assert np.array_equal(out, oracle.modexp(bits, bits, b, e, nl, m, nl))
+        for i in (0, 2, 4):                                                      # each as a shared modulus with a shared exponent
+            bb = L.ints_to_limbs([bases[j] for j in range(count)], nl)
+            out = np.zeros_like(bb)
+            ctx.modexp(bits, bits, count, bb, e[i:i + 1], 0, m[i:i + 1], 0, out)
+            assert np.array_equal(out, oracle.modexp(bits, bits, bb, e[i:i + 1], 0, m[i:i + 1], 0))
+    # --- Enc under structured keys n (n^2 is the modulus): shared key and per-item keys
+    kw = 64
+    ns = [(1 << 2048) - 1, (1 << 2047) + 1, (1 << 2048) - (1 << 1024) - 1, H.fixture_key()[2], (1 << 2040) - 1, d.bits(2048) | 1 | (1 << 2047)]
+    ms = [d.bits(2048) for _ in ns]; rs = [(1 << 2048) - 1, d.bits(2048), (1 << 2047) - 1, (1 << 2048) - 1, d.bits(2048), (1 << 2048) - 1]
+    nl_, ml, rl = L.ints_to_limbs(ns, kw), L.ints_to_limbs(ms, kw), L.ints_to_limbs(rs, kw)
+    out = np.zeros((len(ns), 2 * kw), np.uint32)
+    ctx.paillier_enc(2048, len(ns), nl_, kw, ml, rl, out)
+    assert np.array_equal(out, oracle.paillier_enc(2048, nl_, kw, ml, rl))
+    for i in (0, 2, 3):
+        out = np.zeros((len(ns), 2 * kw), np.uint32)
+        ctx.paillier_enc(2048, len(ns), nl_[i:i + 1], 0, ml, rl, out)
+        assert np.array_equal(out, oracle.paillier_enc(2048, nl_[i:i + 1], 0, ml, rl))

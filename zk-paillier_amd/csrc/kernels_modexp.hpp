@@ -33,7 +33,10 @@ template <int G> struct LdsLayout {
   static constexpr int OFF_B = 0;                        // B operand blocks           [G*BLK]
   static constexpr int OFF_SCR = 0;                      // 29-bit limb scratch        [L+8]   (aliases B)
   static constexpr int OFF_WORDS = (G * BLK > L + 8 ? G * BLK : L + 8);   // 32-bit word staging [NW+8]
-  static constexpr int WORDS = ((OFF_WORDS + NW + 8 + 3) / 4) * 4;   // 16-byte multiple
+  // 16-byte multiple, and an ODD number of 16-byte units: the groups of a wavefront read their staged operand with broadcast
+  // ds_read_b128 at the same offset, so an even stride would put all of them on two bank groups (measured with G = 4 at a
+  // stride of 288 words: SQ_LDS_BANK_CONFLICT = 99 % of the LDS-active cycles, profiles/r02_pmc_enc2048_k_enc4.json)
+  static constexpr int WORDS = (((OFF_WORDS + NW + 8 + 3) / 4) | 1) * 4;
   static constexpr int THREADS = 256;
   static constexpr int GROUPS_PER_BLOCK = THREADS / G;
   static constexpr int BYTES_PER_BLOCK = WORDS * 4 * GROUPS_PER_BLOCK;
