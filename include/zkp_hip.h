@@ -314,7 +314,9 @@ int32_t zkp_limbs_to_decimal_batch(zkp_ctx* ctx, const uint32_t* src, uint64_t s
 /* serde_json documents of the reference's proof types -> the SoA batch (one document per proof, documents back to back or
  * anywhere in `text`; doc_off/doc_len [B]).  Field layout = serde defaults for the derives at range_proof.rs:32-81
  * (EncryptedPairs {"c1":[..],"c2":[..]}, Proof = [{"Open":{"w1","r1","w2","r2"}} | {"Mask":{"j","masked_x","masked_r"}} ..])
- * and correct_key_ni.rs:35-39 ({"sigma_vec":[..]}); white space between tokens is accepted (to_string_pretty).
+ * and correct_key_ni.rs:35-39 ({"sigma_vec":[..]}).  The reader is as tolerant as serde_json with the derived Deserialize impls: white
+ * space between tokens (to_string_pretty), object fields in any order, unknown fields skipped, string escapes decoded; duplicate
+ * or missing fields, a Response with more than one variant key and values of the wrong JSON type are errors, as they are for serde.
  * The tokenising runs on the host (threads), every number is converted on the GPU into p->c1/c2 (pairs) or p->resp_*
  * (proof); p->error_factor rows are expected.  out_status[b]: 0, or ZKP_VERDICT_MALFORMED when document b is not of the
  * expected shape, has another row count, or holds a number the ABI cannot carry (see ZKP_DEC_*): those proofs stay on the

@@ -82,6 +82,52 @@ static void test_batch_round_trip() {   // many provers, one key: what the GPU i
   for (int i = 0; i < 6; i++) ASSERT(res[i].is_ok() == (i != 4));
 }
 
+static void test_batch_survives_crafted_proofs() {   // over-wide prover-chosen fields: per-proof verdicts, no exception for the batch
+  auto [ek, dk] = test_keypair().keys();
+  std::vector<RangeProofNi::Statement> st;
+  for (int i = 0; i < 6; i++) {
+    BigInt range = BigInt::sample(RANGE_BITS);
+    BigInt r = BigInt::sample_below(ek.n), x = BigInt::sample_below(range.div_floor(BigInt(3)));
+    st.push_back({range, Paillier::encrypt_with_chosen_randomness(ek, x, r), x, r});
+  }
+  auto proofs = RangeProofNi::prove_batch(ek, st);
+  auto first = [](const RangeProofNi& p, Response::Kind k) { size_t i = 0; while (p.proof.responses[i].kind != k) i++; return i; };
+  const BigInt wide = BigInt::pow2(2100), wider = BigInt::pow2(4200);
+  {  // 1: masked_x wider than the key: fails the bound T <= masked_x <= 2T (range_proof.rs:338) -> Err
+    Response& m = proofs[1].proof.responses[first(proofs[1], Response::Mask)];
+    m.masked_x = m.masked_x + wide;
+  }
+  {  // 2: r1 + n * 2^80 on an Open row and masked_r + n * 2^80 on a Mask row: r^n mod n^2 only depends on r mod n -> still Ok
+    Response& o = proofs[2].proof.responses[first(proofs[2], Response::Open)];
+    o.r1 = o.r1 + ek.n * BigInt::pow2(80);
+    Response& m = proofs[2].proof.responses[first(proofs[2], Response::Mask)];
+    m.masked_r = m.masked_r + ek.n * BigInt::pow2(80);
+  }
+  {  // 3: c_j[i] + n^2 * 2^100 on a Mask row: only the product mod n^2 is used (:324-328) -> still Ok; ciphertext likewise
+    const size_t i = first(proofs[3], Response::Mask);
+    auto& cj = proofs[3].proof.responses[i].j == 1 ? proofs[3].encrypted_pairs.c1[i] : proofs[3].encrypted_pairs.c2[i];
+    cj = cj + ek.nn * BigInt::pow2(100);
+    proofs[3].ciphertext = proofs[3].ciphertext + ek.nn * wider;
+  }
+  {  // 4: c1[i] + n^2 on an Open row: compared unreduced (:293-298) -> Err;  w1 over-wide would also fail the range flag
+    const size_t i = first(proofs[4], Response::Open);
+    proofs[4].encrypted_pairs.c1[i] = proofs[4].encrypted_pairs.c1[i] + ek.nn * wider;
+  }
+  proofs[5].proof.responses.resize(100);   // 5: responses[i] for i >= 100 is an index panic in the reference (:274)
+  std::vector<const RangeProofNi*> ptr;
+  for (auto& p : proofs) ptr.push_back(&p);
+  auto res = RangeProofNi::verify_batch(ek, ptr);
+  ASSERT(res[0].is_ok());
+  ASSERT(res[1].is_err());
+  ASSERT(res[2].is_ok());
+  ASSERT(res[3].is_ok());
+  ASSERT(res[4].is_err());
+  ASSERT(res[5].would_panic());
+  bool threw = false;
+  try { (void)res[5].is_ok(); } catch (const Panic&) { threw = true; }
+  ASSERT(threw);
+}
+
 // ---- correct_key_ni.rs tests (the reference draws a fresh key with Paillier::keypair(); key generation is
 //      not on the hot path, the fixture key is used instead)
 static void test_correct_zk_proof_no_salt_str() {   // :126-130
@@ -327,6 +373,7 @@ int main() {
   run("range_proof_ni::test_verifier_for_incorrect_proof", test_verifier_for_incorrect_proof, true);
   run("range_proof_ni::verify asserts ek/ciphertext", test_verify_asserts_statement, true);
   run("range_proof_ni::batch round trip", test_batch_round_trip);
+  run("range_proof_ni::batch survives crafted proofs", test_batch_survives_crafted_proofs);
   run("correct_key_ni::test_correct_zk_proof_no_salt_str", test_correct_zk_proof_no_salt_str);
   run("correct_key_ni::test_correct_zk_proof_with_salt_str", test_correct_zk_proof_with_salt_str);
   run("wi_dlog_proof::test_correct_dlog_proof", test_correct_dlog_proof);

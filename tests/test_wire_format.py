@@ -160,7 +160,7 @@ def test_gpu_json_malformed_documents(ctx, oracle):
                 g.replace(b'"w1":"1","r1":"2"', b'"r1":"2","w1":"1"'), proof_json(resp[:3]), g.replace(b'"j":2', b'"j":"2"'), proof_json(resp, pretty=True)]
     st = np.full(B, 9, np.uint8)
     ctx.json_range_proof(variants, pg.struct(), st, device=False)
-    assert list(st) == [0, 2, 2, 2, 2, 2, 2, 0]
+    assert list(st) == [0, 2, 2, 2, 0, 2, 2, 0]          # (field order inside a Response is free, as it is for serde)
     assert list(pg.resp_kind[0]) == [0, 1, 0, 1] and list(pg.resp_j[0]) == [0, 2, 0, 1]
     assert [L.limbs_to_int(x) for x in pg.resp_w1[7]] == [1, 5, 7, 11] and [L.limbs_to_int(x) for x in pg.resp_w2[7]] == [3, 0, 9, 0]
 
@@ -182,3 +182,45 @@ def test_gpu_json_correct_key_proof(ctx, oracle):
     v = np.zeros(3, np.uint8)
     ctx.correct_key_ni_verify(n_bits, 3, n_arr, np.ascontiguousarray(out[:3]), b"KZen", v)
     assert list(v) == [1, 1, 1]
+
+
+@pytest.mark.gpu
+def test_gpu_json_reader_is_as_tolerant_as_serde(ctx):
+    """what serde_json + the derived Deserialize impls accept is accepted: fields in any order, unknown fields (any value) skipped,
+    escapes inside strings (\\uXXXX digits, escaped field names); what they refuse is refused: duplicate fields, two variant keys."""
+    n_bits, ef = 1024, 2
+    B = 8
+    c1, c2 = [123456789012345678901234567890, 7], [5, 99999999999999999999]
+    base = {"c1": [str(v) for v in c1], "c2": [str(v) for v in c2]}
+    docs = [
+        json.dumps({"c2": base["c2"], "c1": base["c1"]}),                                              # order
+        json.dumps({"zz": {"a": [1, 2.5e3, None, True, {"b": "x\\\"y"}]}, "c1": base["c1"], "note": "", "c2": base["c2"]}),   # unknown fields
+        '{"c1":["\\u0031\\u00323456789012345678901234567890","7"],"\\u0063\\u0032":["5","99999999999999999999"]}',      # escapes in a number and in a name
+        '{"c1":["123456789012345678901234567890","7"],"c2":["5","99999999999999999999"],"c1":["1","2"]}',                 # duplicate field
+        '{"c1":["123456789012345678901234567890","7"]}',                                                                    # missing field
+        '{"c1":["12345678901234567890123456789\\u0041","7"],"c2":["5","99999999999999999999"]}',                            # \u0041 = "A": not a digit
+        json.dumps(base) + " ",                                                                                             # trailing white space
+        '{"c1":["1","7"],"c2":["5","9\\"]}',                                                                                # unterminated
+    ]
+    pg = zkp.RangeBatch(n_bits, B, ef, shared_key=True)
+    st = np.full(B, 9, np.uint8)
+    ctx.json_encrypted_pairs([d.encode() for d in docs], pg.struct(), st, device=False)
+    assert list(st) == [0, 0, 0, 2, 2, 2, 0, 2]
+    for b in (0, 1, 2, 6):
+        assert [L.limbs_to_int(x) for x in pg.c1[b]] == c1 and [L.limbs_to_int(x) for x in pg.c2[b]] == c2
+    rows = [
+        '[{"Open":{"r2":"4","w2":"3","r1":"2","w1":"1"}},{"Mask":{"masked_r":"6","j":2,"masked_x":"5","extra":[]}}]',
+        '[{"Open":{"w1":"1","r1":"2","w2":"3","r2":"4"},"Mask":{"j":1,"masked_x":"5","masked_r":"6"}},{"Mask":{"j":1,"masked_x":"5","masked_r":"6"}}]',   # two variants
+        '[{"Open":{"w1":"1","r1":"2","w2":"3","r2":"4","w1":"1"}},{"Mask":{"j":1,"masked_x":"5","masked_r":"6"}}]',                                       # duplicate
+        '[{"Open":{"w1":"1","r1":"2","w2":"3","r2":"4"}},{"Mask":{"j":1.0,"masked_x":"5","masked_r":"6"}}]',                                            # j not an integer
+        '[{"Open":{"w1":"\\u0031","r1":"2","w2":"3","r2":"4"}},{"\\u004dask":{"j":0,"masked_x":"5","masked_r":"6"}}]',
+    ]
+    pr = zkp.RangeBatch(n_bits, len(rows), ef, shared_key=True)
+    st = np.full(len(rows), 9, np.uint8)
+    ctx.json_range_proof([r.encode() for r in rows], pr.struct(), st, device=False)
+    assert list(st) == [0, 2, 2, 2, 0]
+    for b in (0, 4):
+        assert list(pr.resp_kind[b]) == [0, 1]
+        assert [L.limbs_to_int(x) for x in pr.resp_w1[b]] == [1, 5] and [L.limbs_to_int(x) for x in pr.resp_r1[b]] == [2, 6]
+        assert [L.limbs_to_int(x) for x in pr.resp_w2[b]] == [3, 0] and [L.limbs_to_int(x) for x in pr.resp_r2[b]] == [4, 0]
+    assert list(pr.resp_j[0]) == [0, 2] and list(pr.resp_j[4]) == [0, 0]

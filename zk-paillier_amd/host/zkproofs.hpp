@@ -38,14 +38,20 @@ namespace zkproofs {
 struct Panic : std::runtime_error { using std::runtime_error::runtime_error; };
 struct IncorrectProof {};   // src/zkproofs/errors.rs:5-13
 
-// Result<(), IncorrectProof>
+// Result<(), IncorrectProof>.  A batch call returns one Result per proof; a proof on which the reference would have
+// PANICKED (index out of bounds, assert) carries that panic and throws it when it is looked at, so that one crafted proof
+// cannot take the verdicts of the others with it.
 class Result {
-  bool ok_;
+  enum State { Ok, Err, Panicked } st_;
+  std::string what_;
+  void look() const { if (st_ == Panicked) throw Panic(what_); }
  public:
-  explicit Result(bool ok) : ok_(ok) {}
-  bool is_ok() const { return ok_; }
-  bool is_err() const { return !ok_; }
-  void expect(const char* msg) const { if (!ok_) throw Panic(std::string(msg) + ": IncorrectProof"); }
+  explicit Result(bool ok) : st_(ok ? Ok : Err) {}
+  static Result panicked(const std::string& what) { Result r(false); r.st_ = Panicked; r.what_ = what; return r; }
+  bool would_panic() const { return st_ == Panicked; }
+  bool is_ok() const { look(); return st_ == Ok; }
+  bool is_err() const { look(); return st_ == Err; }
+  void expect(const char* msg) const { look(); if (st_ != Ok) throw Panic(std::string(msg) + ": IncorrectProof"); }
 };
 
 // ------------------------------------------------------------------ engine (one ctx per device)
@@ -200,7 +206,14 @@ class RangeProofNi {
     return prove_batch(ek, {Statement{range, ciphertext, secret_x, secret_r}})[0];
   }
 
-  // verify_self for many proofs sharing one key (range_proof_ni.rs:109-128)
+  // verify_self for many proofs sharing one key (range_proof_ni.rs:109-128).  Every field of a proof is prover-chosen and of
+  // arbitrary size in the reference (GMP); the fixed-width ABI carries kw / 2kw limbs.  Each proof is screened on the host so
+  // that an over-wide field yields the verdict the reference would reach for THAT proof, never an exception for the batch:
+  //   * r1, r2, masked_r enter only as r^n mod n^2 = (r mod n)^n mod n^2, and c_j[i], ciphertext on Mask rows only as a product
+  //     reduced mod n^2 (range_proof.rs:324-328): reduced on the host, same result;
+  //   * an over-wide w1 / w2 fails the strict range test of an Open row (:300-305), an over-wide masked_x the bound of a Mask
+  //     row (:338), an over-wide c_j[i] of an Open row can never equal a ciphertext (:293-298): Err(IncorrectProof);
+  //   * a range wider than the key cannot be represented at all: that proof carries a panic-like "unsupported" result.
   static std::vector<Result> verify_batch(const EncryptionKey& ek, const std::vector<const RangeProofNi*>& proofs) {
     Engine& e = Engine::instance();
     const uint32_t nb = width_for(ek.n), kw = nb / 32;
@@ -209,35 +222,51 @@ class RangeProofNi {
     const size_t EF = proofs[0]->error_factor, rows = B * EF;
     std::vector<uint32_t> n(kw), range(B * kw), ct(B * 2 * kw), c1(rows * 2 * kw), c2(rows * 2 * kw), rw1(rows * kw), rr1(rows * kw), rw2(rows * kw), rr2(rows * kw);
     std::vector<uint8_t> kind(rows), jj(rows), verdict(B);
+    enum Pre : uint8_t { Run = 0, Reject, PanicIdx, Unsupported };
+    std::vector<uint8_t> pre(B, Run);
     ek.n.to_limbs(n.data(), kw);
+    const size_t nbits_n = 32 * (size_t)kw, nbits_c = 64 * (size_t)kw;
+    auto fits = [](const BigInt& v, size_t bits) { return v.bit_length() <= bits; };
     for (size_t b = 0; b < B; b++) {
       const RangeProofNi& p = *proofs[b];
       if (p.error_factor != EF) throw std::invalid_argument("verify_batch: mixed error factors");
       // responses[i], c1[i], c2[i] for i < error_factor: out-of-bounds index is a panic in the reference (range_proof.rs:274,293,296)
-      if (p.proof.responses.size() < EF || p.encrypted_pairs.c1.size() < EF || p.encrypted_pairs.c2.size() < EF) throw Panic("index out of bounds");
-      if (p.encrypted_pairs.c1.size() != EF || p.encrypted_pairs.c2.size() != EF)
-        throw std::invalid_argument("verify_batch: the fixed-layout ABI needs len(c1) == len(c2) == error_factor");
-      p.range.to_limbs(&range[b * kw], kw); p.ciphertext.to_limbs(&ct[b * 2 * kw], 2 * kw);
+      if (p.proof.responses.size() < EF || p.encrypted_pairs.c1.size() < EF || p.encrypted_pairs.c2.size() < EF) { pre[b] = PanicIdx; continue; }
+      if (!fits(p.range, nbits_n)) { pre[b] = Unsupported; continue; }
+      p.range.to_limbs(&range[b * kw], kw);
+      (fits(p.ciphertext, nbits_c) ? p.ciphertext : p.ciphertext % ek.nn).to_limbs(&ct[b * 2 * kw], 2 * kw);
       for (size_t i = 0; i < EF; i++) {
         const size_t t = b * EF + i;
-        p.encrypted_pairs.c1[i].to_limbs(&c1[t * 2 * kw], 2 * kw); p.encrypted_pairs.c2[i].to_limbs(&c2[t * 2 * kw], 2 * kw);
         const Response& rs = p.proof.responses[i];
+        const BigInt &C1 = p.encrypted_pairs.c1[i], &C2 = p.encrypted_pairs.c2[i];
         if (rs.kind == Response::Open) {
           kind[t] = ZKP_RESP_OPEN;
-          rs.w1.to_limbs(&rw1[t * kw], kw); rs.r1.to_limbs(&rr1[t * kw], kw); rs.w2.to_limbs(&rw2[t * kw], kw); rs.r2.to_limbs(&rr2[t * kw], kw);
+          if (!fits(rs.w1, nbits_n) || !fits(rs.w2, nbits_n) || !fits(C1, nbits_c) || !fits(C2, nbits_c)) { pre[b] = Reject; continue; }
+          C1.to_limbs(&c1[t * 2 * kw], 2 * kw); C2.to_limbs(&c2[t * 2 * kw], 2 * kw);
+          rs.w1.to_limbs(&rw1[t * kw], kw); rs.w2.to_limbs(&rw2[t * kw], kw);
+          (fits(rs.r1, nbits_n) ? rs.r1 : rs.r1 % ek.n).to_limbs(&rr1[t * kw], kw);
+          (fits(rs.r2, nbits_n) ? rs.r2 : rs.r2 % ek.n).to_limbs(&rr2[t * kw], kw);
         } else {
           kind[t] = ZKP_RESP_MASK; jj[t] = rs.j;
-          rs.masked_x.to_limbs(&rw1[t * kw], kw); rs.masked_r.to_limbs(&rr1[t * kw], kw);
+          if (!fits(rs.masked_x, nbits_n)) { pre[b] = Reject; continue; }
+          (fits(C1, nbits_c) ? C1 : C1 % ek.nn).to_limbs(&c1[t * 2 * kw], 2 * kw);
+          (fits(C2, nbits_c) ? C2 : C2 % ek.nn).to_limbs(&c2[t * 2 * kw], 2 * kw);
+          rs.masked_x.to_limbs(&rw1[t * kw], kw);
+          (fits(rs.masked_r, nbits_n) ? rs.masked_r : rs.masked_r % ek.n).to_limbs(&rr1[t * kw], kw);
         }
       }
     }
+    // (rows of screened-out proofs stay zero: the launch still runs over the whole batch, their verdicts are ignored)
     zkp_range_ni_proofs p{nb, (uint32_t)EF, B, 0, n.data(), range.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
                           rw1.data(), rr1.data(), rw2.data(), rr2.data()};
     e.check(zkp_range_ni_verify_batch(e.ctx(), &p, verdict.data(), 0), "zkp_range_ni_verify_batch");
     std::vector<Result> out;
     for (size_t b = 0; b < B; b++) {
-      if (verdict[b] == ZKP_VERDICT_MALFORMED) throw Panic("RangeProofNi::verify: malformed proof (the reference would panic)");
-      out.emplace_back(verdict[b] == ZKP_VERDICT_ACCEPT);
+      if (pre[b] == PanicIdx) out.push_back(Result::panicked("index out of bounds: the len is less than error_factor"));
+      else if (pre[b] == Unsupported) out.push_back(Result::panicked("RangeProofNi::verify: range wider than the key: not representable in the fixed-width ABI"));
+      else if (pre[b] == Reject) out.emplace_back(false);
+      else if (verdict[b] == ZKP_VERDICT_MALFORMED) out.push_back(Result::panicked("RangeProofNi::verify: malformed proof (the reference would panic)"));
+      else out.emplace_back(verdict[b] == ZKP_VERDICT_ACCEPT);
     }
     return out;
   }
@@ -246,9 +275,11 @@ class RangeProofNi {
   Result verify(const EncryptionKey& ek_, const BigInt& ciphertext_) const {
     if (!(ek_ == ek)) throw Panic("assertion failed: `(left == right)` ek");                  // :86
     if (ciphertext_ != ciphertext) throw Panic("assertion failed: `(left == right)` ciphertext");   // :88
-    return verify_batch(ek, {this})[0];
+    Result r = verify_batch(ek, {this})[0];
+    (void)r.is_ok();                          // a single proof panics right here, as the reference does
+    return r;
   }
-  Result verify_self() const { return verify_batch(ek, {this})[0]; }                          // :109-128
+  Result verify_self() const { Result r = verify_batch(ek, {this})[0]; (void)r.is_ok(); return r; }   // :109-128
 };
 
 // ------------------------------------------------------------------ host SHA-256 (only for NiCorrectKeyProof::proof's MGF)
