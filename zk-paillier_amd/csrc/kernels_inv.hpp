@@ -9,13 +9,10 @@ namespace zkp {
 
 // ------------------------------------------------------------------------------------------
 // out = a^-1 mod M (curv BigInt::mod_inv -> mpz_invert; multiplication_proof.rs:95,135, correct_message.rs:53,76,141).
-// Right-shift binary extended GCD with the cofactors kept modulo M:
-//   invariants u == x*a, v == y*a (mod M); u loses its trailing zero bits z at a time and x is divided by 2^z
-//   modulo M in ONE multiply-accumulate pass (x + ((x0 * -M^-1) mod 2^z) * M is divisible by 2^z); then the larger
-//   of (u, v) is reduced by the other — subtraction and the following shift fused into one pass per operand pair.
-//   gcd = v at the end; the inverse is y when gcd == 1.
-// u, v, x, y and a copy of M live in thread-interleaved LDS (word w of lane t at base[w * LANES + t]: conflict-free).  Data-dependent trip counts: lanes
-// of a wavefront wait for the slowest one.
+// Word-batched binary extended GCD (kernels_gcd.hpp): ~258 rounds of two passes over 4096-bit operands; the cofactors are kept
+// modulo M as two's complement numbers of kw + 1 words with |u|, |v| < M.  a, b, u, v and a copy of M live in thread-interleaved
+// LDS (word w of lane t at base[w * LANES + t]: conflict-free).  Data-dependent trip counts: lanes of a wavefront wait for the
+// slowest one (the counts differ by a few rounds).
 struct ModinvArgs {
   const uint32_t* a; uint64_t a_stride;        // words between consecutive items
   const uint32_t* mod; uint64_t mod_stride;    // modulus words [kw] (0 = shared)
@@ -23,6 +20,7 @@ struct ModinvArgs {
   uint8_t* status;                             // ZKP_INV_*
   uint64_t count; int kw;
 };
+constexpr size_t modinv_lds_words_per_lane(int kw) { return 5 * (size_t)kw + 2; }
 
 __global__ void __launch_bounds__(64) k_modinv(ModinvArgs a) {
   extern __shared__ __align__(16) uint32_t inv_lds[];
@@ -32,11 +30,11 @@ __global__ void __launch_bounds__(64) k_modinv(ModinvArgs a) {
   const uint32_t* A = a.a + item * a.a_stride;
   const uint32_t* M = a.mod + item * a.mod_stride;
   uint32_t* out = a.out + item * a.out_stride;
-  uint32_t* u = inv_lds + threadIdx.x;
-  uint32_t* v = u + (size_t)kw * S;
-  uint32_t* x = v + (size_t)kw * S;
-  uint32_t* y = x + (size_t)kw * S;
-  uint32_t* Ml = y + (size_t)kw * S;                  // this lane's copy of the modulus
+  uint32_t* pa = inv_lds + threadIdx.x;
+  uint32_t* pb = pa + (size_t)kw * S;
+  uint32_t* pu = pb + (size_t)kw * S;
+  uint32_t* pv = pu + (size_t)(kw + 1) * S;
+  uint32_t* pm = pv + (size_t)(kw + 1) * S;            // this lane's copy of the modulus
   // domain: M odd, M >= 3, 0 <= a < M
   int cmp = 0;
   bool a_zero = true, m_small = M[0] < 3;
@@ -52,157 +50,22 @@ __global__ void __launch_bounds__(64) k_modinv(ModinvArgs a) {
   uint32_t minv = M[0];
 #pragma unroll
   for (int it = 0; it < 5; it++) minv *= 2u - M[0] * minv;
-  minv = 0u - minv;                                   // -M^-1 mod 2^32
-  for (int w = 0; w < kw; w++) { u[w * S] = A[w]; v[w * S] = M[w]; Ml[w * S] = M[w]; x[w * S] = w == 0; y[w * S] = 0; }
-  int nu = kw, nv = kw;                               // live word counts of u, v
-  // The word loops below work on chunks of CH words: all loads of a chunk are issued before its first store (the
-  // compiler cannot prove that u, v, x, y and M do not alias, so a plain loop would serialise load -> store -> load and
-  // pay the LDS round trip per word).  kw is a multiple of CH and words above a live count are zero, so a chunk may
-  // run past nu / nv inside the array.
-  constexpr int CH = 8;
-  for (;;) {
-    // ---- u odd: drop zw whole zero words and zb bits; x /= 2^(32 zw + zb) mod M
-    int zw = 0;
-    while (u[zw * S] == 0) zw++;
-    const int zb = __builtin_ctz(u[zw * S]);
-    if (zw | zb) {
-      for (int w0 = 0; w0 < nu; w0 += CH) {
-        uint32_t t[CH + 1];
-#pragma unroll
-        for (int k = 0; k <= CH; k++) { const int s0 = w0 + k + zw; t[k] = s0 < kw ? u[s0 * S] : 0u; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) u[(w0 + k) * S] = zb ? ((t[k] >> zb) | (t[k + 1] << (32 - zb))) : t[k];
-      }
-      for (int step = 0; step < zw + (zb ? 1 : 0); step++) {
-        const int z = step < zw ? 32 : zb;
-        const uint32_t t = (x[0] * minv) & (z == 32 ? 0xFFFFFFFFu : ((1u << z) - 1));
-        uint64_t carry = 0;
-        uint32_t prev = 0;
-        for (int w0 = 0; w0 < kw; w0 += CH) {
-          uint32_t xs[CH], ms[CH], lo[CH];
-#pragma unroll
-          for (int k = 0; k < CH; k++) { xs[k] = x[(w0 + k) * S]; ms[k] = Ml[(w0 + k) * S]; }
-#pragma unroll
-          for (int k = 0; k < CH; k++) {
-            const uint64_t acc = (uint64_t)t * ms[k] + xs[k] + carry;
-            lo[k] = (uint32_t)acc;
-            carry = acc >> 32;
-          }
-#pragma unroll
-          for (int k = 0; k < CH; k++) {
-            const uint32_t below = k ? lo[k - 1] : prev;
-            if (w0 + k > 0) x[(w0 + k - 1) * S] = z == 32 ? lo[k] : ((below >> z) | (lo[k] << (32 - z)));
-          }
-          prev = lo[CH - 1];
-        }
-        x[(kw - 1) * S] = z == 32 ? (uint32_t)carry : ((prev >> z) | ((uint32_t)carry << (32 - z)));
-      }
-    }
-    while (nu > 1 && u[(nu - 1) * S] == 0) nu--;
-    while (nv > 1 && v[(nv - 1) * S] == 0) nv--;
-    int c = nu != nv ? (nu > nv ? 1 : -1) : 0;
-    for (int w = nu - 1; c == 0 && w >= 0; w--) {
-      const uint32_t p = u[w * S], q = v[w * S];
-      if (p != q) c = p > q ? 1 : -1;
-    }
-    if (c == 0) break;                                // u == v == gcd
-    if (c < 0) {
-      uint32_t* t = u; u = v; v = t;
-      t = x; x = y; y = t;
-      const int tn = nu; nu = nv; nv = tn;
-    }
-    // x < y is decided from the top first: x - y needs + M exactly then
-    int lt = 0;
-    for (int w = kw - 1; lt == 0 && w >= 0; w--) {
-      const uint32_t p = x[w * S], q = y[w * S];
-      if (p != q) lt = p < q ? 1 : -1;
-    }
-    const uint32_t addm = lt > 0 ? 0xFFFFFFFFu : 0u;
-    // u - v is even; when its trailing zeros all sit in the low word (always, up to a 2^-32 chance) the subtraction and the
-    // next round's shift are ONE pass over u, and x = (x - y mod M) / 2^z mod M is ONE pass over x with three carry chains
-    const uint32_t d0 = u[0] - v[0];
-    const int z = d0 ? __builtin_ctz(d0) : 0;
-    uint32_t borrow = 0;
-    if (z) {
-      uint32_t prev = 0;
-      for (int w0 = 0; w0 < nu; w0 += CH) {           // u = (u - v) >> z   (nv <= nu)
-        uint32_t p[CH], q[CH], d[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) { p[k] = u[(w0 + k) * S]; q[k] = v[(w0 + k) * S]; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const uint64_t t = (uint64_t)p[k] - q[k] - borrow;
-          d[k] = (uint32_t)t;
-          borrow = (uint32_t)(t >> 63);
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const uint32_t below = k ? d[k - 1] : prev;
-          if (w0 + k > 0) u[(w0 + k - 1) * S] = (below >> z) | (d[k] << (32 - z));
-        }
-        prev = d[CH - 1];
-      }
-      u[(((nu + CH - 1) / CH) * CH - 1) * S] = prev >> z;
-      const uint32_t x0 = x[0] - y[0] + (Ml[0] & addm);
-      const uint32_t t = (x0 * minv) & ((1u << z) - 1);
-      uint32_t cy = 0;
-      uint64_t carry = 0;
-      borrow = 0; prev = 0;
-      for (int w0 = 0; w0 < kw; w0 += CH) {           // x = ((x - y + [M]) + t * M) >> z
-        uint32_t p[CH], q[CH], m[CH], lo[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) { p[k] = x[(w0 + k) * S]; q[k] = y[(w0 + k) * S]; m[k] = Ml[(w0 + k) * S]; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
-          borrow = (uint32_t)(d >> 63);
-          const uint64_t sm = (uint64_t)(uint32_t)d + (m[k] & addm) + cy;
-          cy = (uint32_t)(sm >> 32);
-          const uint64_t acc = (uint64_t)t * m[k] + (uint32_t)sm + carry;
-          lo[k] = (uint32_t)acc;
-          carry = acc >> 32;
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const uint32_t below = k ? lo[k - 1] : prev;
-          if (w0 + k > 0) x[(w0 + k - 1) * S] = (below >> z) | (lo[k] << (32 - z));
-        }
-        prev = lo[CH - 1];
-      }
-      x[(kw - 1) * S] = (prev >> z) | ((uint32_t)carry << (32 - z));
-    } else {
-      for (int w0 = 0; w0 < nu; w0 += CH) {           // u -= v; the zero words are stripped at the top of the loop
-        uint32_t p[CH], q[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) { p[k] = u[(w0 + k) * S]; q[k] = v[(w0 + k) * S]; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
-          u[(w0 + k) * S] = (uint32_t)d;
-          borrow = (uint32_t)(d >> 63);
-        }
-      }
-      uint32_t cy = 0;
-      borrow = 0;
-      for (int w0 = 0; w0 < kw; w0 += CH) {           // x = x - y (+ M)
-        uint32_t p[CH], q[CH], m[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) { p[k] = x[(w0 + k) * S]; q[k] = y[(w0 + k) * S]; m[k] = Ml[(w0 + k) * S] & addm; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const uint64_t d = (uint64_t)p[k] - q[k] - borrow;
-          borrow = (uint32_t)(d >> 63);
-          const uint64_t sm = (uint64_t)(uint32_t)d + m[k] + cy;
-          cy = (uint32_t)(sm >> 32);
-          x[(w0 + k) * S] = (uint32_t)sm;
-        }
-      }
-    }
-  }
-  bool one = v[0] == 1;
-  for (int w = 1; w < nv; w++) one = one && v[w * S] == 0;
+  const uint32_t minv30 = (0u - minv) & GCD_MK;        // -M^-1 mod 2^30
+  // a == A * u, b == A * v (mod M) with (a, b, u, v) = (A, M, 1, 0)
+  for (int w = 0; w < kw; w++) { pa[w * S] = A[w]; pb[w * S] = M[w]; pm[w * S] = M[w]; pu[w * S] = w == 0; pv[w * S] = 0; }
+  pu[kw * S] = 0; pv[kw * S] = 0;
+  const int nb = wb_gcd<true>(pa, pb, pu, pv, pm, minv30, kw, S);
+  bool one = pb[0] == 1;
+  for (int w = 1; w < nb; w++) one = one && pb[w * S] == 0;
   if (!one) { a.status[item] = ZKP_INV_NONE; return; }
-  for (int w = 0; w < kw; w++) out[w] = y[w * S];
+  // 1 == A * v (mod M) with -M < v < M
+  const uint32_t addm = (int32_t)pv[kw * S] < 0 ? 0xFFFFFFFFu : 0u;
+  uint32_t carry = 0;
+  for (int w = 0; w < kw; w++) {
+    const uint64_t t = (uint64_t)pv[w * S] + (pm[w * S] & addm) + carry;
+    out[w] = (uint32_t)t;
+    carry = (uint32_t)(t >> 32);
+  }
   a.status[item] = ZKP_INV_OK;
 }
 

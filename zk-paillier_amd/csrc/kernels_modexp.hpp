@@ -25,7 +25,7 @@ template <int G> struct ConstLayout {
 // a Montgomery product needs stays resident per group — the staged B operand.  The two conversion areas are transient:
 // `words` (32-bit word staging of a value on its way in or out) and `scr` (29-bit limb scratch of words_from_limbs), and
 // `scr` ALIASES the B operand: it is only written by the final conversion of a result, when no product is pending.
-// Exponents are read from global memory (one window per 5-6 products), never staged.
+// Per-item exponents (fixed-window ladder) borrow the `words` area while the ladder runs.
 //   W = 36: G = 4 -> 1152 B per group, 72 KB per workgroup of 64 groups: two workgroups fill the 160 KB of a CU.
 template <int G> struct LdsLayout {
   static constexpr int L = Geo<G>::L;
@@ -158,7 +158,7 @@ template <int G, bool SAFE, class LL> __device__ __forceinline__ void mmo_ip(con
 //     (nwin-1) rounds of [5 squarings, 1 table product].
 template <int G, bool SAFE, class LL>
 __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst,
-                                           const uint32_t* __restrict__ ew /* exponent words in GLOBAL memory, exp_bits/32 of them */) {
+                                           const uint32_t* __restrict__ ew /* exponent words in global memory, exp_bits/32 of them */) {
   using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
   uint32_t NT[W];
@@ -170,21 +170,40 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
   }
   store_limbs_global<G>(tab + L, X, g.gl);
   stageB<G>(g, X);                                  // B() = X throughout the table rounds
-  const int nwin = (exp_bits + WIN - 1) / WIN, ewords = exp_bits >> 5;
-  // one window every WIN + 1 products: two words straight from global memory (the same address for every lane of the group)
+  const int nwin = (exp_bits + WIN - 1) / WIN;
+  // the exponent words sit in the group's words() staging area for the length of the ladder (nothing converts a value in or out
+  // while it runs); zero padded, so a window may straddle the top word
+  fetch_words<G>(g, g.words(), ew, exp_bits >> 5);
+  const uint32_t* lw = g.words();
   auto window = [&](int wi) -> int {
     const int bit = wi * WIN;
     const int w0 = bit >> 5, off = bit & 31;
-    const uint64_t x = (uint64_t)ew[w0] | ((uint64_t)(w0 + 1 < ewords ? ew[w0 + 1] : 0u) << 32);
+    const uint64_t x = (uint64_t)lw[w0] | ((uint64_t)lw[w0 + 1] << 32);
     return (int)((x >> off) & (TAB - 1));
   };
   constexpr int TROUNDS = TAB - 2;
   const int total = TROUNDS + (nwin - 1) * (WIN + 1);
+  // The table lives in HBM (it is far larger than L2): the entry a round of squarings will be multiplied by is known from the
+  // exponent alone, so its cache lines are touched when the round STARTS (one dword per 128-byte line of this lane's block)
+  // and the load of the entry itself, WIN products later, finds them in L2 instead of waiting for HBM.
+  constexpr int PF = (W * 4 + 127) / 128 + 1;
+  uint32_t pf = 0, pfv[PF];
+#pragma unroll
+  for (int k = 0; k < PF; k++) pfv[k] = 0;
   // the table stores of this lane are re-read by this lane only: program order suffices
 #pragma unroll 1
   for (int i = 0; i < total; i++) {
     const int step = i - TROUNDS;
-    if (step >= 0 && step % (WIN + 1) == WIN) load_limbs_global<G>(X, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
+    if (step >= 0 && step % (WIN + 1) == 0) {
+      const uint32_t* nxt = tab + window(nwin - 2 - step / (WIN + 1)) * L + g.gl * W;
+#pragma unroll
+      for (int k = 0; k < PF; k++) pfv[k] = nxt[k * 32 < W ? k * 32 : W - 1];      // not looked at until the entry is loaded
+    }
+    if (step >= 0 && step % (WIN + 1) == WIN) {
+#pragma unroll
+      for (int k = 0; k < PF; k++) pf ^= pfv[k];
+      load_limbs_global<G>(X, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
+    }
     mmo_ip<G, SAFE>(g, NT, X);
     if (step < 0) {
       store_limbs_global<G>(tab + (i + 2) * L, X, g.gl);
@@ -193,6 +212,8 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
       stageB<G>(g, X);
     }
   }
+  // (keeps the touches alive: pf is data the compiler cannot prove zero, the condition never holds for 29-bit limbs)
+  if (pf == 0xFFFFFFFFu && X[0] == 0xFFFFFFFFu) X[0] = pf;
 }
 
 // (b) ONE exponent for the whole launch (Paillier Enc under a shared key: exponent n): sliding windows of
@@ -262,12 +283,14 @@ __device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[
 
 // The fast product needs the key's M~ to have passed k_setup's digit-sum test; a wavefront takes the fast ladder only when
 // every one of its groups may (uniform control flow; per-key batches mix keys inside a wavefront).
-template <int G, class LL>
+// SHARED_EXP: the launch has ONE exponent (sliding-window script `sched`), else every item has its own (fixed windows).  Each
+// kernel is instantiated for one kind only: both ladders in one kernel cost registers in the hot loops.
+template <int G, bool SHARED_EXP, class LL>
 __device__ __forceinline__ void powm(const Grp<G, LL>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst, const uint8_t* sched,
                                      const uint32_t* __restrict__ exp_words_global) {
   using CL = ConstLayout<G>;
   const bool fast = !COL_NEEDS_CARE || __all(cst[CL::OFF_ST + 1] != 0);
-  if (sched) {
+  if constexpr (SHARED_EXP) {
     if (fast) powm_sliding<G, false>(g, X, sched, tab, cst);
     else powm_sliding<G, true>(g, X, sched, tab, cst);
   } else {
@@ -452,7 +475,7 @@ struct ModexpArgs {
   unsigned long long* work_counter;   // zeroed per launch: wavefronts claim 64/G items at a time
 };
 
-template <int G>
+template <int G, bool SHARED_EXP>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
@@ -480,7 +503,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
     load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
     stageB<G>(g, X);
     mm<G>(g, X, T);
-    powm<G>(g, X, a.exp_bits, tab, cst, a.sched, a.exp + item * a.exp_stride);
+    powm<G, SHARED_EXP>(g, X, a.exp_bits, tab, cst, a.sched, a.exp + item * a.exp_stride);
     // leave the Montgomery domain: montmul(X, 1) <= M
     stage_one<G>(g);
     mm<G>(g, R, X);
@@ -582,7 +605,7 @@ template <int G, class LL> __device__ __forceinline__ void stage_const(const Grp
 //   s4  Y  = Y * R2 / R ; s5  Y = Y * 1 / R  -> value <= M -> canonical words = c
 //   mode 1 only (expected ciphertext e = c_j[i], or c_j[i] * cipher_x mod n^2 on Mask rows, range_proof.rs:324-328):
 //   s6  Y  = e * R2 / R ; s7  Y = Y * (mask ? cipher_x : 1) / R ; s8  Y = Y * R2 / R ; s9  Y = Y * 1 / R -> canonical
-template <int G>
+template <int G, bool SHARED_EXP>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
@@ -650,7 +673,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
 #pragma unroll 1
     for (int s = 0; s < nsteps; s++) {
       if (s == 1) {
-        powm<G>(g, X, a.n_bits, tab, cst, a.sched, pn);                 // exponent = n (read from global memory by the fixed-window ladder)
+        powm<G, SHARED_EXP>(g, X, a.n_bits, tab, cst, a.sched, pn);                 // exponent = n (read from global memory by the fixed-window ladder)
         continue;
       }
       // ---- operands

@@ -3,6 +3,7 @@
 // for RangeProofNi, plus the NiCorrectKeyProof and CompositeDLogProof checks.
 #pragma once
 #include "kernels_modexp.hpp"
+#include "kernels_gcd.hpp"
 #include "sha256_dev.hpp"
 
 namespace zkp {
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
     stageB<G>(g, T);
     load_value<G>(g, T, a.sigma + item * kw, kw);
     mm<G>(g, X, T);
-    powm<G>(g, X, a.n_bits, tab, cst, nullptr, a.n + b * kw);
+    powm<G, false>(g, X, a.n_bits, tab, cst, nullptr, a.n + b * kw);
     stage_one<G>(g);
     mm<G>(g, R, X);
     normalize_exact<G>(R, g.gl);
@@ -417,78 +418,6 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // CompositeDLogProof (wi_dlog_proof.rs:46-91), one thread per proof for the byte/word-level parts.
-
-// gcd(a, N) == 1 for odd N: binary GCD on kw-word integers kept in thread-interleaved LDS
-// (word w of lane t at base[w * stride + t]: conflict-free).  Trailing zeros are stripped many bits at a time.
-__device__ __forceinline__ bool coprime_to_odd(const uint32_t* a, const uint32_t* N, int kw, uint32_t* u, uint32_t* v, int stride) {
-  bool uz = true;
-  for (int w = 0; w < kw; w++) { const uint32_t x = a[w]; u[w * stride] = x; v[w * stride] = N[w]; uz = uz && x == 0; }
-  if (uz) {                         // gcd(0, N) = N
-    bool one = N[0] == 1;
-    for (int w = 1; w < kw; w++) one = one && N[w] == 0;
-    return one;
-  }
-  int nu = kw, nv = kw;             // live word counts (high words that became zero are skipped)
-  // word loops in chunks of CH: every load of a chunk is issued before its first store (u and v may alias as far as the
-  // compiler knows, a plain loop pays one LDS round trip per word); kw is a multiple of CH, words above a live count are zero
-  constexpr int CH = 8;
-  for (;;) {
-    // make u odd: drop whole zero words, then the remaining trailing zero bits at once
-    int zw = 0;
-    while (u[zw * stride] == 0) zw++;                 // u != 0 here
-    const int zb = __builtin_ctz(u[zw * stride]);
-    if (zw | zb) {
-      for (int w0 = 0; w0 < nu; w0 += CH) {
-        uint32_t t[CH + 1];
-#pragma unroll
-        for (int k = 0; k <= CH; k++) { const int s0 = w0 + k + zw; t[k] = s0 < kw ? u[s0 * stride] : 0u; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) u[(w0 + k) * stride] = zb ? ((t[k] >> zb) | (t[k + 1] << (32 - zb))) : t[k];
-      }
-    }
-    while (nu > 1 && u[(nu - 1) * stride] == 0) nu--;
-    while (nv > 1 && v[(nv - 1) * stride] == 0) nv--;
-    // compare
-    int cmp = nu != nv ? (nu > nv ? 1 : -1) : 0;
-    for (int w = nu - 1; cmp == 0 && w >= 0; w--) {
-      const uint32_t x = u[w * stride], y = v[w * stride];
-      if (x != y) cmp = x > y ? 1 : -1;
-    }
-    if (cmp == 0) break;            // gcd = u = v
-    if (cmp < 0) { uint32_t* t = u; u = v; v = t; const int tn = nu; nu = nv; nv = tn; }
-    // u -= v (both odd -> u even, non-zero; nv <= nu).  When the trailing zeros of the difference all sit in its low word
-    // (always, up to a 2^-32 chance) the subtraction and the next round's shift are one pass.
-    const uint32_t d0 = u[0] - v[0];
-    const int z = d0 ? __builtin_ctz(d0) : 0;
-    uint32_t borrow = 0, prev = 0;
-    for (int w0 = 0; w0 < nu; w0 += CH) {
-      uint32_t p[CH], q[CH], d[CH];
-#pragma unroll
-      for (int k = 0; k < CH; k++) { p[k] = u[(w0 + k) * stride]; q[k] = v[(w0 + k) * stride]; }
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        const uint64_t t = (uint64_t)p[k] - q[k] - borrow;
-        d[k] = (uint32_t)t;
-        borrow = (uint32_t)(t >> 63);
-      }
-      if (z) {
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const uint32_t below = k ? d[k - 1] : prev;
-          if (w0 + k > 0) u[(w0 + k - 1) * stride] = (below >> z) | (d[k] << (32 - z));
-        }
-        prev = d[CH - 1];
-      } else {
-#pragma unroll
-        for (int k = 0; k < CH; k++) u[(w0 + k) * stride] = d[k];
-      }
-    }
-    if (z) u[(((nu + CH - 1) / CH) * CH - 1) * stride] = prev >> z;
-  }
-  bool one = v[0] == 1;
-  for (int w = 1; w < nv; w++) one = one && v[w * stride] == 0;
-  return one;
-}
 
 struct DlogHashArgs {
   const uint32_t* N; const uint32_t* g; const uint32_t* ni; const uint32_t* x;   // [B][kw]
@@ -524,7 +453,7 @@ __global__ void __launch_bounds__(DLOG_THREADS) k_dlog_hash(DlogHashArgs a) {
     if (ok) {
       uint32_t* u = dlog_lds + 16 * DLOG_THREADS + threadIdx.x;
       uint32_t* v = u + kw * DLOG_THREADS;
-      ok = coprime_to_odd(g, N, kw, u, v, DLOG_THREADS) && coprime_to_odd(ni, N, kw, u, v, DLOG_THREADS);
+      ok = wb_coprime_to_odd(g, N, kw, u, v, DLOG_THREADS) && wb_coprime_to_odd(ni, N, kw, u, v, DLOG_THREADS);
     }
     a.verdict[b] = ok ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_MALFORMED;
   }

@@ -224,6 +224,13 @@ template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_
   return ensure(c, c->table, (size_t)blocks * LL::GROUPS_PER_BLOCK * TAB * Geo<G>::L * sizeof(uint32_t));
 }
 
+// k_enc is instantiated per ladder kind: one shared exponent n (sliding-window script) or one key per item (fixed windows)
+template <int G> static void launch_k_enc(zkp_ctx* c, unsigned blocks, const EncArgs& a) {
+  using LL = LdsLayout<G>;
+  if (a.sched) hipLaunchKernelGGL((k_enc<G, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+  else hipLaunchKernelGGL((k_enc<G, false>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+}
+
 // ---- ctx ------------------------------------------------------------------------------------
 extern "C" int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out) try {
   if (!out) return ZKP_EINVAL;
@@ -314,7 +321,7 @@ static int32_t modexp_core(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const 
   using LL = LdsLayout<G>;
   unsigned blocks = 0;
   int32_t st;
-  if ((st = table_for<G>(c, k_modexp<G>, count, &blocks))) return st;
+  if ((st = table_for<G>(c, k_modexp<G, true>, count, &blocks))) return st;
   const uint8_t* sched = nullptr;
   if (exp_stride == 0 && (st = build_schedule(c, exp, exp_bits, &sched))) return st;
   unsigned long long* wc = nullptr;
@@ -322,7 +329,8 @@ static int32_t modexp_core(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const 
   ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words, out_words ? out_words : io_words, sched, wc};
   {
     TimedRegion tr(c, count);
-    hipLaunchKernelGGL(k_modexp<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+    if (a.sched) hipLaunchKernelGGL((k_modexp<G, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+    else hipLaunchKernelGGL((k_modexp<G, false>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
   }
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
@@ -426,7 +434,7 @@ static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint3
   int32_t st = enc_setup<G>(c, n_bits, n, n_stride, nkeys);
   if (st) return st;
   unsigned blocks = 0;
-  if ((st = table_for<G>(c, k_enc<G>, count, &blocks))) return st;
+  if ((st = table_for<G>(c, k_enc<G, true>, count, &blocks))) return st;
   EncArgs a{};
   a.n = n; a.n_stride = n_stride; a.consts = (const uint32_t*)c->consts.p; a.const_stride = n_stride ? (uint64_t)CL::WORDS : 0;
   a.table = (uint32_t*)c->table.p; a.count = count; a.n_bits = (int)n_bits; a.mode = 0;
@@ -435,7 +443,7 @@ static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint3
   if ((st = fresh_work_counter(c, &a.work_counter))) return st;
   {
     TimedRegion tr(c, count);
-    hipLaunchKernelGGL(k_enc<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+    launch_k_enc<G>(c, blocks, a);
   }
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
@@ -475,7 +483,7 @@ static int32_t enc_check_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const
   int32_t st = enc_setup<G>(c, n_bits, n, n_stride, nkeys);
   if (st) return st;
   unsigned blocks = 0;
-  if ((st = table_for<G>(c, k_enc<G>, count, &blocks))) return st;
+  if ((st = table_for<G>(c, k_enc<G, true>, count, &blocks))) return st;
   EncArgs a{};
   a.n = n; a.n_stride = n_stride; a.consts = (const uint32_t*)c->consts.p; a.const_stride = n_stride ? (uint64_t)CL::WORDS : 0;
   a.table = (uint32_t*)c->table.p; a.count = count; a.n_bits = (int)n_bits; a.mode = 2;
@@ -485,7 +493,7 @@ static int32_t enc_check_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const
   if ((st = fresh_work_counter(c, &a.work_counter))) return st;
   {
     TimedRegion tr(c, count);
-    hipLaunchKernelGGL(k_enc<G>, dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+    launch_k_enc<G>(c, blocks, a);
   }
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
