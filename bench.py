@@ -145,7 +145,7 @@ def parse_args(argv=None):
     ap.add_argument("--big-batch", type=int, default=4096, help="proofs of the n=4096 leg (configs[4]); 0 = skip")
     ap.add_argument("--distinct-batch", type=int, default=4096, help="proofs of the distinct-keys leg (SURVEY 8(d) config 3); 0 = skip")
     ap.add_argument("--no-pcie-leg", action="store_true")
-    ap.add_argument("--pmc-shape", choices=["enc2048", "enc4096", "ck2048"], default=None,
+    ap.add_argument("--pmc-shape", choices=["enc2048", "enc2048keys", "enc4096", "ck2048"], default=None,
                     help="run ONE short launch shape only (for rocprofv3 --pmc passes, profiles/collect_pmc.sh)")
     return ap.parse_args(argv)
 
@@ -216,7 +216,7 @@ def main():
 
     def enc_roofline(kms, launches, modexps, nb, kernel, extra_note=""):
         ach = modexps * enc_limb_macs(nb) / (kms * 1e-3) if kms else 0.0
-        per, src = pmc_traffic_per_modexp(kernel.split(" ")[0])
+        per, src = pmc_traffic_per_modexp(kernel.split(" (")[0])            # the kernel's name as rocprofv3 prints it
         per_launch = modexps / max(launches, 1)
         bytes_per_enc = 4 * (nb // 32) * 4 + 8          # r, m (kw words each) + expected ciphertext (2kw) + 8 B work item
         return {"bound": "valu", "achieved": ach / 1e12, "peak": PEAK_LIMB_MAC_PER_S / 1e12, "unit": "Tlimb-MAC/s", "frac": ach / PEAK_LIMB_MAC_PER_S,
@@ -268,7 +268,7 @@ def main():
     if "c1" in gathered:
         ok = ok and bool(torch.equal(gathered["c1"].view(world, B, *pb.c1.shape[1:])[rank], pb.c1))
     value = B * world * args.steps / dt
-    roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc<{144 // lpl}> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer)")
+    roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc<{144 // lpl}, true> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer; sliding-window ladder)")
     ms_per_step = 1e3 * dt / args.steps
     gathered.clear()
 
@@ -408,7 +408,9 @@ def other_configs(args, ctx, synth, torch, dev, sync, pb, wt, rank, enc_roofline
     ach_k = me_k * modexp_limb_macs(2048, 2048) / (kms_k * 1e-3)
     other["configs[3] NiCorrectKeyProof verify, n=2048, batch=65536 distinct moduli (per GPU)"] = {
         "verifies_per_s": Bk / dtk, "modexp_per_s": me_k / (kms_k * 1e-3), "all_rejected_as_expected": bool((vk == 0).all().item()),
-        "kernel": f"k_ck_check<{72 // lpl}>", "kernel_ms": kms_k, "achieved_limb_mac_per_s": ach_k, "frac": ach_k / PEAK_LIMB_MAC_PER_S}
+        "kernel": f"k_ck_check<{72 // lpl}>", "kernel_ms": kms_k, "achieved_limb_mac_per_s": ach_k, "frac": ach_k / PEAK_LIMB_MAC_PER_S,
+        "frac_vs_16ms_kernel_peak": ach_k / PEAK_LIMB_MAC_PER_S_16MS_KERNELS,
+        "traffic": (lambda per: per[0] * me_k if per[0] else None)(pmc_traffic_per_modexp(f"k_ck_check<{72 // lpl}>"))}
     ok = ok and bool((vk == 0).all().item())
     del nk, sg, vk
 
@@ -434,13 +436,13 @@ def other_configs(args, ctx, synth, torch, dev, sync, pb, wt, rank, enc_roofline
     # SURVEY §8(d) config 3 "4096 distinct eks": every proof under its own 2048-bit key (fixed 5-bit windows: the exponent differs per item)
     if args.distinct_batch > 0:
         keys = synth.distinct_keys_2048(args.distinct_batch)
-        rec, good = range_leg(keys, 2048, args.distinct_batch, 777 + rank, f"k_enc<{144 // lpl}> (per-proof keys: fixed-window ladder)")
+        rec, good = range_leg(keys, 2048, args.distinct_batch, 777 + rank, f"k_enc<{144 // lpl}, false> (per-proof keys: fixed-window ladder)")
         other[f"configs[2]/[1] with {args.distinct_batch} DISTINCT 2048-bit keys (products of pooled 1024-bit primes), prove + verify (per GPU)"] = rec
         ok = ok and good
     # configs[4]: RangeProofNi prove + verify at n = 4096 (8192-bit n^2) under a real 4096-bit key
     if args.big_batch > 0:
         n5 = synth.bench_key_4096()[2]
-        rec, good = range_leg(n5, 4096, args.big_batch, 4321 + rank, f"k_enc<{288 // lpl}> (n = 4096: {288 // lpl} lanes x {lpl} limbs per 8192-bit integer)")
+        rec, good = range_leg(n5, 4096, args.big_batch, 4321 + rank, f"k_enc<{288 // lpl}, true> (n = 4096: {288 // lpl} lanes x {lpl} limbs per 8192-bit integer)")
         other[f"configs[4] RangeProofNi prove+verify, n=4096 (4096-bit key p*q of bench_keys.json), batch={args.big_batch} (per GPU)"] = rec
         ok = ok and good
     return other, ok
@@ -449,13 +451,13 @@ def other_configs(args, ctx, synth, torch, dev, sync, pb, wt, rank, enc_roofline
 def run_pmc_shape(args, ctx, synth, torch, dev, sync):
     """ONE dominant-kernel launch of a fixed, small shape; prints the modexp count of that launch (stdout, JSON)"""
     shape = args.pmc_shape
-    if shape in ("enc2048", "enc4096"):
-        nb = 2048 if shape == "enc2048" else 4096
-        Bx = 512 if shape == "enc2048" else 128
-        nkey = synth.BENCH_N if shape == "enc2048" else synth.bench_key_4096()[2]
+    if shape in ("enc2048", "enc2048keys", "enc4096"):
+        nb = 4096 if shape == "enc4096" else 2048
+        Bx = 128 if shape == "enc4096" else 512
+        nkey = synth.bench_key_4096()[2] if shape == "enc4096" else (synth.distinct_keys_2048(Bx) if shape == "enc2048keys" else synth.BENCH_N)
         pbx, wtx = synth.synth_range_inputs(nkey, nb, Bx, seed=5, device=dev)
         sync()
-        ctx.paillier_enc(nb, Bx, pbx.n, 0, wtx.x, wtx.r, pbx.ciphertext); sync()
+        ctx.paillier_enc(nb, Bx, pbx.n, 0 if isinstance(nkey, int) else nb // 32, wtx.x, wtx.r, pbx.ciphertext); sync()
         ctx.range_ni_prove(pbx.struct(), wtx.struct(), None, None, None, device=True); sync()
         v = torch.zeros(Bx, dtype=torch.uint8, device=dev)
         ctx.timing_reset(True)

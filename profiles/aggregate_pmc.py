@@ -36,7 +36,7 @@ def main():
     name = next((k for k in out if kernel in k), None)
     if name and modexps:
         r = out[name]
-        lanes = 64 // int(kernel.split("<")[1].split(">")[0]) if "<" in kernel else 1      # modexps per wavefront
+        lanes = 64 // int(kernel.split("<")[1].split(">")[0].split(",")[0]) if "<" in kernel else 1      # modexps per wavefront
         d = {"modexps_in_these_dispatches": modexps, "modexps_per_wavefront": lanes}
         if "SQ_INSTS_VALU" in r:
             d["valu_wave_instr_per_wave_modexp"] = r["SQ_INSTS_VALU"] / (modexps / lanes)

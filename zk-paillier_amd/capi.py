@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkp_hip.so")
+LIB_PATH = os.environ.get("ZKP_HIP_LIB") or os.path.join(_HERE, "libzkp_hip.so")   # (the override is for A/B measurements of kernel variants)
 
 ZKP_OK, ZKP_EINVAL, ZKP_ENONCANONICAL, ZKP_EDEVICE, ZKP_ENOMEM = range(5)
 ZKP_F_DEVICE_PTRS = 1

@@ -33,10 +33,14 @@ template <int G> struct LdsLayout {
   static constexpr int OFF_B = 0;                        // B operand blocks           [G*BLK]
   static constexpr int OFF_SCR = 0;                      // 29-bit limb scratch        [L+8]   (aliases B)
   static constexpr int OFF_WORDS = (G * BLK > L + 8 ? G * BLK : L + 8);   // 32-bit word staging [NW+8]
-  // 16-byte multiple, and an ODD number of 16-byte units: the groups of a wavefront read their staged operand with broadcast
-  // ds_read_b128 at the same offset, so an even stride would put all of them on two bank groups (measured with G = 4 at a
-  // stride of 288 words: SQ_LDS_BANK_CONFLICT = 99 % of the LDS-active cycles, profiles/r02_pmc_enc2048_k_enc4.json)
-  static constexpr int WORDS = (((OFF_WORDS + NW + 8 + 3) / 4) | 1) * 4;
+  // 16-byte multiple.  The group stride decides the LDS bank pattern of the two hot accesses: the broadcast ds_read_b128 of the
+  // staged operand (all groups of a wavefront at the same offset) and the ds_write_b128 that stages a product (lane gl of group g
+  // at g * stride + gl * BLK).  With G = 4 the natural stride of 288 words (72 units of 16 bytes) put every group on two bank
+  // groups: SQ_LDS_BANK_CONFLICT = 99 % of the LDS-active cycles (profiles/r02_early/r02_pmc_enc2048_k_enc4.json); a stride of
+  // 4 (mod 8) units makes g * stride + gl * 9 distinct (mod 16) for all 16 (g, gl) of a quarter wavefront.  G = 2 and G = 8 measure
+  // < 2 % conflicts at their natural strides.
+  static constexpr int NATURAL = ((OFF_WORDS + NW + 8 + 3) / 4) * 4;
+  static constexpr int WORDS = G == 4 ? ((NATURAL / 4 + 7 - 4) / 8 * 8 + 4) * 4 : NATURAL;
   static constexpr int THREADS = 256;
   static constexpr int GROUPS_PER_BLOCK = THREADS / G;
   static constexpr int BYTES_PER_BLOCK = WORDS * 4 * GROUPS_PER_BLOCK;
@@ -183,27 +187,11 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
   };
   constexpr int TROUNDS = TAB - 2;
   const int total = TROUNDS + (nwin - 1) * (WIN + 1);
-  // The table lives in HBM (it is far larger than L2): the entry a round of squarings will be multiplied by is known from the
-  // exponent alone, so its cache lines are touched when the round STARTS (one dword per 128-byte line of this lane's block)
-  // and the load of the entry itself, WIN products later, finds them in L2 instead of waiting for HBM.
-  constexpr int PF = (W * 4 + 127) / 128 + 1;
-  uint32_t pf = 0, pfv[PF];
-#pragma unroll
-  for (int k = 0; k < PF; k++) pfv[k] = 0;
   // the table stores of this lane are re-read by this lane only: program order suffices
 #pragma unroll 1
   for (int i = 0; i < total; i++) {
     const int step = i - TROUNDS;
-    if (step >= 0 && step % (WIN + 1) == 0) {
-      const uint32_t* nxt = tab + window(nwin - 2 - step / (WIN + 1)) * L + g.gl * W;
-#pragma unroll
-      for (int k = 0; k < PF; k++) pfv[k] = nxt[k * 32 < W ? k * 32 : W - 1];      // not looked at until the entry is loaded
-    }
-    if (step >= 0 && step % (WIN + 1) == WIN) {
-#pragma unroll
-      for (int k = 0; k < PF; k++) pf ^= pfv[k];
-      load_limbs_global<G>(X, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
-    }
+    if (step >= 0 && step % (WIN + 1) == WIN) load_limbs_global<G>(X, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
     mmo_ip<G, SAFE>(g, NT, X);
     if (step < 0) {
       store_limbs_global<G>(tab + (i + 2) * L, X, g.gl);
@@ -212,8 +200,6 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
       stageB<G>(g, X);
     }
   }
-  // (keeps the touches alive: pf is data the compiler cannot prove zero, the condition never holds for 29-bit limbs)
-  if (pf == 0xFFFFFFFFu && X[0] == 0xFFFFFFFFu) X[0] = pf;
 }
 
 // (b) ONE exponent for the whole launch (Paillier Enc under a shared key: exponent n): sliding windows of
@@ -247,7 +233,10 @@ __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int e
     int val = 0;
     for (int k = i; k >= l; k--) val = (val << 1) | bit(k);
     if (!started) { ops[n++] = (uint8_t)(OP_FIRST | (val >> 1)); started = true; }
-    else { for (int k = 0; k < i - l + 1; k++) ops[n++] = 0; ops[n++] = (uint8_t)(OP_MUL | (val >> 1)); }
+    else {
+      for (int k = 0; k < i - l + 1; k++) ops[n++] = 0;
+      ops[n++] = (uint8_t)(OP_MUL | (val >> 1));
+    }
     i = l - 1;
   }
   ops[n] = OP_END;
