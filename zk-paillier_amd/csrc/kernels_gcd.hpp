@@ -11,7 +11,7 @@
 // and, for the inverse, to the cofactors modulo m in one more pass (u' = (f0 u + g0 v + c m) / 2^30 with the balanced
 // c = -(f0 u + g0 v) / m mod 2^30, so that |u'| < m forever).  len(a) + len(b) shrinks by about 30 bits per round: 258 rounds for
 // 4096-bit operands instead of ~5800 bit-serial ones.  b stays odd throughout; the loop ends when a == 0, gcd = b.
-// scratch/wbgcd_model.py is the word-for-word Python model of this file (int64 ranges asserted).
+// tools/wbgcd_model.py is the word-for-word Python model of this file (int64 ranges asserted).
 //
 // Data layout: every operand lives in thread-interleaved LDS (word w of this lane at p[w * S], conflict-free); all loads of a
 // chunk of CH words are issued before its first store.  kw (words per operand) is a multiple of CH.
