@@ -564,6 +564,8 @@ struct EncArgs {
   int mode;                  // 0 = Enc, 1 = RangeProofNi verify work list, 2 = flat Enc-and-compare (m, r, c1 = expected | factor a, cipher_x = factor b | null, verdict = ok bytes)
   // mode 0: item i -> m[i], r[i], out[i]; key index = i / items_per_key
   const uint32_t* m; const uint32_t* r; uint32_t* out; uint64_t items_per_key;
+  uint64_t half;                // != 0: items [half, count) are a second set (m2, r2, out2), indexed from 0 again
+  const uint32_t* m2; const uint32_t* r2; uint32_t* out2;
   int m_words, r_words;         // mode 0: words per m / r element (0 = n_bits/32; m may be null when m_words < 0: m = 0)
   // mode 1: item list
   const uint32_t* item_proof;   // [count] proof index b
@@ -626,12 +628,17 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
     bool mask_row = false;
     uint64_t b = 0;
     int mw = kw, rw_ = kw;
+    uint32_t* pout = nullptr;
     if (a.mode == 0) {
-      key = item / a.items_per_key;
+      // a launch may carry two equally long halves (c1 = Enc(w1, r1) and c2 = Enc(w2, r2) of a prove step): one grid, one tail
+      const bool second = a.half && item >= a.half;
+      const uint64_t it = second ? item - a.half : item;
+      key = it / a.items_per_key;
       mw = a.m_words < 0 ? 0 : (a.m_words ? a.m_words : kw);
       rw_ = a.r_words ? a.r_words : kw;
-      pm = a.m + item * mw;
-      pr = a.r + item * rw_;
+      pm = (second ? a.m2 : a.m) + it * mw;
+      pr = (second ? a.r2 : a.r) + it * rw_;
+      pout = (second ? a.out2 : a.out) + it * 2 * kw;
     } else if (a.mode == 2) {
       // flat Enc-and-compare (zkp_paillier_enc_check_batch): expected = c1[item], or c1[item] * cipher_x[item] mod n^2
       key = item / a.items_per_key;
@@ -694,7 +701,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
       if (s == 5) {
         if (a.mode == 0) {
           canonical_words<G>(g, Y, cst + CL::OFF_N);                   // words()[0..NW) = c
-          if (live) for (int w = g.gl; w < 2 * kw; w += G) a.out[item * 2 * kw + w] = valid ? g.words()[w] : 0u;
+          if (live) for (int w = g.gl; w < 2 * kw; w += G) pout[w] = valid ? g.words()[w] : 0u;
         } else {
           canonical_limbs<G>(g, Y);                                    // keep c (exact limbs of the canonical residue) for the final comparison
 #pragma unroll
