@@ -65,7 +65,7 @@ typedef struct zkp_ctx zkp_ctx;
 int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out_ctx);
 int32_t zkp_ctx_destroy(zkp_ctx* ctx);
 const char* zkp_backend_name(void);               /* "hip-gfx950" */
-int32_t zkp_build_limbs_per_lane(void);           /* compile-time W of the kernels (18, or 9): G = 144/W lanes per 4096-bit integer */
+int32_t zkp_build_limbs_per_lane(void);           /* compile-time W of the kernels (36; 18 or 9 in the alternative builds): G = 144/W lanes per 4096-bit integer */
 const char* zkp_last_error_string(zkp_ctx* ctx);  /* valid until the next call on ctx */
 void* zkp_ctx_stream(zkp_ctx* ctx);               /* the hipStream_t every launch uses */
 int32_t zkp_ctx_synchronize(zkp_ctx* ctx);

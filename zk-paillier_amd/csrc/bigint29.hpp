@@ -7,7 +7,7 @@
 //     a carry-free one.  With 29-bit limbs a 64-bit column accumulator absorbs 64 products
 //     before it can overflow, so the inner loops are pure v_mad_u64_u32 chains.
 //   * one big integer is spread over a group of G lanes of a wavefront, W limbs per lane
-//     (W = 18 by default, 9 with -DZKP_W=9); G*W = 72 limbs = 2088 bits (moduli up to 2048 bits:
+//     (W = 36 by default; -DZKP_W=18 / 9 build the earlier geometries); G*W = 72 limbs = 2088 bits (moduli up to 2048 bits:
 //     n, N of the DLog proof), 144 limbs = 4176 bits (n^2 for a 2048-bit n), 288 limbs =
 //     8352 bits (n^2 for a 4096-bit n); a 64-lane wavefront works on 64/G independent
 //     modular exponentiations.
@@ -35,9 +35,10 @@ constexpr uint32_t LMASK = (1u << LB) - 1;
 constexpr int BLK = (W + 3) & ~3;           // LDS words per W-limb block (16-B multiple: keeps ds_read_b128 aligned)
 static_assert(W == 9 || W == 18 || W == 36, "limbs per lane");
 // minimum waves per SIMD requested from the register allocator for the modexp-class kernels: the hot
-// loop (montmul) needs ~70 VGPRs at W = 9 and ~150 at W = 18; values that live across an exponentiation
-// may spill around it.  Measured on MI355X (Enc/s at n = 2048): W=9 @5 waves 251 K, W=18 @2 waves 269 K,
-// W=18 @3 waves 265 K — the larger window halves the per-limb overhead instructions per multiply.
+// loop (montmul) needs ~70 VGPRs at W = 9, ~150 at W = 18 and all 256 at W = 36 (72 accumulator + 72 operand registers);
+// values that live across an exponentiation spill around it.  Measured on MI355X (Enc/s at n = 2048): W=9 @5 waves 251 K,
+// W=18 @2 waves 269 K (322 K at the end of round 1), W=36 @2 waves 337 K — every doubling of the window halves the
+// bookkeeping instructions per multiply-add.
 #ifndef ZKP_WPE
 #define ZKP_WPE (ZKP_W == 9 ? 5 : 2)   /* W = 36 also runs 2 waves per SIMD (256 VGPRs) */
 #endif
@@ -198,7 +199,7 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
 }
 
 // ---------------------------------------------------------------- representation changes
-// 32-bit words (LDS, `nwords` valid, zero padded up to at least nwords+2) -> this lane's 9 limbs
+// 32-bit words (LDS, `nwords` valid, zero padded up to at least nwords+2) -> this lane's W limbs
 __device__ __forceinline__ void limbs_from_words(uint32_t (&v)[W], const uint32_t* words, int gl) {
 #pragma unroll
   for (int k = 0; k < W; k++) {

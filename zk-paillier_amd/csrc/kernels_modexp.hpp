@@ -588,7 +588,7 @@ template <int G, class LL> __device__ __forceinline__ void stage_const(const Grp
 }
 
 // The kernel body is a short script of Montgomery products around the ladder, executed by ONE loop with ONE
-// generic montmul call site (every inlined montmul copy costs registers, which is what limits W = 18):
+// generic montmul call site (every inlined montmul copy costs registers and code size):
 //   s0  X  = r * R2 / R                      (to the Montgomery domain)
 //   s1  X  = X^n                             (ladder: powm)
 //   s2  Y  = m * NR / R = m*n mod n^2 ; Y += 1
