@@ -65,3 +65,17 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".inc", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle"
+
+
+def test_c_example_compiles_and_links(lib):
+    """examples/multi_gpu_verify.c is plain C against include/zkp_hip.h: the header must be usable from C, the symbols must link"""
+    src = os.path.join(ROOT, "examples", "multi_gpu_verify.c")
+    exe = os.path.join(ROOT, "build", "multi_gpu_verify")
+    pkg = os.path.join(ROOT, "zk-paillier_amd")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-L" + pkg, "-lzkp_hip",
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 2 and "no CPU fallback" in out.stderr        # fails loudly without a GPU

@@ -69,3 +69,25 @@ def test_multi_create_rejects_bad_device_list(zkp):
         zkp.MultiContext([0, 99])
     with pytest.raises(zkp.ZkpError):
         zkp.MultiContext([])
+
+
+def _build_c_example():
+    import os
+    import subprocess
+    src = os.path.join(H.ROOT, "examples", "multi_gpu_verify.c")
+    exe = os.path.join(H.ROOT, "build", "multi_gpu_verify")
+    pkg = os.path.join(H.ROOT, "zk-paillier_amd")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    if not os.path.exists(exe) or os.path.getmtime(src) > os.path.getmtime(exe) or os.path.getmtime(zkp.LIB_PATH) > os.path.getmtime(exe):
+        subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(H.ROOT, "include"), src, "-L" + pkg, "-lzkp_hip",
+                               "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_c_example_prove_and_verify_over_three_contexts():
+    """examples/multi_gpu_verify.c: a plain-C caller (what the Rust shim of INTEGRATION.md does) proves 64 RangeProofNi, tampers one,
+    verifies: 63 accepted, proof 5 rejected"""
+    import subprocess
+    out = subprocess.run([_build_c_example(), "0", "0", "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "contexts=3 proofs=64 accepted=63 rejected=1 prove_status_errors=0 verdict[5]=0" in out.stdout
