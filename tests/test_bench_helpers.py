@@ -1,0 +1,42 @@
+"""CPU tests of the bench plumbing that does not need a GPU: the synthetic key material, the algorithmic-work figures of SURVEY.md
+§8(d), the PMC file lookup behind `roofline.traffic`."""
+import importlib
+import math
+import os
+import sys
+
+import helpers as H
+
+sys.path.insert(0, H.ROOT)
+import bench  # noqa: E402
+
+synth = importlib.import_module("zk-paillier_amd.synth")
+
+
+def test_bench_key_material():
+    p, q, n = synth.bench_key_4096()
+    assert n == p * q and n.bit_length() == 4096 and p != q
+    assert H.is_probable_prime(p, rounds=4) and H.is_probable_prime(q, rounds=4)
+    keys = synth.distinct_keys_2048(4096)
+    assert len(set(keys)) == 4096 and all(k.bit_length() == 2048 and k % 2 == 1 for k in keys)
+    assert math.gcd(keys[0], keys[1]) > 1 or math.gcd(keys[0], keys[2]) > 1        # products of POOLED primes: neighbours share a factor
+    assert synth.BENCH_N == H.fixture_key()[2]
+
+
+def test_algorithmic_work_figures_match_the_survey():
+    # Enc(k=2048) = 8.085e7, Enc(k=4096) = 6.455e8, sigma^n mod n (k=2048) = 2.029e7 limb-MACs
+    assert abs(bench.enc_limb_macs(2048) / 8.085e7 - 1) < 1e-3
+    assert abs(bench.enc_limb_macs(4096) / 6.455e8 - 1) < 1e-3
+    assert abs(bench.modexp_limb_macs(2048, 2048) / 2.029e7 - 1) < 1e-3
+
+
+def test_pmc_lookup_reads_the_committed_profiles():
+    for kernel in ("k_enc<4, true>", "k_enc<4, false>", "k_enc<8, true>", "k_ck_check<2>"):
+        per, src = bench.pmc_traffic_per_modexp(kernel)
+        assert per and per > 1e4 and os.path.exists(os.path.join(H.ROOT, src)), kernel
+    assert bench.pmc_traffic_per_modexp("k_no_such_kernel") == (None, None)
+
+
+def test_argument_defaults_are_the_baseline_sizes():
+    a = bench.parse_args([])
+    assert (a.gpus, a.batch, a.n_bits, a.big_batch, a.distinct_batch) == (1, 4096, 2048, 4096, 4096)
