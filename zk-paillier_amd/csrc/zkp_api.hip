@@ -429,7 +429,6 @@ template <int G>
 static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m, const uint32_t* r,
                         uint32_t* out) {
   using CL = ConstLayout<G>;
-  using LL = LdsLayout<G>;
   const uint64_t nkeys = n_stride ? count : 1;
   int32_t st = enc_setup<G>(c, n_bits, n, n_stride, nkeys);
   if (st) return st;
@@ -478,7 +477,6 @@ template <int G>
 static int32_t enc_check_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m, const uint32_t* r,
                               const uint32_t* exp_or_a, const uint32_t* mulc_b, uint8_t* out_ok) {
   using CL = ConstLayout<G>;
-  using LL = LdsLayout<G>;
   const uint64_t nkeys = n_stride ? count : 1;
   int32_t st = enc_setup<G>(c, n_bits, n, n_stride, nkeys);
   if (st) return st;
