@@ -44,13 +44,17 @@ constexpr int HASH_PROOFS = 64;
 
 __device__ __forceinline__ void hash_stage_value(uint32_t* tile, int row_stride, const uint32_t* base, uint64_t proof_stride_words,
                                                   int nwords, int nproofs, int lane) {
-  // tile[p][w] = base[p * proof_stride_words + w]
+  // tile[p][w] = base[p * proof_stride_words + w].  32 loads in flight per wait: the loop is bound by HBM latency, not bandwidth
   wave_lds_fence();
   for (int w0 = 0; w0 < nwords; w0 += 64) {
     const int w = w0 + lane;
-#pragma unroll 8
-    for (int p = 0; p < HASH_PROOFS; p++) {
-      if (p < nproofs && w < nwords) tile[p * row_stride + w] = base[(uint64_t)p * proof_stride_words + w];
+    const bool inw = w < nwords;
+    for (int p0 = 0; p0 < HASH_PROOFS; p0 += 32) {
+      uint32_t t[32];
+#pragma unroll
+      for (int q = 0; q < 32; q++) t[q] = (inw && p0 + q < nproofs) ? base[(uint64_t)(p0 + q) * proof_stride_words + w] : 0u;
+#pragma unroll
+      for (int q = 0; q < 32; q++) if (inw && p0 + q < nproofs) tile[(p0 + q) * row_stride + w] = t[q];
     }
   }
   wave_lds_fence();

@@ -40,6 +40,11 @@ struct Sha256 {
     uint32_t w[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = buf[i * stride];
+    compress_words(w);
+  }
+
+  // one 64-byte block given as its 16 big-endian words (clobbers w)
+  __device__ __forceinline__ void compress_words(uint32_t (&w)[16]) {
     uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
 #pragma unroll
     for (int i = 0; i < 64; i++) {
@@ -88,14 +93,37 @@ struct Sha256 {
   __device__ __forceinline__ void put_word(uint32_t x) { put_bytes(x, 4); }
 
   // minimal big-endian encoding of the little-endian limb array v[0..nwords): zero -> one 00 byte
-  // ([upstream] curv BigInt::to_bytes over GMP: (sizeinbase(x,2)+7)/8 bytes)
+  // ([upstream] curv BigInt::to_bytes over GMP: (sizeinbase(x,2)+7)/8 bytes).
+  // The top word goes through the byte path (1..4 bytes).  Below it the value is whole words: once the block buffer is empty
+  // they are consumed 16 at a time straight into registers — each message word is one funnel shift of two neighbouring source
+  // words by the 0..3 pending bytes — without the per-word trip through the LDS block buffer; head (until the buffer is empty)
+  // and tail (< 16 words) take the word path.  Transcripts are ~2 000 blocks per proof: this is where the time goes.
   __device__ __forceinline__ void put_bigint(const uint32_t* v, int nwords) {
     int top = nwords - 1;
     while (top > 0 && v[top] == 0) top--;
     const uint32_t tw = v[top];
     const int k = tw == 0 ? 1 : (4 - (__clz(tw) >> 3));
     put_bytes(tw, k);
-    for (int i = top - 1; i >= 0; i--) put_word(v[i]);
+    int i = top - 1;
+    while (i >= 0 && widx != 0) { put_word(v[i]); i--; }
+    if (i >= 15) {
+      const int sh = 8 * npend;                       // 0, 8, 16, 24: the same for the whole value
+      uint32_t prev = pend;                           // npend pending bytes, right aligned
+      while (i >= 15) {
+        uint32_t w[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) w[q] = v[i - q];
+        if (sh) {
+#pragma unroll
+          for (int q = 0; q < 16; q++) { const uint32_t cur = w[q]; w[q] = (prev << (32 - sh)) | (cur >> sh); prev = cur; }
+        }
+        compress_words(w);
+        nbytes += 64;
+        i -= 16;
+      }
+      if (sh) pend = prev & ((1u << sh) - 1);
+    }
+    for (; i >= 0; i--) put_word(v[i]);
   }
 
   __device__ __forceinline__ void finish(uint32_t (&out)[8]) {
