@@ -182,6 +182,7 @@ def main():
     dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
     ctx = zkp.Context(local_rank)          # raises if the HIP library / a gfx950 GPU is missing
     lpl = int(zkp.load().zkp_build_limbs_per_lane())
+    ctx.set_geometry(lpl)                  # every batch leg runs on the throughput engine, whatever --batch says (the latency engine is measured in configs[0])
     engine = GpuEngine(ctx, torch)
 
     B, n_bits, EF = args.batch, args.n_bits, 128
@@ -387,15 +388,25 @@ def other_configs(args, ctx, synth, torch, dev, sync, pb, wt, rank, enc_roofline
     # and out (what a caller of the crate sees: staging and PCIe included); prove and verify timed separately
     pb1 = pb.slice(1, 2).to(None); wt1 = wt.slice(1, 2).to(None)
     v1 = np.zeros(1, np.uint8)
-    ctx.range_ni_prove(pb1.struct(), wt1.struct(), None, None, None, device=False)      # warm-up
-    t0 = time.perf_counter()
-    ctx.range_ni_prove(pb1.struct(), wt1.struct(), None, None, None, device=False)
-    t1 = time.perf_counter()
-    ctx.range_ni_verify(pb1.struct(), v1, device=False)
-    t2 = time.perf_counter()
-    ok = ok and bool(v1[0] == 1)
-    other["configs[0] one RangeProofNi, n=2048, host buffers (GPU latency)"] = {
-        "prove_ms": 1e3 * (t1 - t0), "verify_ms": 1e3 * (t2 - t1), "prove_plus_verify_ms": 1e3 * (t2 - t0), "accepted": bool(v1[0] == 1)}
+
+    def one_proof():
+        ctx.range_ni_prove(pb1.struct(), wt1.struct(), None, None, None, device=False)      # warm-up
+        t0 = time.perf_counter()
+        ctx.range_ni_prove(pb1.struct(), wt1.struct(), None, None, None, device=False)
+        t1 = time.perf_counter()
+        ctx.range_ni_verify(pb1.struct(), v1, device=False)
+        t2 = time.perf_counter()
+        return {"prove_ms": 1e3 * (t1 - t0), "verify_ms": 1e3 * (t2 - t1), "prove_plus_verify_ms": 1e3 * (t2 - t0), "accepted": bool(v1[0] == 1),
+                "limbs_per_lane": ctx.last_geometry()}
+
+    ctx.set_geometry(0)                      # automatic geometry: a call this small runs on the latency engine (W = 9) when it is loaded
+    try:
+        rec0 = one_proof()
+    finally:
+        ctx.set_geometry(lpl)                # the batch legs are pinned to the throughput engine
+    rec0["on_the_throughput_engine"] = one_proof()
+    ok = ok and rec0["accepted"] and rec0["on_the_throughput_engine"]["accepted"]
+    other["configs[0] one RangeProofNi, n=2048, host buffers (GPU latency)"] = rec0
 
     # configs[3]: 65536 NiCorrectKeyProof verifies, n = 2048, 65536 distinct (pseudo-)moduli: pure throughput shape,
     # every record is expected to be rejected (random sigma); accept parity is covered by tests/test_gpu_fullsize.py

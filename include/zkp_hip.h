@@ -63,9 +63,25 @@ enum { ZKP_RESP_OPEN = 0, ZKP_RESP_MASK = 1 };
 typedef struct zkp_ctx zkp_ctx;
 
 int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out_ctx);
+/* The same, launching on a stream the caller owns (a hipStream_t, e.g. the framework's current stream); the ctx never
+ * destroys it. */
+int32_t zkp_ctx_create_on_stream(int32_t device_id, void* hip_stream, zkp_ctx** out_ctx);
 int32_t zkp_ctx_destroy(zkp_ctx* ctx);
 const char* zkp_backend_name(void);               /* "hip-gfx950" */
-int32_t zkp_build_limbs_per_lane(void);           /* compile-time W of the kernels (36; 18 or 9 in the alternative builds): G = 144/W lanes per 4096-bit integer */
+int32_t zkp_build_limbs_per_lane(void);           /* compile-time W of the throughput kernels (36): G = 144/W lanes per 4096-bit integer */
+
+/* Two kernel geometries serve one ctx.  The throughput engine (libzkp_hip.so itself: W = 36 limbs per lane, 4 lanes per
+ * 4096-bit integer) is the one the batch metric is quoted on.  A modular exponentiation is a chain of ~2400 dependent
+ * products, so ONE proof (the reference's own bench, benches/all.rs:55-71) takes as long as ~30 of them there; the latency
+ * engine (libzkp_hip_lat.so next to this library, the same sources built with W = 9: 16 lanes per integer) halves that time
+ * and is chosen automatically while a call's work fits ~2 wavefronts per SIMD of it.  Results are bit-identical.
+ * zkp_ctx_set_geometry: limbs_per_lane 0 = automatic (default), 36 / 9 = always that engine (ZKP_EINVAL when it is not
+ * loaded).  zkp_ctx_last_geometry: limbs per lane of the engine the most recent batch call ran on.
+ * zkp_ctx_latency_limbs_per_lane: W of the loaded latency engine, 0 when there is none (small calls then run on the
+ * throughput engine: slower, never wrong). */
+int32_t zkp_ctx_set_geometry(zkp_ctx* ctx, int32_t limbs_per_lane);
+int32_t zkp_ctx_last_geometry(zkp_ctx* ctx);
+int32_t zkp_ctx_latency_limbs_per_lane(zkp_ctx* ctx);
 const char* zkp_last_error_string(zkp_ctx* ctx);  /* valid until the next call on ctx */
 void* zkp_ctx_stream(zkp_ctx* ctx);               /* the hipStream_t every launch uses */
 int32_t zkp_ctx_synchronize(zkp_ctx* ctx);

@@ -45,9 +45,13 @@ def oracle():
     return oracle_lib.Oracle()
 
 
-@pytest.fixture(scope="session")
-def ctx(zkp):
-    """one GPU context for the whole -m gpu session; fails loudly without GPU / built library"""
+@pytest.fixture(scope="session", params=[36, 9], ids=["w36", "w9"])
+def ctx(zkp, request):
+    """one GPU context for the whole -m gpu session; fails loudly without GPU / built library.  Every test that takes it runs
+    twice: pinned to the throughput engine (36 limbs per lane) and to the latency engine (9; libzkp_hip_lat.so) — left to
+    itself the library would send these small batches to the latency engine only (tests/test_gpu_geometry.py covers that)."""
     c = zkp.Context(0)
+    c.set_geometry(request.param)          # raises when the engine is not loaded
+    c.test_geometry = request.param
     yield c
     c.close()

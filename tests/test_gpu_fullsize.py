@@ -12,6 +12,12 @@ pytestmark = pytest.mark.gpu
 synth = importlib.import_module("zk-paillier_amd.synth")
 
 
+@pytest.fixture(autouse=True)
+def _throughput_engine_only(ctx):
+    if ctx.test_geometry != 36:
+        pytest.skip("full-size batches belong to the throughput engine (the latency engine serves calls of a few proofs)")
+
+
 def test_config2_3_batch4096_prove_verify_n2048(ctx, oracle):
     torch = pytest.importorskip("torch")
     B, n_bits = 4096, 2048

@@ -98,6 +98,10 @@ EXPORTS = {
     "zkp_multi_size": (C.c_uint32, [C.c_void_p]),
     "zkp_multi_ctx": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "zkp_multi_last_error_string": (C.c_char_p, [C.c_void_p]),
+    "zkp_ctx_create_on_stream": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "zkp_ctx_set_geometry": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "zkp_ctx_last_geometry": (C.c_int32, [C.c_void_p]),
+    "zkp_ctx_latency_limbs_per_lane": (C.c_int32, [C.c_void_p]),
     "zkp_multi_range_ni_prove_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness), C.c_void_p, C.c_void_p, C.c_void_p]),
     "zkp_multi_range_ni_verify_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p]),
     "zkp_multi_correct_key_ni_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -195,10 +199,15 @@ class MultiContext:
 class Context:
     """One GPU + one stream (zkp_ctx)."""
 
-    def __init__(self, device_id: int = 0):
+    def __init__(self, device_id: int = 0, stream=None):
+        """stream: a hipStream_t (integer / pointer) the caller owns, e.g. torch.cuda.current_stream().cuda_stream; default: the
+        ctx creates its own"""
         self.lib = load()
         h = C.c_void_p()
-        st = self.lib.zkp_ctx_create(device_id, C.byref(h))
+        if stream is None:
+            st = self.lib.zkp_ctx_create(device_id, C.byref(h))
+        else:
+            st = self.lib.zkp_ctx_create_on_stream(device_id, C.c_void_p(stream), C.byref(h))
         if st != ZKP_OK:
             raise ZkpError(f"zkp_ctx_create(device {device_id}) failed with status {st} "
                            "(no gfx950 GPU / HIP runtime error; there is no CPU fallback)")
@@ -218,6 +227,18 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.zkp_ctx_synchronize(self.h))
+
+    def set_geometry(self, limbs_per_lane: int):
+        """0 = automatic (small calls go to the latency engine), 36 / 9 = always that engine"""
+        self.check(self.lib.zkp_ctx_set_geometry(self.h, limbs_per_lane))
+
+    def last_geometry(self) -> int:
+        """limbs per lane of the engine the most recent batch call ran on"""
+        return self.lib.zkp_ctx_last_geometry(self.h)
+
+    def latency_limbs_per_lane(self) -> int:
+        """W of the loaded latency engine (libzkp_hip_lat.so); 0 when it is not there"""
+        return self.lib.zkp_ctx_latency_limbs_per_lane(self.h)
 
     def stream(self):
         return self.lib.zkp_ctx_stream(self.h)

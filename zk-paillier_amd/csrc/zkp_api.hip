@@ -2,11 +2,13 @@
 // One ctx = one GPU + one HIP stream; all device scratch (Montgomery constants, window
 // tables, work lists) is owned by the ctx and grown on demand.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
 #include <new>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,7 +35,13 @@ struct zkp_ctx {
   uint32_t* setup_flag_host = nullptr; // its pinned host mirror
   int device = 0;
   hipStream_t stream = nullptr;
+  bool owns_stream = true;
   int cus = 0;
+  // the latency engine's twin of this ctx (same device, same stream); null in the latency engine itself or when it is not loaded
+  const struct LatEngine* lat = nullptr;
+  zkp_ctx* lat_ctx = nullptr;
+  int geometry = 0;                    // 0 = automatic, else the limbs per lane every call must run on
+  int last_geometry = 0;
   std::string err;
   DevBuf consts, consts2, table, scratch[48];
   // timing of the dominant kernels
@@ -65,6 +73,83 @@ static int32_t zkp_caught(zkp_ctx* c, int32_t st, const char* what) noexcept {
   catch (const std::bad_alloc&) { return zkp_caught((ctx), ZKP_ENOMEM, "out of host memory"); }               \
   catch (const std::exception& e_) { return zkp_caught((ctx), ZKP_EDEVICE, e_.what()); }                      \
   catch (...) { return zkp_caught((ctx), ZKP_EDEVICE, "unknown exception"); }
+
+// ---- the latency engine -----------------------------------------------------------------------
+// libzkp_hip_lat.so is THIS source built with W = 9 (-DZKP_SECONDARY_ENGINE): four times the lanes per big integer, so a
+// chain of dependent Montgomery products finishes in less than half the time while the launch is too small to fill the GPU
+// anyway.  It is loaded once per process from the directory of this library (or $ZKP_HIP_LAT_LIB); every ctx gets a twin
+// ctx of it on the same stream, and the batch entry points hand small calls over (ZKP_ROUTE).
+#define ZKP_LAT_FUNCS(X)                                                                                                        \
+  X(zkp_ctx_create_on_stream) X(zkp_ctx_destroy) X(zkp_last_error_string) X(zkp_build_limbs_per_lane) X(zkp_ctx_release_staging) \
+  X(zkp_timing_reset) X(zkp_timing_get) X(zkp_modexp_batch) X(zkp_paillier_enc_batch) X(zkp_paillier_enc_check_batch)            \
+  X(zkp_range_ni_prove_batch) X(zkp_range_ni_verify_batch) X(zkp_range_generate_encrypted_pairs_batch)                           \
+  X(zkp_range_verifier_output_batch) X(zkp_correct_key_ni_verify_batch) X(zkp_dlog_prove_batch) X(zkp_dlog_verify_batch)         \
+  X(zkp_zero_proof_prove_batch) X(zkp_zero_proof_verify_batch) X(zkp_ciphertext_proof_prove_batch)                               \
+  X(zkp_ciphertext_proof_verify_batch) X(zkp_verlin_proof_prove_batch) X(zkp_verlin_proof_verify_batch)                          \
+  X(zkp_mul_proof_prove_batch) X(zkp_mul_proof_verify_batch) X(zkp_correct_message_prove_batch) X(zkp_correct_message_verify_batch)
+
+struct LatEngine {
+  void* handle = nullptr;
+  int limbs_per_lane = 0;
+#define X(f) decltype(&f) p_##f = nullptr;
+  ZKP_LAT_FUNCS(X)
+#undef X
+};
+
+// status of a call made on the twin ctx, with its error text copied over (the twin only exists in the throughput build)
+static int32_t lat_forward_plain(zkp_ctx* c, int32_t st) {
+  if (st && c->lat_ctx) { try { c->err = c->lat->p_zkp_last_error_string(c->lat_ctx); } catch (...) {} }
+  return st;
+}
+
+#ifndef ZKP_SECONDARY_ENGINE
+static const LatEngine* lat_engine() {
+  static LatEngine eng;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::string path;
+    if (const char* e = std::getenv("ZKP_HIP_LAT_LIB")) path = e;
+    else {
+      Dl_info info;
+      if (!dladdr((const void*)&zkp_backend_name, &info) || !info.dli_fname) return;
+      path = info.dli_fname;
+      const size_t slash = path.rfind('/');
+      path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libzkp_hip_lat.so";
+    }
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    bool all = true;
+#define X(f) eng.p_##f = (decltype(&f))dlsym(h, #f); all = all && eng.p_##f;
+    ZKP_LAT_FUNCS(X)
+#undef X
+    if (!all || eng.p_zkp_build_limbs_per_lane() == W) { dlclose(h); return; }   // a stale or identical build: not an engine
+    eng.limbs_per_lane = eng.p_zkp_build_limbs_per_lane();
+    eng.handle = h;
+  });
+  return eng.handle ? &eng : nullptr;
+}
+
+// does this call (items independent modexp chains under mod_bits-bit moduli) go to the latency engine?
+static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits) {
+  c->last_geometry = W;
+  if (!c->lat_ctx || c->geometry == W || items == 0) return false;
+  bool take = c->geometry == c->lat->limbs_per_lane;
+  if (!take) {
+    // automatic: the latency engine wins while its launch stays within ~2 wavefronts per SIMD (measured on MI355X,
+    // tests/perf_gpu_latency.py: RangeProofNi n = 2048, 32 proofs = 2048 wavefronts: 46 ms against 68 ms; at twice that the
+    // throughput engine is ahead)
+    const uint64_t limbs = mod_bits <= 2048 ? 72 : mod_bits <= 4096 ? 144 : 288;
+    const uint64_t lanes = limbs / (uint64_t)c->lat->limbs_per_lane;
+    take = items <= (2ull * 4 * (uint64_t)c->cus * 64) / lanes;
+  }
+  if (take) c->last_geometry = c->lat->limbs_per_lane;
+  return take;
+}
+#define ZKP_ROUTE(c, items, mod_bits, fn, ...)                                              \
+  if ((c) && route_latency((c), (items), (mod_bits))) return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__));
+#else
+#define ZKP_ROUTE(c, items, mod_bits, fn, ...)
+#endif
 
 static int32_t ensure(zkp_ctx* c, DevBuf& b, size_t bytes) {
   if (b.cap >= bytes) return ZKP_OK;
@@ -232,7 +317,7 @@ template <int G> static void launch_k_enc(zkp_ctx* c, unsigned blocks, const Enc
 }
 
 // ---- ctx ------------------------------------------------------------------------------------
-extern "C" int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out) try {
+static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream, zkp_ctx** out) {
   if (!out) return ZKP_EINVAL;
   *out = nullptr;
   int n = 0;
@@ -244,18 +329,53 @@ extern "C" int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out) try {
   zkp_ctx* c = new zkp_ctx();
   c->device = device_id;
   c->cus = p.multiProcessorCount;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKP_EDEVICE; }
+  c->last_geometry = W;
+  c->owns_stream = own_stream;
+  c->stream = stream;
+  if (own_stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKP_EDEVICE; }
   if (hipHostMalloc((void**)&c->pinned_counts, zkp_ctx::PINNED_SLOTS * sizeof(unsigned long long)) != hipSuccess) c->pinned_counts = nullptr;
   if (hipMalloc((void**)&c->setup_flag, 64) != hipSuccess || hipHostMalloc((void**)&c->setup_flag_host, 64) != hipSuccess ||
       hipMemset(c->setup_flag, 0, 64) != hipSuccess) { (void)zkp_ctx_destroy(c); return ZKP_EDEVICE; }
+#ifndef ZKP_SECONDARY_ENGINE
+  if (const LatEngine* eng = lat_engine()) {
+    const int32_t st = eng->p_zkp_ctx_create_on_stream(device_id, (void*)c->stream, &c->lat_ctx);
+    if (st) { (void)zkp_ctx_destroy(c); return st; }
+    c->lat = eng;
+  }
+  if (const char* g = std::getenv("ZKP_GEOMETRY")) {                        // testing aid: the same as zkp_ctx_set_geometry
+    const int32_t st = zkp_ctx_set_geometry(c, std::atoi(g));
+    if (st) { (void)zkp_ctx_destroy(c); return st; }
+  }
+#endif
   *out = c;
   return ZKP_OK;
+}
+
+extern "C" int32_t zkp_ctx_create(int32_t device_id, zkp_ctx** out) try {
+  return ctx_create(device_id, nullptr, true, out);
 } ZKP_CATCH(nullptr)
+
+extern "C" int32_t zkp_ctx_create_on_stream(int32_t device_id, void* hip_stream, zkp_ctx** out) try {
+  return ctx_create(device_id, (hipStream_t)hip_stream, false, out);
+} ZKP_CATCH(nullptr)
+
+extern "C" int32_t zkp_ctx_set_geometry(zkp_ctx* c, int32_t limbs_per_lane) try {
+  if (!c) return ZKP_EINVAL;
+  if (limbs_per_lane != 0 && limbs_per_lane != W && !(c->lat && limbs_per_lane == c->lat->limbs_per_lane)) {
+    c->err = "zkp_ctx_set_geometry: no engine with " + std::to_string(limbs_per_lane) + " limbs per lane is loaded";
+    return ZKP_EINVAL;
+  }
+  c->geometry = limbs_per_lane;
+  return ZKP_OK;
+} ZKP_CATCH(c)
+extern "C" int32_t zkp_ctx_last_geometry(zkp_ctx* c) { return c ? c->last_geometry : 0; }
+extern "C" int32_t zkp_ctx_latency_limbs_per_lane(zkp_ctx* c) { return (c && c->lat) ? c->lat->limbs_per_lane : 0; }
 
 extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   if (!c) return ZKP_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->lat_ctx) (void)c->lat->p_zkp_ctx_destroy(c->lat_ctx);
   for (DevBuf* b : {&c->consts, &c->consts2, &c->table}) if (b->p) (void)hipFree(b->p);
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -263,7 +383,7 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   for (auto& b : c->stage_free) (void)hipFree(b.p);
   if (c->setup_flag) (void)hipFree(c->setup_flag);
   if (c->setup_flag_host) (void)hipHostFree(c->setup_flag_host);
-  (void)hipStreamDestroy(c->stream);
+  if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ZKP_OK;
 } ZKP_CATCH(c)
@@ -274,6 +394,7 @@ extern "C" int32_t zkp_ctx_release_staging(zkp_ctx* c) try {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (auto& b : c->stage_free) (void)hipFree(b.p);
   c->stage_free.clear();
+  if (c->lat_ctx) return lat_forward_plain(c, c->lat->p_zkp_ctx_release_staging(c->lat_ctx));
   return ZKP_OK;
 } ZKP_CATCH(c)
 
@@ -292,6 +413,7 @@ extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) try {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->timing = enable != 0;
   c->ev_used = 0; c->timed_launches = 0; c->timed_modexps = 0; c->pinned_used = 0;
+  if (c->lat_ctx) return lat_forward_plain(c, c->lat->p_zkp_timing_reset(c->lat_ctx, enable));
   return ZKP_OK;
 } ZKP_CATCH(c)
 
@@ -304,11 +426,17 @@ extern "C" int32_t zkp_timing_get(zkp_ctx* c, double* ms, uint64_t* launches, ui
     HIPCHK(c, hipEventElapsedTime(&t, c->ev[i].first, c->ev[i].second));
     total += t;
   }
-  if (ms) *ms = total;
-  if (launches) *launches = c->timed_launches;
-  uint64_t extra = 0;
+  uint64_t extra = 0, lat_launches = 0, lat_modexps = 0;
   for (size_t i = 0; i < c->pinned_used; i++) extra += c->pinned_counts[i];
-  if (modexps) *modexps = c->timed_modexps + extra;
+  if (c->lat_ctx) {                                  // the twin ctx's share of the calls since the reset
+    double lat_ms = 0;
+    const int32_t st = lat_forward_plain(c, c->lat->p_zkp_timing_get(c->lat_ctx, &lat_ms, &lat_launches, &lat_modexps));
+    if (st) return st;
+    total += lat_ms;
+  }
+  if (ms) *ms = total;
+  if (launches) *launches = c->timed_launches + lat_launches;
+  if (modexps) *modexps = c->timed_modexps + extra + lat_modexps;
   return ZKP_OK;
 } ZKP_CATCH(c)
 
@@ -354,6 +482,7 @@ static int32_t modexp_impl(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const 
 extern "C" int32_t zkp_modexp_batch(zkp_ctx* c, uint32_t mod_bits, uint32_t exp_bits, uint64_t count, const uint32_t* base,
                                     const uint32_t* exp, uint64_t exp_stride, const uint32_t* mod, uint64_t mod_stride, uint32_t* out,
                                     uint32_t flags) try {
+  ZKP_ROUTE(c, count, mod_bits, zkp_modexp_batch, mod_bits, exp_bits, count, base, exp, exp_stride, mod, mod_stride, out, flags)
   if (!c) return ZKP_EINVAL;
   if (count == 0) return ZKP_OK;
   if (!base || !exp || !mod || !out || (mod_bits != 2048 && mod_bits != 4096 && mod_bits != 8192) || exp_bits == 0 || exp_bits % 32 ||
@@ -450,6 +579,7 @@ static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint3
 
 extern "C" int32_t zkp_paillier_enc_batch(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m,
                                           const uint32_t* r, uint32_t* out_c, uint32_t flags) try {
+  ZKP_ROUTE(c, count, 2 * n_bits, zkp_paillier_enc_batch, n_bits, count, n, n_stride, m, r, out_c, flags)
   if (!c) return ZKP_EINVAL;
   if (count == 0) return ZKP_OK;
   if (!n || !m || !r || !out_c || (n_bits != 1024 && n_bits != 2048 && n_bits != 4096) || count > (1ull << 40) || (n_stride && n_stride < n_bits / 32)) { c->err = "zkp_paillier_enc_batch: invalid argument"; return ZKP_EINVAL; }
@@ -500,6 +630,7 @@ static int32_t enc_check_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const
 extern "C" int32_t zkp_paillier_enc_check_batch(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m,
                                                 const uint32_t* r, const uint32_t* mulc_a, const uint32_t* mulc_b, const uint32_t* expected,
                                                 uint8_t* out_ok, uint32_t flags) try {
+  ZKP_ROUTE(c, count, 2 * n_bits, zkp_paillier_enc_check_batch, n_bits, count, n, n_stride, m, r, mulc_a, mulc_b, expected, out_ok, flags)
   if (!c) return ZKP_EINVAL;
   if (count == 0) return ZKP_OK;
   const bool product = mulc_a || mulc_b;
@@ -529,4 +660,6 @@ extern "C" int32_t zkp_paillier_enc_check_batch(zkp_ctx* c, uint32_t n_bits, uin
 #include "zkp_api_proofs.inc"
 #include "zkp_api_mul.inc"
 #include "zkp_api_serde.inc"
+#ifndef ZKP_SECONDARY_ENGINE
 #include "zkp_api_multi.inc"
+#endif
