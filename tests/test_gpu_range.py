@@ -121,6 +121,16 @@ def test_verify_tampering_matches_oracle(ctx, oracle):
     assert vo[0] == zkp.VERDICT_ACCEPT and vo[1] == zkp.VERDICT_REJECT
     assert vo[tampers.index(t_j_other)] == zkp.VERDICT_ACCEPT
     assert vo[tampers.index(t_r_plus_n)] == zkp.VERDICT_ACCEPT
+    # the same 16 proofs tiled to 640: a call of this size takes the one-stream sequence (hash -> plan -> k_enc), the 16-proof
+    # call above the two-stream one (hash next to k_enc, zkp_api_proofs.inc:range_verify_impl); both must say what the oracle says
+    tiles = 40
+    big = zkp.RangeBatch(n_bits, B * tiles, 128, shared_key=True)
+    big.n[:] = pb.n
+    for f in ("range", "ciphertext") + OUT_FIELDS:
+        getattr(big, f)[:] = np.tile(getattr(pb, f), (tiles,) + (1,) * (getattr(pb, f).ndim - 1))
+    vb = np.full(B * tiles, 7, np.uint8)
+    ctx.range_ni_verify(big.struct(), vb, device=False)
+    assert np.array_equal(vb, np.tile(vo, tiles))
 
 
 def test_boundary_masked_x(ctx, oracle):

@@ -131,12 +131,20 @@ struct VerifyPlanArgs {
   uint32_t* item_proof; uint32_t* item_row; unsigned long long* counter;
 };
 
+// Two further shapes serve calls of a few proofs, where the transcript hash (one lane per proof, ~10 ms) would otherwise sit
+// in front of an almost empty GPU: e == nullptr builds the work list from the response kinds alone (an Open row always costs
+// two Enc checks, a Mask row one; rows whose kind contradicts the challenge bit reject the proof whatever their Encs say), so
+// that k_enc can start while the hash runs on a second stream; item_proof == nullptr applies the predicates only.
 __global__ void __launch_bounds__(256) k_verify_plan(VerifyPlanArgs a) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const bool in = t < a.batch * a.ef;
   uint32_t nitems = 0;
   uint64_t b = 0; uint32_t i = 0;
-  if (in) {
+  if (in && !a.e) {
+    b = t / a.ef; i = (uint32_t)(t % a.ef);
+    const int kind = a.resp_kind[t];
+    nitems = kind == ZKP_RESP_OPEN ? 2 : kind == ZKP_RESP_MASK ? 1 : 0;
+  } else if (in) {
     b = t / a.ef; i = (uint32_t)(t % a.ef);
     if (a.verdict[b] != ZKP_VERDICT_MALFORMED) {
       const int ei = challenge_bit(a.e + b * 32, i);
@@ -159,6 +167,7 @@ __global__ void __launch_bounds__(256) k_verify_plan(VerifyPlanArgs a) {
       }
     }
   }
+  if (!a.item_proof) return;
   // wave-aggregated append
   const unsigned long long m2 = __ballot(nitems == 2), m1 = __ballot(nitems == 1);
   const int lane = threadIdx.x & 63;
@@ -172,6 +181,27 @@ __global__ void __launch_bounds__(256) k_verify_plan(VerifyPlanArgs a) {
     a.item_proof[base + before + k] = (uint32_t)b;
     a.item_row[base + before + k] = (i << 1) | k;
   }
+}
+
+// Joins the two strands of a small verify call: verdict[] holds what the hash + predicate strand decided, enc_verdict[] what
+// the Enc checks of the kind-derived work list found.  The result is what the one-stream sequence writes: a failed Enc check
+// rejects; an even key (k_enc says MALFORMED) marks the proof only if it has a row whose Encs the one-stream plan would have
+// scheduled (kind matching its challenge bit).
+struct VerdictMergeArgs {
+  uint8_t* verdict; const uint8_t* enc_verdict; const uint8_t* e; const uint8_t* resp_kind; uint32_t ef; uint64_t batch;
+};
+__global__ void __launch_bounds__(256) k_verdict_merge(VerdictMergeArgs a) {
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.batch) return;
+  const uint8_t v = a.verdict[b], ev = a.enc_verdict[b];
+  if (v == ZKP_VERDICT_MALFORMED || ev == ZKP_VERDICT_ACCEPT) return;
+  if (ev == ZKP_VERDICT_REJECT) { a.verdict[b] = ZKP_VERDICT_REJECT; return; }
+  bool any = false;
+  for (uint32_t i = 0; i < a.ef; i++) {
+    const int ei = challenge_bit(a.e + b * 32, i), kind = a.resp_kind[b * a.ef + i];
+    any = any || (!ei && kind == ZKP_RESP_OPEN) || (ei && kind == ZKP_RESP_MASK);
+  }
+  if (any) a.verdict[b] = ZKP_VERDICT_MALFORMED;
 }
 
 // ------------------------------------------------------------------------------------------

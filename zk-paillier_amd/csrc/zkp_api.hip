@@ -42,6 +42,9 @@ struct zkp_ctx {
   zkp_ctx* lat_ctx = nullptr;
   int geometry = 0;                    // 0 = automatic, else the limbs per lane every call must run on
   int last_geometry = 0;
+  // second stream + fork / join events for calls of a few proofs (hash next to the Enc checks); created on first use
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   DevBuf consts, consts2, table, scratch[48];
   // timing of the dominant kernels
@@ -301,6 +304,15 @@ static int32_t fresh_work_counter(zkp_ctx* c, unsigned long long** out) {
   return ZKP_OK;
 }
 
+// the ctx's second stream (work forked from and joined back into c->stream inside one call)
+static int32_t side_stream(zkp_ctx* c) {
+  if (c->side) return ZKP_OK;
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  return ZKP_OK;
+}
+
 template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_t items, unsigned* blocks_out) {
   using LL = LdsLayout<G>;
   const uint64_t need = (items + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK;
@@ -383,6 +395,9 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   for (auto& b : c->stage_free) (void)hipFree(b.p);
   if (c->setup_flag) (void)hipFree(c->setup_flag);
   if (c->setup_flag_host) (void)hipHostFree(c->setup_flag_host);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ZKP_OK;
