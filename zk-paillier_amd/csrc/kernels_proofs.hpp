@@ -119,6 +119,203 @@ __global__ void __launch_bounds__(HASH_PROOFS) k_range_hash(RangeHashArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same challenge, ONE WAVEFRONT PER PROOF: for calls of a few proofs, where the one-lane-per-proof kernel above leaves 63
+// lanes of its wavefront idle for the ~2 000 chained compressions of a transcript.  SHA-256's rounds are a serial chain, its
+// message schedule is not: the lanes assemble the byte stream together (every value is staged into LDS once, its words
+// funnel-shifted into stream position by the pending bytes), each lane expands the schedule of one of 64 consecutive blocks
+// (W[r] + K[r] into LDS), and then all lanes walk the 64 x 64 rounds in lockstep reading those sums as broadcasts — about half
+// the instructions of a compression leave the serial path (9.5 -> ~5 ms per 131 KB transcript).
+constexpr int HW_BLOCKS = 64;                      // blocks per batch: one schedule per lane
+constexpr int HW_WORDS = 16 * HW_BLOCKS;
+constexpr int HW_KW_STRIDE = 68;                   // 64 sums per block, padded: 16-byte aligned rows for ds_read_b128
+__host__ __device__ constexpr int hw_pidx(int s) { return s + (s >> 4); }      // stream word -> LDS slot (a block's 16 words stay apart in the banks)
+__host__ __device__ constexpr int hw_kw_offset(int kw) { return (hw_pidx(HW_WORDS + 2 * kw + 8) + 4) & ~3; }   // 16-byte aligned
+__host__ __device__ constexpr int hw_lds_words(int kw) { return hw_kw_offset(kw) + HW_BLOCKS * HW_KW_STRIDE + (2 * kw + 4); }
+
+struct WaveShaState { uint32_t h[8]; };
+
+// Compress the first nblk (<= 64) blocks of the chunk buffer.  One out-of-line copy (two unrolled SHA bodies per call site in
+// one function is more than the register allocator of this compiler survives); the LDS areas are derived from the kernel's
+// dynamic shared array here so that they stay LDS pointers (a pointer handed through memory becomes a flat one).
+__device__ __noinline__ WaveShaState hw_compress(WaveShaState st, int nblk, int kw, int lane) {
+  extern __shared__ __align__(16) uint32_t hash_lds[];
+  uint32_t* chunk = hash_lds;
+  uint32_t* kwbuf = hash_lds + hw_kw_offset(kw);
+  wave_lds_fence();
+  if (lane < nblk) {                                          // this lane's block: schedule + round constants
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = chunk[hw_pidx(16 * lane + i)];
+    uint32_t* out = kwbuf + lane * HW_KW_STRIDE;
+    // (16 at a time: with all 64 round constants as literals the iterative-ilp scheduler of this compiler crashes the register allocator)
+#pragma unroll 16
+    for (int i = 0; i < 64; i++) {
+      uint32_t wi;
+      if (i < 16) wi = w[i];
+      else {
+        const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+        wi = w[i & 15] + Sha256::xor3(Sha256::ror(w15, 7), Sha256::ror(w15, 18), w15 >> 3) + w[(i - 7) & 15] +
+             Sha256::xor3(Sha256::ror(w2, 17), Sha256::ror(w2, 19), w2 >> 10);
+        w[i & 15] = wi;
+      }
+      out[i] = wi + SHA_K[i];
+    }
+  }
+  wave_lds_fence();
+#pragma unroll 1
+  for (int j = 0; j < nblk; j++) {                            // the serial chain, identical on every lane
+    const uint4* kp = reinterpret_cast<const uint4*>(kwbuf + j * HW_KW_STRIDE);
+    uint32_t a = st.h[0], b = st.h[1], c = st.h[2], d = st.h[3], e = st.h[4], f = st.h[5], g = st.h[6], hh = st.h[7];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const uint4 k4 = kp[q];
+      const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t S1 = Sha256::xor3(Sha256::ror(e, 6), Sha256::ror(e, 11), Sha256::ror(e, 25));
+        const uint32_t ch = (e & f) ^ (~e & g);
+        const uint32_t t1 = hh + S1 + ch + kk[r];
+        const uint32_t S0 = Sha256::xor3(Sha256::ror(a, 2), Sha256::ror(a, 13), Sha256::ror(a, 22));
+        const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
+      }
+    }
+    st.h[0] += a; st.h[1] += b; st.h[2] += c; st.h[3] += d; st.h[4] += e; st.h[5] += f; st.h[6] += g; st.h[7] += hh;
+  }
+  wave_lds_fence();
+  return st;
+}
+
+struct WaveSha {
+  WaveShaState st;
+  uint32_t* chunk;      // stream words not yet compressed (padded index)
+  uint32_t* row;        // one staged value + two words of head room
+  int wpos;             // words in chunk
+  uint32_t pend; int npend;
+  uint64_t nbytes;
+  int lane, kw;
+
+  __device__ __forceinline__ void init(uint32_t* lds, int kw_, int lane_) {
+    st.h[0] = 0x6a09e667; st.h[1] = 0xbb67ae85; st.h[2] = 0x3c6ef372; st.h[3] = 0xa54ff53a;
+    st.h[4] = 0x510e527f; st.h[5] = 0x9b05688c; st.h[6] = 0x1f83d9ab; st.h[7] = 0x5be0cd19;
+    chunk = lds;
+    row = lds + hw_kw_offset(kw_) + HW_BLOCKS * HW_KW_STRIDE;
+    wpos = 0; pend = 0; npend = 0; nbytes = 0; lane = lane_; kw = kw_;
+  }
+
+  // compress the first nblk blocks and move the rest of the chunk down
+  __device__ __forceinline__ void flush(int nblk) {
+    st = hw_compress(st, nblk, kw, lane);
+    const int rest = wpos - 16 * nblk;                       // <= 2kw + 8 words
+    uint32_t t[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const int q = lane + 64 * k; t[k] = q < rest ? chunk[hw_pidx(16 * nblk + q)] : 0u; }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const int q = lane + 64 * k; if (q < rest) chunk[hw_pidx(q)] = t[k]; }
+    wpos = rest;
+    wave_lds_fence();
+  }
+
+  // append the minimal big-endian bytes of a value (nwords <= 2kw little-endian words at src; zero -> one 00 byte)
+  __device__ __forceinline__ void put_bigint(const uint32_t* __restrict__ src, int nwords) {
+    wave_lds_fence();
+    unsigned long long nz[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int w = lane + 64 * k;
+      const uint32_t x = w < nwords ? src[w] : 0u;
+      if (w < nwords + 2) row[w] = x;
+      nz[k] = __ballot(x != 0);
+    }
+    int top = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) if (nz[k]) top = 64 * k + 63 - __builtin_clzll(nz[k]);
+    wave_lds_fence();
+    const uint32_t tw = row[top];
+    const int kb = tw == 0 ? 1 : (4 - (__clz(tw) >> 3));        // bytes of the top word
+    // E = pend || value as one little-endian number: the pending bytes sit right above the value's top byte
+    if (npend && lane == 0) {
+      if (kb < 4) { row[top] = tw | (pend << (8 * kb)); row[top + 1] = kb + npend > 4 ? pend >> (8 * (4 - kb)) : 0u; }
+      else row[top + 1] = pend;
+    }
+    wave_lds_fence();
+    const int elen = 4 * top + kb + npend, nfull = elen >> 2, rem = elen & 3, sh = 8 * rem;
+    for (int q = lane; q < nfull; q += 64) {                    // stream word q = the 4 bytes of E below byte offset elen - 4q
+      const int u = elen - 4 - 4 * q;
+      const uint32_t lo = row[u >> 2], hi = row[(u >> 2) + 1];
+      chunk[hw_pidx(wpos + q)] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    }
+    pend = rem ? row[0] & ((1u << sh) - 1) : 0u;
+    npend = rem;
+    nbytes += (uint64_t)(4 * top + kb);
+    wpos += nfull;
+  }
+
+  __device__ __forceinline__ void pad() {
+    const uint64_t bits = nbytes * 8;
+    wave_lds_fence();
+    int p = wpos;
+    if (lane == 0) chunk[hw_pidx(p)] = ((pend << 8) | 0x80u) << (8 * (3 - npend));
+    p++;
+    while ((p & 15) != 14) { if (lane == 0) chunk[hw_pidx(p)] = 0; p++; }
+    if (lane == 0) { chunk[hw_pidx(p)] = (uint32_t)(bits >> 32); chunk[hw_pidx(p + 1)] = (uint32_t)bits; }
+    wpos = p + 2;
+  }
+};
+
+__global__ void __launch_bounds__(64) k_range_hash_wave(RangeHashArgs a) {
+  extern __shared__ __align__(16) uint32_t hash_lds[];
+  const int lane = threadIdx.x;
+  const uint64_t b = blockIdx.x;
+  const int kw = (int)a.kw;
+  WaveSha s;
+  s.init(hash_lds, kw, lane);
+  const int nvalues = 1 + 2 * (int)a.ef;                      // n, c1[0..ef), c2[0..ef)
+  const uint64_t pstride = (uint64_t)a.ef * 2 * kw;
+  bool padded = false;
+#pragma unroll 1
+  for (int v = 0;; v++) {                                     // ONE call site of put_bigint / flush for the whole stream
+    if (v < nvalues) {
+      const int idx = v - 1, half = idx >= (int)a.ef;
+      const uint32_t* src = v == 0 ? a.n + b * a.n_stride : (half ? a.c2 : a.c1) + b * pstride + (uint64_t)(idx - half * (int)a.ef) * 2 * kw;
+      s.put_bigint(src, v == 0 ? kw : 2 * kw);
+      if (s.wpos < HW_WORDS) continue;
+    } else if (!padded) {
+      s.pad();
+      padded = true;
+    }
+    if (s.wpos == 0) break;
+    s.flush(s.wpos / 16 < HW_BLOCKS ? s.wpos / 16 : HW_BLOCKS);
+  }
+  if (lane != 0) return;
+  // the digest as bytes in LDS (byte j at byte address j): the dynamic byte indexing below stays out of the register file
+  wave_lds_fence();
+#pragma unroll
+  for (int i = 0; i < 8; i++) s.row[i] = __builtin_bswap32(s.st.h[i]);
+  wave_lds_fence();
+  const uint8_t* db = reinterpret_cast<const uint8_t*>(s.row);
+  int lead = 0;
+  while (lead < 31 && db[lead] == 0) lead++;      // BigInt round trip drops leading zero bytes; zero -> "00"
+  uint8_t* e = a.e + b * 32;
+  for (int i = 0; i < 32; i++) e[i] = (i + lead < 32) ? db[i + lead] : 0;
+  const int elen = 32 - lead;
+  a.e_len[b] = (uint8_t)elen;
+  a.verdict[b] = ((uint32_t)elen * 8 >= a.ef) ? a.ok_value : (uint8_t)ZKP_VERDICT_MALFORMED;
+  const uint32_t* rg = a.range + b * a.kw;
+  uint32_t* t1 = a.third + b * a.kw;
+  uint32_t* t2 = a.two_thirds + b * a.kw;
+  uint64_t rem = 0;
+  for (int w = (int)a.kw - 1; w >= 0; w--) {
+    const uint64_t cur = (rem << 32) | rg[w];
+    t1[w] = (uint32_t)(cur / 3);
+    rem = cur % 3;
+  }
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < a.kw; w++) { const uint32_t v = t1[w]; t2[w] = (v << 1) | carry; carry = v >> 31; }
+}
+
+// ------------------------------------------------------------------------------------------
 // Verify planning: one thread per (proof, row).  Applies the kind/bit match and the range
 // predicates of verifier_output (range_proof.rs:270-348) and appends the Enc checks the row
 // needs to the work list: Open -> (w1,r1)->c1[i] and (w2,r2)->c2[i]; Mask -> (masked_x,masked_r).

@@ -29,6 +29,8 @@ struct Sha256 {
   uint64_t nbytes;
 
   __device__ __forceinline__ static uint32_t ror(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+  // a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96); the compiler alone emits two v_xor_b32
+  __device__ __forceinline__ static uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
   __device__ __forceinline__ void init(uint32_t* lds_buf, int lds_stride) {
     h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
@@ -53,15 +55,15 @@ struct Sha256 {
         wi = w[i];
       } else {
         const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-        const uint32_t s0 = ror(w15, 7) ^ ror(w15, 18) ^ (w15 >> 3);
-        const uint32_t s1 = ror(w2, 17) ^ ror(w2, 19) ^ (w2 >> 10);
+        const uint32_t s0 = xor3(ror(w15, 7), ror(w15, 18), w15 >> 3);
+        const uint32_t s1 = xor3(ror(w2, 17), ror(w2, 19), w2 >> 10);
         wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
         w[i & 15] = wi;
       }
-      const uint32_t S1 = ror(e, 6) ^ ror(e, 11) ^ ror(e, 25);
+      const uint32_t S1 = xor3(ror(e, 6), ror(e, 11), ror(e, 25));
       const uint32_t ch = (e & f) ^ (~e & g);
       const uint32_t t1 = hh + S1 + ch + SHA_K[i] + wi;
-      const uint32_t S0 = ror(a, 2) ^ ror(a, 13) ^ ror(a, 22);
+      const uint32_t S0 = xor3(ror(a, 2), ror(a, 13), ror(a, 22));
       const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
       const uint32_t t2 = S0 + mj;
       hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
