@@ -559,6 +559,66 @@ __global__ void __launch_bounds__(256) k_ck_hash(CkHashArgs a) {
   a.verdict[b] = coprime ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
 }
 
+// The same per key on ONE WAVEFRONT, for calls of a few keys (one thread per key spends ~12 ms, mostly in the 830 trial
+// divisions): lane i < 11 derives rho_i (its seed hash and mask blocks), and all 64 lanes share the primes.
+__global__ void __launch_bounds__(64) k_ck_hash_wave(CkHashArgs a) {
+  __shared__ uint32_t shabuf[16 * 64];
+  const uint64_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t* n = a.n + b * a.kw;
+  const int kw = (int)a.kw;
+  if (lane < ZKP_CORRECT_KEY_M2) {
+    const uint32_t i = (uint32_t)lane;
+    Sha256 s;
+    uint32_t salt_d[8];
+    {
+      s.init(shabuf + lane, 64);
+      uint32_t lead = 0;
+      while (lead < a.salt_len && a.salt[lead] == 0) lead++;
+      if (lead == a.salt_len) s.put_bytes(0, 1);
+      for (uint32_t k = lead; k < a.salt_len; k++) s.put_bytes(a.salt[k], 1);
+      s.finish(salt_d);
+    }
+    int top = kw - 1;
+    while (top > 0 && n[top] == 0) top--;
+    const int key_length = n[top] ? top * 32 + 32 - __clz(n[top]) : 0;
+    const int msklen = key_length / 256 + 1;
+    uint32_t le[8], seed_d[8];
+    s.init(shabuf + lane, 64);
+    s.put_bigint(n, kw);
+#pragma unroll
+    for (int k = 0; k < 8; k++) le[k] = salt_d[7 - k];
+    s.put_bigint(le, 8);
+    sha_put_u32_as_bigint(s, i);
+    s.finish(seed_d);
+    uint32_t seed_le[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) seed_le[k] = seed_d[7 - k];
+    uint32_t* out = a.mgf + (b * ZKP_CORRECT_KEY_M2 + i) * (uint64_t)(kw + 8);
+    for (int w = 0; w < kw + 8; w++) out[w] = 0;
+    for (int j = 0; j < msklen; j++) {
+      uint32_t hj[8];
+      s.init(shabuf + lane, 64);
+      s.put_bigint(seed_le, 8);
+      sha_put_u32_as_bigint(s, (uint32_t)j);
+      s.finish(hj);
+      if (8 * j + 8 <= kw + 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) out[8 * j + k] = hj[7 - k];
+      }
+    }
+  }
+  bool coprime = true;
+  for (uint32_t pi = (uint32_t)lane; pi < a.nprimes; pi += 64) {
+    const uint32_t p = a.primes[pi];
+    uint64_t rem = 0;
+    for (int w = kw - 1; w >= 0; w--) rem = ((rem << 32) | n[w]) % p;
+    if (rem == 0) coprime = false;
+  }
+  const bool all = __all(coprime);
+  if (lane == 0) a.verdict[b] = all ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
+}
+
 // (2) one group (n context) per (proof, i): sigma_i^n mod n  ==  mask_generation(..) mod n  (:84,:92,:95)
 struct CkCheckArgs {
   const uint32_t* n; const uint32_t* sigma; const uint32_t* mgf; const uint32_t* consts;

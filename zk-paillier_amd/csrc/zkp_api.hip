@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <new>
 #include <cstring>
 #include <mutex>
@@ -106,19 +107,30 @@ static int32_t lat_forward_plain(zkp_ctx* c, int32_t st) {
 }
 
 #ifndef ZKP_SECONDARY_ENGINE
+// directory of this shared library, resolved when it is loaded (a relative load path stops meaning anything once the process
+// changes its working directory)
+static const std::string& own_directory() {
+  static const std::string dir = [] {
+    Dl_info info;
+    if (!dladdr((const void*)&zkp_backend_name, &info) || !info.dli_fname) return std::string();
+    char* real = realpath(info.dli_fname, nullptr);
+    std::string path = real ? real : info.dli_fname;
+    std::free(real);
+    const size_t slash = path.rfind('/');
+    return slash == std::string::npos ? std::string(".") : path.substr(0, slash);
+  }();
+  return dir;
+}
+__attribute__((constructor)) static void resolve_own_directory() { try { (void)own_directory(); } catch (...) {} }
+
 static const LatEngine* lat_engine() {
   static LatEngine eng;
   static std::once_flag once;
   std::call_once(once, [] {
     std::string path;
     if (const char* e = std::getenv("ZKP_HIP_LAT_LIB")) path = e;
-    else {
-      Dl_info info;
-      if (!dladdr((const void*)&zkp_backend_name, &info) || !info.dli_fname) return;
-      path = info.dli_fname;
-      const size_t slash = path.rfind('/');
-      path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libzkp_hip_lat.so";
-    }
+    else if (!own_directory().empty()) path = own_directory() + "/libzkp_hip_lat.so";
+    else return;
     void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) return;
     bool all = true;
