@@ -74,7 +74,7 @@ int32_t zkp_build_limbs_per_lane(void);           /* compile-time W of the throu
  * 4096-bit integer) is the one the batch metric is quoted on.  A modular exponentiation is a chain of ~2400 dependent
  * products, so ONE proof (the reference's own bench, benches/all.rs:55-71) takes as long as ~30 of them there; the latency
  * engine (libzkp_hip_lat.so next to this library, the same sources built with W = 9: 16 lanes per integer) halves that time
- * and is chosen automatically while a call's work fits ~2 wavefronts per SIMD of it.  Results are bit-identical.
+ * and is chosen automatically while a call's work fits 3-5 wavefronts per SIMD of it.  Results are bit-identical.
  * zkp_ctx_set_geometry: limbs_per_lane 0 = automatic (default), 36 / 9 = always that engine (ZKP_EINVAL when it is not
  * loaded).  zkp_ctx_last_geometry: limbs per lane of the engine the most recent batch call ran on.
  * zkp_ctx_latency_limbs_per_lane: W of the loaded latency engine, 0 when there is none (small calls then run on the

@@ -150,12 +150,14 @@ static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits) {
   if (!c->lat_ctx || c->geometry == W || items == 0) return false;
   bool take = c->geometry == c->lat->limbs_per_lane;
   if (!take) {
-    // automatic: the latency engine wins while its launch stays within ~2 wavefronts per SIMD (measured on MI355X,
-    // tests/perf_gpu_latency.py: RangeProofNi n = 2048, 32 proofs = 2048 wavefronts: 46 ms against 68 ms; at twice that the
-    // throughput engine is ahead)
+    // automatic: the latency engine wins while its launch stays within a few wavefronts per SIMD — measured on MI355X
+    // (tools/dev/sweep.py, both engines pinned): RangeProofNi n = 2048 (16 lanes per integer) 48 proofs = 3 waves per SIMD:
+    // 56 ms against 62 ms, 64 proofs: 70 against 63; NiCorrectKeyProof (2048-bit moduli, 8 lanes) 4096 keys = 5.5 per SIMD:
+    // 62 against 70 ms, 8192 keys: 101 against 96; CompositeDLogProof 16384 proofs = 4 per SIMD: 11 against 18 ms
     const uint64_t limbs = mod_bits <= 2048 ? 72 : mod_bits <= 4096 ? 144 : 288;
     const uint64_t lanes = limbs / (uint64_t)c->lat->limbs_per_lane;
-    take = items <= (2ull * 4 * (uint64_t)c->cus * 64) / lanes;
+    const uint64_t waves_per_simd = mod_bits <= 2048 ? 6 : 3;
+    take = items <= (waves_per_simd * 4 * (uint64_t)c->cus * 64) / lanes;
   }
   if (take) c->last_geometry = c->lat->limbs_per_lane;
   return take;
