@@ -83,7 +83,8 @@ int32_t zkp_ctx_set_geometry(zkp_ctx* ctx, int32_t limbs_per_lane);
 int32_t zkp_ctx_last_geometry(zkp_ctx* ctx);
 int32_t zkp_ctx_latency_limbs_per_lane(zkp_ctx* ctx);
 const char* zkp_last_error_string(zkp_ctx* ctx);  /* valid until the next call on ctx */
-void* zkp_ctx_stream(zkp_ctx* ctx);               /* the hipStream_t every launch uses */
+void* zkp_ctx_stream(zkp_ctx* ctx);               /* the hipStream_t every call is ordered on (a small verify call forks part of
+                                                     its work to an internal second stream and joins it back before it returns) */
 int32_t zkp_ctx_synchronize(zkp_ctx* ctx);
 /* Host-pointer calls stage their buffers through device blocks the ctx keeps between calls (no hipMalloc / hipFree per
  * call once warm).  This frees the cached blocks (zkp_ctx_destroy does so too). */
