@@ -191,6 +191,11 @@ int32_t zkp_range_ni_verify_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p,
  *   verifier_output          (range_proof.rs:254-355): verdicts from (c1, c2, resp_*, e) */
 int32_t zkp_range_generate_encrypted_pairs_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w,
                                                  uint32_t flags);
+/* The Fiat-Shamir challenge alone (utils::compute_digest, src/zkproofs/utils.rs:9-22, with the glue of
+ * range_proof_ni.rs:58-61 / 89-92 / 110-113): out_e[b] = to_bytes(from_bytes(SHA256(to_bytes(n) || to_bytes(c1[0..EF)) ||
+ * to_bytes(c2[0..EF))))), left aligned in 32 bytes, out_e_len[b] its length (leading zero bytes of the digest are dropped, a
+ * zero digest is the one byte 00).  Reads p->n, p->c1, p->c2 only. */
+int32_t zkp_range_challenge_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p, uint8_t* out_e, uint8_t* out_e_len, uint32_t flags);
 int32_t zkp_range_generate_proof_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w,
                                        const uint8_t* e, const uint8_t* e_len, uint8_t* out_status, uint32_t flags);
 int32_t zkp_range_verifier_output_batch(zkp_ctx* ctx, const zkp_range_ni_proofs* p, const uint8_t* e, const uint8_t* e_len,

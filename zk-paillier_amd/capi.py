@@ -63,6 +63,7 @@ EXPORTS = {
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_range_ni_verify_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_uint32]),
     "zkp_range_generate_encrypted_pairs_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness), C.c_uint32]),
+    "zkp_range_challenge_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_range_generate_proof_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness), C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_uint32]),
     "zkp_range_verifier_output_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
@@ -325,6 +326,10 @@ class Context:
     def verlin_proof_verify(self, n_bits, batch, n, n_stride, c, c_prime, phi_x, phi_a, z, zp, zpp, r_z, out_verdict):
         arrs = [c, c_prime, phi_x, phi_a, z, zp, zpp, r_z, out_verdict]
         self.check(self.lib.zkp_verlin_proof_verify_batch(self.h, n_bits, batch, ptr(n), n_stride, *[ptr(a) for a in arrs], self._flags(n, *arrs)))
+
+    def range_challenge(self, proofs, out_e, out_e_len, device: bool):
+        """the Fiat-Shamir challenge of (n, c1, c2) alone: out_e [B][32] left aligned, out_e_len [B]"""
+        self.check(self.lib.zkp_range_challenge_batch(self.h, C.byref(proofs), ptr(out_e), ptr(out_e_len), ZKP_F_DEVICE_PTRS if device else 0))
 
     # ---- interactive RangeProof building blocks (challenge supplied by the caller)
     def range_generate_encrypted_pairs(self, proofs, wit, device: bool):

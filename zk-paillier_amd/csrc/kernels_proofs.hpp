@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(HASH_PROOFS) k_range_hash(RangeHashArgs a) {
   a.e_len[b] = (uint8_t)elen;
   // bits_of_e[i] for i < EF must exist, otherwise the reference panics (index out of bounds)
   a.verdict[b] = ((uint32_t)elen * 8 >= a.ef) ? a.ok_value : (uint8_t)ZKP_VERDICT_MALFORMED;
+  if (!a.range) return;                            // challenge only (zkp_range_challenge_batch)
   // T = range div_floor 3, 2T
   const uint32_t* rg = a.range + b * a.kw;
   uint32_t* t1 = a.third + b * a.kw;
@@ -302,6 +303,7 @@ __global__ void __launch_bounds__(64) k_range_hash_wave(RangeHashArgs a) {
   const int elen = 32 - lead;
   a.e_len[b] = (uint8_t)elen;
   a.verdict[b] = ((uint32_t)elen * 8 >= a.ef) ? a.ok_value : (uint8_t)ZKP_VERDICT_MALFORMED;
+  if (!a.range) return;                            // challenge only (zkp_range_challenge_batch)
   const uint32_t* rg = a.range + b * a.kw;
   uint32_t* t1 = a.third + b * a.kw;
   uint32_t* t2 = a.two_thirds + b * a.kw;

@@ -86,7 +86,7 @@ static int32_t zkp_caught(zkp_ctx* c, int32_t st, const char* what) noexcept {
 #define ZKP_LAT_FUNCS(X)                                                                                                        \
   X(zkp_ctx_create_on_stream) X(zkp_ctx_destroy) X(zkp_last_error_string) X(zkp_build_limbs_per_lane) X(zkp_ctx_release_staging) \
   X(zkp_timing_reset) X(zkp_timing_get) X(zkp_modexp_batch) X(zkp_paillier_enc_batch) X(zkp_paillier_enc_check_batch)            \
-  X(zkp_range_ni_prove_batch) X(zkp_range_ni_verify_batch) X(zkp_range_generate_encrypted_pairs_batch)                           \
+  X(zkp_range_ni_prove_batch) X(zkp_range_ni_verify_batch) X(zkp_range_generate_encrypted_pairs_batch) X(zkp_range_challenge_batch)                           \
   X(zkp_range_verifier_output_batch) X(zkp_correct_key_ni_verify_batch) X(zkp_dlog_prove_batch) X(zkp_dlog_verify_batch)         \
   X(zkp_zero_proof_prove_batch) X(zkp_zero_proof_verify_batch) X(zkp_ciphertext_proof_prove_batch)                               \
   X(zkp_ciphertext_proof_verify_batch) X(zkp_verlin_proof_prove_batch) X(zkp_verlin_proof_verify_batch)                          \
