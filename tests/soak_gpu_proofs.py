@@ -26,7 +26,8 @@ def main():
     total = 0
     for rd in range(rounds):
         rng = np.random.default_rng(1000 + rd)
-        n_bits, B = 1024, 48
+        n_bits, B = 1024, (48, 1, 5, 300)[rd % 4]          # one proof ... a batch that takes the one-stream verify sequence
+        ctx.set_geometry((0, 36, 9)[rd % 3])               # automatic choice / pinned to either engine
         shared = bool(rd % 2)
         klist = [keys[rd % 6]] if shared else [keys[(rd + b) % 6] for b in range(B)]
         cases = H.build_range_case(b"soakp-%d" % rd, klist, n_bits, B, shared=shared)
@@ -57,7 +58,7 @@ def main():
         ctx.range_ni_verify(pb_g.struct(), vg, device=False)
         assert np.array_equal(vo, vg), (rd, list(vo), list(vg))
         total += B
-        print("round", rd, "ok: accepted", int((vo == 1).sum()), "rejected", int((vo == 0).sum()), "of", B, flush=True)
+        print("round", rd, "B", B, "ran on", ctx.last_geometry(), "limbs per lane, ok: accepted", int((vo == 1).sum()), "rejected", int((vo == 0).sum()), "of", B, flush=True)
     print("PROOF SOAK OK", total)
 
 
