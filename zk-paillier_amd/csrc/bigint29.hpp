@@ -50,11 +50,20 @@ template <int G> struct Geo {
 };
 
 // ---------------------------------------------------------------- cross-lane primitives
-// value held by lane 0 of the group -> every lane of the group (ds_swizzle, bit-mask mode:
-// lane' = lane & and_mask inside each 32-lane half)
+// value held by lane 0 of the group -> every lane of the group (the quotient digit, once per sub-step).  Groups that fit a
+// quad take ONE DPP move (quad_perm): against the LDS-crossbar ds_swizzle (8.4 issue cycles and a trip through the LDS queue)
+// that is +1.2 % verifies/s on the throughput engine, whose Paillier kernels are G = 4 (A/B on one box).  Wider
+// groups keep ds_swizzle: a 16-lane broadcast needs three dependent DPP moves (quad_perm, row_shr:4 and row_shr:8 under bank
+// masks), and on the latency engine, where one wavefront per SIMD waits out every dependent instruction, that chain doubled
+// the time of a sub-step (one proof 27 -> 48 ms) — measured, not adopted.
+#ifndef ZKP_BCAST_DPP
+#define ZKP_BCAST_DPP 1
+#endif
 template <int G> __device__ __forceinline__ uint32_t bcast0(uint32_t v) {
   static_assert(G == 2 || G == 4 || G == 8 || G == 16 || G == 32, "group size");
-  if constexpr (G == 2) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x001E);
+  if constexpr (ZKP_BCAST_DPP && G == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xA0 /*quad_perm:[0,0,2,2]*/, 0xf, 0xf, true);
+  else if constexpr (ZKP_BCAST_DPP && G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
+  else if constexpr (G == 2) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x001E);
   else if constexpr (G == 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0000);
   else if constexpr (G == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0010);
   else if constexpr (G == 8) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0018);
