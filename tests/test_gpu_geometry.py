@@ -126,3 +126,29 @@ def test_ctx_on_a_caller_owned_stream():
                 assert H.L.limbs_to_int(head[i].cpu().numpy().view(np.uint32)) == (1 + mi * n) * pow(ri, n, n * n) % (n * n)
     finally:
         c.close()
+
+
+def test_ctx_lifecycle_with_both_engines_and_the_second_stream(oracle):
+    """contexts come and go (each owns a twin ctx of the latency engine, lazily a second stream and its events): every one of
+    them must give the same verdicts, and tearing them down must not disturb the ones still alive"""
+    n_bits = 1024
+    n = H.test_key(1024)[2]
+    cases = H.build_range_case(b"lifecycle", [n], n_bits, 2)
+    cases[1] = H.build_range_case(b"lifecycle-bad", [n], n_bits, 1, honest=False)[0]
+    pb, wt = H.fill_batch(cases, n_bits, True, oracle)
+    oracle.range_ni_prove(pb.struct(), wt.struct(), None, None, None)
+    alive = []
+    for round_ in range(12):
+        c = zkp.Context(0)
+        c.set_geometry((0, 36, 9)[round_ % 3])
+        v = np.full(2, 9, np.uint8)
+        c.range_ni_verify(pb.struct(), v, device=False)            # two-stream sequence on whichever engine serves it
+        assert list(v) == [1, 0], (round_, list(v))
+        alive.append(c)
+        if round_ % 2:
+            alive.pop(0).close()                                   # destroy an older ctx while newer ones are in use
+    for c in alive:
+        v = np.full(2, 9, np.uint8)
+        c.range_ni_verify(pb.struct(), v, device=False)
+        assert list(v) == [1, 0]
+        c.close()
