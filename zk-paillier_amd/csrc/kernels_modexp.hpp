@@ -462,9 +462,19 @@ struct ModexpArgs {
   int out_words;            // words per out element
   const uint8_t* sched;     // sliding-window schedule of the launch-uniform exponent (k_sliding_schedule), or null
   unsigned long long* work_counter;   // zeroed per launch: wavefronts claim 64/G items at a time
+  // Further segments of the SAME launch (per-item exponents only): independent exponentiations under the same per-item moduli
+  // that a proof needs side by side (ni^e and g^y of CompositeDLogProof::verify, the three powers of MulProof, ...).  One launch
+  // runs their chains next to each other instead of one after the other — in a call that does not fill the GPU the time is the
+  // longest chain, not the sum.  Segment k covers the claims after those of segment k-1 (each rounded up to whole claims, so a
+  // wavefront never mixes exponent lengths).
+  struct Seg { const uint32_t* base; const uint32_t* exp; uint64_t exp_stride; uint32_t* out; uint64_t count; int exp_bits, io_words, out_words; };
+  Seg more[2];
+  int nmore;
 };
 
-template <int G, bool SHARED_EXP>
+// MULTI: the launch has further segments (ModexpArgs::more).  A variant of its own: the segment bookkeeping costs registers
+// that the single-segment kernels, which carry the throughput-bound launches, need inside their product loops.
+template <int G, bool SHARED_EXP, bool MULTI = false>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
@@ -480,25 +490,45 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / G));
     base = __shfl(base, 0);
-    if (base >= a.count) break;
-    const uint64_t idx = base + (uint64_t)(lane / G);
-    const bool live = idx < a.count;
-    const uint64_t item = live ? idx : a.count - 1;
+    // the segment this claim belongs to (wave-uniform)
+    constexpr uint64_t IPW = 64 / G;
+    ModexpArgs::Seg sg{a.base, a.exp, a.exp_stride, a.out, a.count, a.exp_bits, a.io_words, a.out_words};
+    uint64_t rel = base;
+    bool found = MULTI ? rel < (sg.count + IPW - 1) / IPW * IPW : rel < sg.count;
+    int segment = 0;
+    if constexpr (MULTI) {
+      for (int k = 0; !found && k < a.nmore; k++) {
+        rel -= (sg.count + IPW - 1) / IPW * IPW;
+        sg = a.more[k];
+        segment = k + 1;
+        found = rel < (sg.count + IPW - 1) / IPW * IPW;
+      }
+    }
+    if (!found) break;
+    // (single-segment kernels read the launch arguments where they are used, as before: nothing of the segment stays live)
+#define ZKP_SEG(f) (MULTI ? sg.f : a.f)
+    const uint64_t idx = rel + (uint64_t)(lane / G);
+    const bool live = idx < ZKP_SEG(count);
+    const uint64_t item = live ? idx : ZKP_SEG(count) - 1;
     const uint32_t* cst = a.consts + item * a.const_stride;
     load_modulus_consts<G>(g, cst);
     uint32_t X[W], R[W], T[W];
     // base -> Montgomery form: X = base * R2 / R
-    load_value<G>(g, T, a.base + item * a.io_words, a.io_words);
+    load_value<G>(g, T, ZKP_SEG(base) + item * ZKP_SEG(io_words), ZKP_SEG(io_words));
     load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
     stageB<G>(g, X);
     mm<G>(g, X, T);
-    powm<G, SHARED_EXP>(g, X, a.exp_bits, tab, cst, a.sched, a.exp + item * a.exp_stride);
+    powm<G, SHARED_EXP>(g, X, ZKP_SEG(exp_bits), tab, cst, a.sched, ZKP_SEG(exp) + item * ZKP_SEG(exp_stride));
+#undef ZKP_SEG
     // leave the Montgomery domain: montmul(X, 1) <= M
     stage_one<G>(g);
     mm<G>(g, R, X);
     canonical_words<G>(g, R, cst + CL::OFF_N);
+    // (the output side of the segment is read again here rather than kept in registers across the exponentiation)
+    uint32_t* out = a.out; int out_words = a.out_words;
+    if constexpr (MULTI) { if (segment) { out = a.more[segment - 1].out; out_words = a.more[segment - 1].out_words; } }
     if (live && cst[CL::OFF_ST] == 0) {
-      for (int w = g.gl; w < a.out_words; w += G) a.out[item * a.out_words + w] = g.words()[w];
+      for (int w = g.gl; w < out_words; w += G) out[item * out_words + w] = g.words()[w];
     }
   }
 }

@@ -483,11 +483,51 @@ static int32_t modexp_core(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const 
   if (exp_stride == 0 && (st = build_schedule(c, exp, exp_bits, &sched))) return st;
   unsigned long long* wc = nullptr;
   if ((st = fresh_work_counter(c, &wc))) return st;
-  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words, out_words ? out_words : io_words, sched, wc};
+  ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words, out_words ? out_words : io_words, sched, wc, {}, 0};
   {
     TimedRegion tr(c, count);
     if (a.sched) hipLaunchKernelGGL((k_modexp<G, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
     else hipLaunchKernelGGL((k_modexp<G, false>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+  }
+  HIPCHK(c, hipGetLastError());
+  return ZKP_OK;
+}
+
+// Up to three exponentiations per item (per-item exponents, the same per-item moduli already set up in c->consts) in ONE
+// launch: ModexpArgs::more.  Longest exponent first, so that the long chains start first.
+struct ModexpCall { uint32_t exp_bits; const uint32_t* base; const uint32_t* exp; uint64_t exp_stride; uint32_t* out; int io_words; int out_words; };
+template <int G>
+static int32_t modexp_multi(zkp_ctx* c, uint64_t count, bool per_item_mod, std::initializer_list<ModexpCall> calls_in) {
+  using CL = ConstLayout<G>;
+  using LL = LdsLayout<G>;
+  std::vector<ModexpCall> calls(calls_in);
+  std::stable_sort(calls.begin(), calls.end(), [](const ModexpCall& x, const ModexpCall& y) { return x.exp_bits > y.exp_bits; });
+  if (calls.empty() || calls.size() > 3) { c->err = "modexp_multi: 1..3 segments"; return ZKP_EINVAL; }
+  for (const ModexpCall& k : calls) if (k.exp_stride == 0) { c->err = "modexp_multi: per-item exponents only"; return ZKP_EINVAL; }
+  constexpr uint64_t IPW = 64 / G;
+  const uint64_t claims = (count + IPW - 1) / IPW * IPW * calls.size();
+  int32_t st;
+  if (calls.size() == 1 || claims > (uint64_t)resident_blocks<G>(c, k_modexp<G, false, true>) * LL::GROUPS_PER_BLOCK) {
+    // the launch fills the GPU anyway: one launch per exponentiation on the single-segment kernel (no segment bookkeeping in
+    // its product loops)
+    for (const ModexpCall& k : calls)
+      if ((st = modexp_core<G>(c, k.exp_bits, count, k.base, k.exp, k.exp_stride, per_item_mod, k.out, k.io_words, k.out_words))) return st;
+    return ZKP_OK;
+  }
+  unsigned blocks = 0;
+  if ((st = table_for<G>(c, k_modexp<G, false, true>, claims, &blocks))) return st;
+  unsigned long long* wc = nullptr;
+  if ((st = fresh_work_counter(c, &wc))) return st;
+  const ModexpCall& f = calls[0];
+  ModexpArgs a{f.base, f.exp, f.exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, f.out, (uint32_t*)c->table.p, count,
+               (int)f.exp_bits, f.io_words, f.out_words ? f.out_words : f.io_words, nullptr, wc, {}, (int)calls.size() - 1};
+  for (size_t k = 1; k < calls.size(); k++) {
+    const ModexpCall& m = calls[k];
+    a.more[k - 1] = {m.base, m.exp, m.exp_stride, m.out, count, (int)m.exp_bits, m.io_words, m.out_words ? m.out_words : m.io_words};
+  }
+  {
+    TimedRegion tr(c, count * calls.size());
+    hipLaunchKernelGGL((k_modexp<G, false, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
   }
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
