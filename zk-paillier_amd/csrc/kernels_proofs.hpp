@@ -720,6 +720,8 @@ struct DlogHashArgs {
   uint8_t* verdict;       // ACCEPT / MALFORMED to start with (nullable in prove)
   // prove only: y = r + e * secret  (wi_dlog_proof.rs:62)
   const uint32_t* secret; const uint32_t* r; uint32_t* y; uint32_t yw;
+  uint32_t parts;         // 1 = the challenge (and the prover's y), 2 = the verifier's pre-checks, 3 = both.  A small verify call
+                          // runs the pre-checks (two GCDs, ~1 ms on one lane) on the second stream next to the exponentiations
 };
 
 constexpr int DLOG_THREADS = 64;
@@ -730,14 +732,17 @@ __global__ void __launch_bounds__(DLOG_THREADS) k_dlog_hash(DlogHashArgs a) {
   if (b >= a.batch) return;
   const int kw = (int)a.kw;
   const uint32_t *N = a.N + b * kw, *g = a.g + b * kw, *ni = a.ni + b * kw, *x = a.x + b * kw;
-  Sha256 s;
-  s.init(shabuf + threadIdx.x, DLOG_THREADS);
-  s.put_bigint(x, kw); s.put_bigint(g, kw); s.put_bigint(N, kw); s.put_bigint(ni, kw);   // :56-61 / :75-80
-  uint32_t d[8], e[8];
-  s.finish(d);
+  uint32_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (a.parts & 1) {
+    Sha256 s;
+    s.init(shabuf + threadIdx.x, DLOG_THREADS);
+    s.put_bigint(x, kw); s.put_bigint(g, kw); s.put_bigint(N, kw); s.put_bigint(ni, kw);   // :56-61 / :75-80
+    uint32_t d[8];
+    s.finish(d);
 #pragma unroll
-  for (int k = 0; k < 8; k++) { e[k] = d[7 - k]; a.e[b * 8 + k] = e[k]; }
-  if (a.verdict) {
+    for (int k = 0; k < 8; k++) { e[k] = d[7 - k]; a.e[b * 8 + k] = e[k]; }
+  }
+  if (a.verdict && (a.parts & 2)) {
     // assert!(N > 2^128) :69 ; gcd(g, N) == 1 :72 ; gcd(ni, N) == 1 :73  (panics in the reference)
     bool big = false;
     for (int w = 5; w < kw; w++) big = big || N[w] != 0;
@@ -750,7 +755,7 @@ __global__ void __launch_bounds__(DLOG_THREADS) k_dlog_hash(DlogHashArgs a) {
     }
     a.verdict[b] = ok ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_MALFORMED;
   }
-  if (a.y) {
+  if (a.y && (a.parts & 1)) {
     const uint32_t* sc = a.secret + b * 8;
     const uint32_t* r = a.r + b * 16;
     uint32_t* y = a.y + b * a.yw;
