@@ -62,3 +62,10 @@ def test_dlog_matches_oracle(ctx, oracle, n_bits):
     ctx.dlog_verify(n_bits, yb, B + 2, N2, g2, ni2, x2, y2, vg)
     assert np.array_equal(vo, vg), (list(vo), list(vg))
     assert vo[0] == zkp.VERDICT_ACCEPT and vo[1] == zkp.VERDICT_REJECT and vo[6] == zkp.VERDICT_MALFORMED and vo[8] == zkp.VERDICT_MALFORMED
+    # the same proofs tiled to a batch that fills the GPU: one launch per exponentiation, pre-checks on the one stream (the
+    # small call above took the merged launch with the pre-checks on the second stream, zkp_api_proofs.inc:dlog_verify_impl)
+    tiles = 3000
+    big = [np.tile(a, (tiles, 1)) for a in (N2, g2, ni2, x2, y2)]
+    vb = np.full((B + 2) * tiles, 9, np.uint8)
+    ctx.dlog_verify(n_bits, yb, (B + 2) * tiles, *big, vb)
+    assert np.array_equal(vb, np.tile(vo, tiles))
