@@ -288,6 +288,44 @@ __device__ __forceinline__ void powm(const Grp<G, LL>& g, uint32_t (&X)[W], int 
   }
 }
 
+// (c) the latency ladder: right-to-left binary exponentiation on a PAIR of neighbouring groups, for calls that leave most
+//     of the GPU idle anyway (latency engine, a few proofs).  A left-to-right window ladder is a chain of t squarings WITH its
+//     ~t/7 + 33 multiplications in line; here the even group of the pair only squares (s_j = x^(2^j), staged as its B operand
+//     before every product as always) while the odd group keeps the running product acc *= s_j for the set exponent bits in
+//     the same product slots — its B operand is the squarer's staged s_j, or its own staged Montgomery one when the bit is
+//     clear, a per-group pointer, so the instruction stream stays uniform.  The chain is t products instead of ~1.16 t + 33
+//     (2048 instead of 2383 for Enc at n = 2048) for twice the lanes.  No table, no schedule.
+//     In: X = base (Montgomery form) in BOTH groups; out: X = base^exp in both groups, staged in B().
+template <int G, class LL>
+__device__ __forceinline__ void powm_pair(const Grp<G, LL>& g, uint32_t (&X)[W], int exp_bits, const uint32_t* cst,
+                                          const uint32_t* __restrict__ ew, int role /* 0 = squarer, 1 = accumulator */) {
+  using CL = ConstLayout<G>;
+  uint32_t NT[W];
+  load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
+  uint32_t* partner = g.B() + (role ? -LL::WORDS : LL::WORDS);
+  const uint32_t* squarerB = role ? partner : g.B();
+  const uint32_t* accB = role ? g.B() : partner;
+  fetch_words<G>(g, g.words(), ew, exp_bits >> 5);
+  const uint32_t* lw = g.words();
+  if (role) load_limbs_global<G>(X, cst + CL::OFF_R1, g.gl);          // acc = 1
+  wave_lds_fence();
+  if (role) lds_store_block(g.B() + g.gl * BLK, X);                   // ... and its B operand stays 1 for the whole ladder
+#pragma unroll 1
+  for (int j = 0; j < exp_bits; j++) {
+    wave_lds_fence();
+    if (!role) lds_store_block(g.B() + g.gl * BLK, X);                // s_j
+    wave_lds_fence();
+    const bool bit = (lw[j >> 5] >> (j & 31)) & 1;
+    const uint32_t* b = (role && bit) ? squarerB : g.B();
+    montmul<G, true, COL_NEEDS_CARE>(X, X, b, NT, 1u, g.gl);          // squarer: s * s ; accumulator: acc * (s_j | 1)
+  }
+  wave_lds_fence();
+  if (role) lds_store_block(g.B() + g.gl * BLK, X);
+  wave_lds_fence();
+  lds_load_block(X, accB + g.gl * BLK);
+  stageB<G>(g, X);
+}
+
 // B() := the integer 1
 template <int G, class LL> __device__ __forceinline__ void stage_one(const Grp<G, LL>& g) {
   uint32_t one[W];
@@ -626,7 +664,9 @@ template <int G, class LL> __device__ __forceinline__ void stage_const(const Grp
 //   s4  Y  = Y * R2 / R ; s5  Y = Y * 1 / R  -> value <= M -> canonical words = c
 //   mode 1 only (expected ciphertext e = c_j[i], or c_j[i] * cipher_x mod n^2 on Mask rows, range_proof.rs:324-328):
 //   s6  Y  = e * R2 / R ; s7  Y = Y * (mask ? cipher_x : 1) / R ; s8  Y = Y * R2 / R ; s9  Y = Y * 1 / R -> canonical
-template <int G, bool SHARED_EXP>
+// PAIR: two neighbouring groups per work item and the right-to-left ladder powm_pair (both groups run the whole script on the
+// same item; the even one owns the outputs).
+template <int G, bool SHARED_EXP, bool PAIR = false>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
@@ -639,19 +679,21 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
   const int kw = a.n_bits / 32;
   const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
   const int lane = threadIdx.x & 63;
-  const unsigned long long gmask = ((1ull << G) - 1) << (lane & ~(G - 1));
+  const unsigned long long gmask = (G == 64 ? ~0ull : (1ull << G) - 1) << (lane & ~(G - 1));
   const int nsteps = a.mode == 0 ? 6 : 10;
+  constexpr int GP = PAIR ? 2 * G : G;                   // lanes per work item
+  const int role = PAIR ? (lane / G) & 1 : 0;
   // Work items are claimed per wavefront (64/G consecutive items at a time) from a device counter: the verify work
   // list has a data-dependent length, a static round-robin would leave most of the chip idle in its last round.
   // Every group of a wavefront runs the same number of iterations (surplus groups recompute the last item).
   for (;;) {
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / G));
+    if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / GP));
     base = __shfl(base, 0);
     if (base >= count) break;
-    const uint64_t idx = base + (uint64_t)(lane / G);
-    const bool live = idx < count;
-    const uint64_t item = live ? idx : count - 1;
+    const uint64_t idx = base + (uint64_t)(lane / GP);
+    const bool live = idx < count && role == 0;           // (the odd group of a pair computes along and stores nothing)
+    const uint64_t item = idx < count ? idx : count - 1;
     uint64_t key;
     const uint32_t *pm, *pr;
     const uint32_t* pexp = nullptr;       // expected ciphertext (mode 1)
@@ -699,7 +741,8 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
 #pragma unroll 1
     for (int s = 0; s < nsteps; s++) {
       if (s == 1) {
-        powm<G, SHARED_EXP>(g, X, a.n_bits, tab, cst, a.sched, pn);                 // exponent = n (read from global memory by the fixed-window ladder)
+        if constexpr (PAIR) powm_pair<G>(g, X, a.n_bits, cst, pn, role);
+        else powm<G, SHARED_EXP>(g, X, a.n_bits, tab, cst, a.sched, pn);             // exponent = n (read from global memory by the fixed-window ladder)
         continue;
       }
       // ---- operands

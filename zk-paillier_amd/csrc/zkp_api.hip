@@ -335,9 +335,22 @@ template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_
   return ensure(c, c->table, (size_t)blocks * LL::GROUPS_PER_BLOCK * TAB * Geo<G>::L * sizeof(uint32_t));
 }
 
-// k_enc is instantiated per ladder kind: one shared exponent n (sliding-window script) or one key per item (fixed windows)
+// k_enc is instantiated per ladder kind: one shared exponent n (sliding-window script) or one key per item (fixed windows).
+// The latency engine has a third: the right-to-left ladder on pairs of groups (kernels_modexp.hpp: powm_pair), taken while a
+// launch with twice the lanes per item still leaves every SIMD at most one wavefront — the call is then a single chain of
+// products per item, and that chain is 14 % shorter.
 template <int G> static void launch_k_enc(zkp_ctx* c, unsigned blocks, const EncArgs& a) {
   using LL = LdsLayout<G>;
+#if ZKP_W <= 9
+  const uint64_t items = a.count;                        // (an upper bound when the count is device resident: verify work list)
+  if constexpr (2 * G <= 64) {
+    if (items * 2 * G <= 4ull * (uint64_t)c->cus * 64) {
+      const unsigned pair_blocks = (unsigned)std::max<uint64_t>(1, (items + LL::GROUPS_PER_BLOCK / 2 - 1) / (LL::GROUPS_PER_BLOCK / 2));
+      hipLaunchKernelGGL((k_enc<G, false, true>), dim3(pair_blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+      return;
+    }
+  }
+#endif
   if (a.sched) hipLaunchKernelGGL((k_enc<G, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
   else hipLaunchKernelGGL((k_enc<G, false>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
 }
