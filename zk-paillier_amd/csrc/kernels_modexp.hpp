@@ -512,7 +512,8 @@ struct ModexpArgs {
 
 // MULTI: the launch has further segments (ModexpArgs::more).  A variant of its own: the segment bookkeeping costs registers
 // that the single-segment kernels, which carry the throughput-bound launches, need inside their product loops.
-template <int G, bool SHARED_EXP, bool MULTI = false>
+// PAIR: two neighbouring groups per item and the right-to-left ladder powm_pair (latency engine, calls of a few items).
+template <int G, bool SHARED_EXP, bool MULTI = false, bool PAIR = false>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
@@ -526,10 +527,12 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
   const int lane = threadIdx.x & 63;
   for (;;) {
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / G));
+    constexpr int GP = PAIR ? 2 * G : G;
+    const int role = PAIR ? (lane / G) & 1 : 0;
+    if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / GP));
     base = __shfl(base, 0);
     // the segment this claim belongs to (wave-uniform)
-    constexpr uint64_t IPW = 64 / G;
+    constexpr uint64_t IPW = 64 / GP;
     ModexpArgs::Seg sg{a.base, a.exp, a.exp_stride, a.out, a.count, a.exp_bits, a.io_words, a.out_words};
     uint64_t rel = base;
     bool found = MULTI ? rel < (sg.count + IPW - 1) / IPW * IPW : rel < sg.count;
@@ -545,9 +548,9 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
     if (!found) break;
     // (single-segment kernels read the launch arguments where they are used, as before: nothing of the segment stays live)
 #define ZKP_SEG(f) (MULTI ? sg.f : a.f)
-    const uint64_t idx = rel + (uint64_t)(lane / G);
-    const bool live = idx < ZKP_SEG(count);
-    const uint64_t item = live ? idx : ZKP_SEG(count) - 1;
+    const uint64_t idx = rel + (uint64_t)(lane / GP);
+    const bool live = idx < ZKP_SEG(count) && role == 0;
+    const uint64_t item = idx < ZKP_SEG(count) ? idx : ZKP_SEG(count) - 1;
     const uint32_t* cst = a.consts + item * a.const_stride;
     load_modulus_consts<G>(g, cst);
     uint32_t X[W], R[W], T[W];
@@ -556,7 +559,8 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
     load_limbs_global<G>(X, cst + CL::OFF_R2, g.gl);
     stageB<G>(g, X);
     mm<G>(g, X, T);
-    powm<G, SHARED_EXP>(g, X, ZKP_SEG(exp_bits), tab, cst, a.sched, ZKP_SEG(exp) + item * ZKP_SEG(exp_stride));
+    if constexpr (PAIR) powm_pair<G>(g, X, ZKP_SEG(exp_bits), cst, ZKP_SEG(exp) + item * ZKP_SEG(exp_stride), role);
+    else powm<G, SHARED_EXP>(g, X, ZKP_SEG(exp_bits), tab, cst, a.sched, ZKP_SEG(exp) + item * ZKP_SEG(exp_stride));
 #undef ZKP_SEG
     // leave the Montgomery domain: montmul(X, 1) <= M
     stage_one<G>(g);

@@ -628,7 +628,8 @@ struct CkCheckArgs {
   unsigned long long* work_counter;
 };
 
-template <int G>
+// PAIR: two neighbouring groups per item and the right-to-left ladder (kernels_modexp.hpp: powm_pair; latency engine, a few keys)
+template <int G, bool PAIR = false>
 __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
   using CL = ConstLayout<G>;
   using LL = LdsLayout<G>;
@@ -642,12 +643,14 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
   const int lane0 = threadIdx.x & 63;
   for (;;) {
     unsigned long long base = 0;
-    if (lane0 == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / G));
+    constexpr int GP = PAIR ? 2 * G : G;
+    const int role = PAIR ? (lane0 / G) & 1 : 0;
+    if (lane0 == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / GP));
     base = __shfl(base, 0);
     if (base >= a.count) break;
-    const uint64_t idx = base + (uint64_t)(lane0 / G);
-    const bool live = idx < a.count;
-    const uint64_t item = live ? idx : a.count - 1;
+    const uint64_t idx = base + (uint64_t)(lane0 / GP);
+    const bool live = idx < a.count && role == 0;
+    const uint64_t item = idx < a.count ? idx : a.count - 1;
     const uint64_t b = item / ZKP_CORRECT_KEY_M2;
     const uint32_t* cst = a.consts + b * CL::WORDS;
     load_modulus_consts<G>(g, cst);
@@ -690,7 +693,8 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
     stageB<G>(g, T);
     load_value<G>(g, T, a.sigma + item * kw, kw);
     mm<G>(g, X, T);
-    powm<G, false>(g, X, a.n_bits, tab, cst, nullptr, a.n + b * kw);
+    if constexpr (PAIR) powm_pair<G>(g, X, a.n_bits, cst, a.n + b * kw, role);
+    else powm<G, false>(g, X, a.n_bits, tab, cst, nullptr, a.n + b * kw);
     stage_one<G>(g);
     mm<G>(g, R, X);
     normalize_exact<G>(R, g.gl);

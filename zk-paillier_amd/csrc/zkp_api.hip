@@ -335,22 +335,28 @@ template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_
   return ensure(c, c->table, (size_t)blocks * LL::GROUPS_PER_BLOCK * TAB * Geo<G>::L * sizeof(uint32_t));
 }
 
+// may `items` exponentiations take the pair ladder (two groups of G lanes each)?  Latency engine only, and only while the
+// launch with twice the lanes still leaves every SIMD at most one wavefront.
+constexpr bool PAIR_LADDER_BUILD = ZKP_W <= 9;            // the pair kernels are instantiated in the latency engine only
+template <int G> static bool pair_ladder(const zkp_ctx* c, uint64_t items) {
+  if constexpr (PAIR_LADDER_BUILD && 2 * G <= 64) return items * 2 * G <= 4ull * (uint64_t)c->cus * 64;
+  (void)c; (void)items;
+  return false;
+}
+
 // k_enc is instantiated per ladder kind: one shared exponent n (sliding-window script) or one key per item (fixed windows).
 // The latency engine has a third: the right-to-left ladder on pairs of groups (kernels_modexp.hpp: powm_pair), taken while a
 // launch with twice the lanes per item still leaves every SIMD at most one wavefront — the call is then a single chain of
 // products per item, and that chain is 14 % shorter.
 template <int G> static void launch_k_enc(zkp_ctx* c, unsigned blocks, const EncArgs& a) {
   using LL = LdsLayout<G>;
-#if ZKP_W <= 9
-  const uint64_t items = a.count;                        // (an upper bound when the count is device resident: verify work list)
-  if constexpr (2 * G <= 64) {
-    if (items * 2 * G <= 4ull * (uint64_t)c->cus * 64) {
-      const unsigned pair_blocks = (unsigned)std::max<uint64_t>(1, (items + LL::GROUPS_PER_BLOCK / 2 - 1) / (LL::GROUPS_PER_BLOCK / 2));
+  if constexpr (PAIR_LADDER_BUILD && 2 * G <= 64) {
+    if (pair_ladder<G>(c, a.count)) {                     // (a.count: an upper bound when the count is device resident, verify work list)
+      const unsigned pair_blocks = (unsigned)std::max<uint64_t>(1, (a.count + LL::GROUPS_PER_BLOCK / 2 - 1) / (LL::GROUPS_PER_BLOCK / 2));
       hipLaunchKernelGGL((k_enc<G, false, true>), dim3(pair_blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
       return;
     }
   }
-#endif
   if (a.sched) hipLaunchKernelGGL((k_enc<G, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
   else hipLaunchKernelGGL((k_enc<G, false>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
 }
@@ -491,6 +497,21 @@ static int32_t modexp_core(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const 
   using LL = LdsLayout<G>;
   unsigned blocks = 0;
   int32_t st;
+  if constexpr (PAIR_LADDER_BUILD && 2 * G <= 64) {
+    if (pair_ladder<G>(c, count)) {                       // a few items on the latency engine: right-to-left ladder on pairs of groups
+      unsigned long long* wcp = nullptr;
+      if ((st = fresh_work_counter(c, &wcp))) return st;
+      ModexpArgs pa{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, nullptr, count, (int)exp_bits, io_words,
+                    out_words ? out_words : io_words, nullptr, wcp, {}, 0};
+      const unsigned pair_blocks = (unsigned)std::max<uint64_t>(1, (count + LL::GROUPS_PER_BLOCK / 2 - 1) / (LL::GROUPS_PER_BLOCK / 2));
+      {
+        TimedRegion tr(c, count);
+        hipLaunchKernelGGL((k_modexp<G, false, false, true>), dim3(pair_blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, pa);
+      }
+      HIPCHK(c, hipGetLastError());
+      return ZKP_OK;
+    }
+  }
   if ((st = table_for<G>(c, k_modexp<G, true>, count, &blocks))) return st;
   const uint8_t* sched = nullptr;
   if (exp_stride == 0 && (st = build_schedule(c, exp, exp_bits, &sched))) return st;
@@ -517,10 +538,12 @@ static int32_t modexp_multi(zkp_ctx* c, uint64_t count, bool per_item_mod, std::
   std::stable_sort(calls.begin(), calls.end(), [](const ModexpCall& x, const ModexpCall& y) { return x.exp_bits > y.exp_bits; });
   if (calls.empty() || calls.size() > 3) { c->err = "modexp_multi: 1..3 segments"; return ZKP_EINVAL; }
   for (const ModexpCall& k : calls) if (k.exp_stride == 0) { c->err = "modexp_multi: per-item exponents only"; return ZKP_EINVAL; }
-  constexpr uint64_t IPW = 64 / G;
-  const uint64_t claims = (count + IPW - 1) / IPW * IPW * calls.size();
   int32_t st;
-  if (calls.size() == 1 || claims > (uint64_t)resident_blocks<G>(c, k_modexp<G, false, true>) * LL::GROUPS_PER_BLOCK) {
+  bool pair = false;
+  if constexpr (PAIR_LADDER_BUILD && 2 * G <= 64) pair = pair_ladder<G>(c, count * calls.size());
+  const uint64_t IPW = pair ? 64 / (2 * G) : 64 / G;      // items per claim, as the kernel counts them
+  const uint64_t claims = (count + IPW - 1) / IPW * IPW * calls.size();
+  if (!pair && (calls.size() == 1 || claims > (uint64_t)resident_blocks<G>(c, k_modexp<G, false, true>) * LL::GROUPS_PER_BLOCK)) {
     // the launch fills the GPU anyway: one launch per exponentiation on the single-segment kernel (no segment bookkeeping in
     // its product loops)
     for (const ModexpCall& k : calls)
@@ -528,7 +551,8 @@ static int32_t modexp_multi(zkp_ctx* c, uint64_t count, bool per_item_mod, std::
     return ZKP_OK;
   }
   unsigned blocks = 0;
-  if ((st = table_for<G>(c, k_modexp<G, false, true>, claims, &blocks))) return st;
+  if (pair) blocks = (unsigned)std::max<uint64_t>(1, (claims + LL::GROUPS_PER_BLOCK / 2 - 1) / (LL::GROUPS_PER_BLOCK / 2));
+  else if ((st = table_for<G>(c, k_modexp<G, false, true>, claims, &blocks))) return st;
   unsigned long long* wc = nullptr;
   if ((st = fresh_work_counter(c, &wc))) return st;
   const ModexpCall& f = calls[0];
@@ -540,7 +564,11 @@ static int32_t modexp_multi(zkp_ctx* c, uint64_t count, bool per_item_mod, std::
   }
   {
     TimedRegion tr(c, count * calls.size());
-    hipLaunchKernelGGL((k_modexp<G, false, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+    bool launched = false;
+    if constexpr (PAIR_LADDER_BUILD && 2 * G <= 64) {
+      if (pair) { hipLaunchKernelGGL((k_modexp<G, false, true, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a); launched = true; }
+    }
+    if (!launched) hipLaunchKernelGGL((k_modexp<G, false, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
   }
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
