@@ -86,7 +86,8 @@ def pmc_traffic_per_modexp(kernel_substr):
             continue
         for k, rec in data.items():
             d = rec.get("_derived") if isinstance(rec, dict) else None
-            if kernel_substr in k and d and "modexps_in_these_dispatches" in d and "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+            # (kernel names carry further template arguments in later builds: "k_enc<4, true" matches "k_enc<4, true, false>")
+            if kernel_substr.rstrip(">") in k and d and "modexps_in_these_dispatches" in d and "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
                 return (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0 / d["modexps_in_these_dispatches"], os.path.relpath(f, ROOT)
     return None, None
 

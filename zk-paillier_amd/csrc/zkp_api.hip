@@ -677,7 +677,7 @@ static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint3
   a.n = n; a.n_stride = n_stride; a.consts = (const uint32_t*)c->consts.p; a.const_stride = n_stride ? (uint64_t)CL::WORDS : 0;
   a.table = (uint32_t*)c->table.p; a.count = count; a.n_bits = (int)n_bits; a.mode = 0;
   a.m = m; a.r = r; a.out = out; a.items_per_key = n_stride ? 1 : count;
-  if (n_stride == 0 && (st = build_schedule(c, n, n_bits, &a.sched))) return st;
+  if (n_stride == 0 && !pair_ladder<G>(c, a.count) && (st = build_schedule(c, n, n_bits, &a.sched))) return st;
   if ((st = fresh_work_counter(c, &a.work_counter))) return st;
   {
     TimedRegion tr(c, count);
@@ -727,7 +727,7 @@ static int32_t enc_check_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const
   a.table = (uint32_t*)c->table.p; a.count = count; a.n_bits = (int)n_bits; a.mode = 2;
   a.m = m; a.r = r; a.items_per_key = n_stride ? 1 : count;
   a.c1 = exp_or_a; a.cipher_x = mulc_b; a.verdict = out_ok;
-  if (n_stride == 0 && (st = build_schedule(c, n, n_bits, &a.sched))) return st;
+  if (n_stride == 0 && !pair_ladder<G>(c, a.count) && (st = build_schedule(c, n, n_bits, &a.sched))) return st;
   if ((st = fresh_work_counter(c, &a.work_counter))) return st;
   {
     TimedRegion tr(c, count);
