@@ -336,7 +336,9 @@ template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_
 }
 
 // may `items` exponentiations take the pair ladder (two groups of G lanes each)?  Latency engine only, and only while the
-// launch with twice the lanes still leaves every SIMD at most one wavefront.
+// launch with twice the lanes still leaves every SIMD at most one wavefront (tools/dev/pair_sweep.py on MI355X, RangeProofNi
+// n = 2048: 8 proofs 24.0 / 22.2 ms either way; 12 proofs 27.2 / 22.8 ms on the window ladder, 34.6 / 29.2 ms on pairs that
+// share SIMDs two by two).
 constexpr bool PAIR_LADDER_BUILD = ZKP_W <= 9;            // the pair kernels are instantiated in the latency engine only
 template <int G> static bool pair_ladder(const zkp_ctx* c, uint64_t items) {
   if constexpr (PAIR_LADDER_BUILD && 2 * G <= 64) return items * 2 * G <= 4ull * (uint64_t)c->cus * 64;
