@@ -156,6 +156,18 @@ template <int G, bool SAFE, class LL> __device__ __forceinline__ void mmo_ip(con
   montmul<G, true, SAFE>(X, X, g.B(), NT, 1u, g.gl);
 }
 
+// Bits the ladders of this wavefront have to walk: the longest exponent among its groups (exponent words of this group in LDS at
+// lw, exp_bits/32 of them).  Leading zero bits cost nothing to skip, and the widths of the ABI are upper bounds — an honest
+// CompositeDLogProof response y has 513 bits in a 768-bit field.  Wave-uniform, so the control flow stays uniform.
+template <int G> __device__ __forceinline__ int wave_exponent_bits(const uint32_t* lw, int exp_bits) {
+  int top = (exp_bits >> 5) - 1;
+  while (top > 0 && lw[top] == 0) top--;
+  int bl = lw[top] ? 32 * top + 32 - __clz(lw[top]) : 0;
+#pragma unroll
+  for (int off = 32; off >= G && off >= 1; off >>= 1) { const int o = __shfl_xor(bl, off); bl = o > bl ? o : bl; }
+  return __builtin_amdgcn_readfirstlane(bl);
+}
+
 // (a) per-item exponents (sigma^n mod n with a different n per proof, DLog): fixed 5-bit windows, uniform
 //     control flow whatever the exponents are.  1.2 t + 30 products, ONE montmul call site: the table T[0] = R mod M
 //     (Montgomery one), T[1] = X, T[k] = T[k-1]*X is built by the first TAB-2 rounds of the same loop that then runs
@@ -174,11 +186,19 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
   }
   store_limbs_global<G>(tab + L, X, g.gl);
   stageB<G>(g, X);                                  // B() = X throughout the table rounds
-  const int nwin = (exp_bits + WIN - 1) / WIN;
   // the exponent words sit in the group's words() staging area for the length of the ladder (nothing converts a value in or out
   // while it runs); zero padded, so a window may straddle the top word
   fetch_words<G>(g, g.words(), ew, exp_bits >> 5);
   const uint32_t* lw = g.words();
+  // The number of windows follows the longest exponent of the wavefront.  It is parked in the (zero) padding of the words area
+  // and read back once, when the table is complete: a computed loop bound held in a register for the length of the ladder is one
+  // live value more than the product loop of the W = 36 kernels has room for (30 instead of 13 scratch accesses per product).
+  {
+    const int eff_bits = wave_exponent_bits<G>(lw, exp_bits);
+    wave_lds_fence();
+    if (g.gl == 0) g.words()[LL::NW + 6] = (uint32_t)(eff_bits ? (eff_bits + WIN - 1) / WIN : 1);
+    wave_lds_fence();
+  }
   auto window = [&](int wi) -> int {
     const int bit = wi * WIN;
     const int w0 = bit >> 5, off = bit & 31;
@@ -186,18 +206,26 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
     return (int)((x >> off) & (TAB - 1));
   };
   constexpr int TROUNDS = TAB - 2;
-  const int total = TROUNDS + (nwin - 1) * (WIN + 1);
+  // ONE counter: c < 0 counts the table rounds up to zero, then c counts the remaining products of the main part down to zero
+  // (window w = (c - 1) / (WIN + 1) from the top one down, the table product when (c - 1) % (WIN + 1) == 0).
   // the table stores of this lane are re-read by this lane only: program order suffices
+  int c = -TROUNDS;
 #pragma unroll 1
-  for (int i = 0; i < total; i++) {
-    const int step = i - TROUNDS;
-    if (step >= 0 && step % (WIN + 1) == WIN) load_limbs_global<G>(X, tab + window(nwin - 2 - step / (WIN + 1)) * L, g.gl);
+  for (;;) {
+    if (c > 0 && c % (WIN + 1) == 1) load_limbs_global<G>(X, tab + window((c - 1) / (WIN + 1)) * L, g.gl);
     mmo_ip<G, SAFE>(g, NT, X);
-    if (step < 0) {
-      store_limbs_global<G>(tab + (i + 2) * L, X, g.gl);
-      if (i == TROUNDS - 1) { load_limbs_global<G>(X, tab + window(nwin - 1) * L, g.gl); stageB<G>(g, X); }
+    if (c < 0) {
+      store_limbs_global<G>(tab + (c + TROUNDS + 2) * L, X, g.gl);
+      if (++c == 0) {
+        const int nwin = __builtin_amdgcn_readfirstlane((int)lw[LL::NW + 6]);
+        load_limbs_global<G>(X, tab + window(nwin - 1) * L, g.gl);
+        stageB<G>(g, X);
+        c = (nwin - 1) * (WIN + 1);
+        if (c == 0) break;
+      }
     } else {
       stageB<G>(g, X);
+      if (--c == 0) break;
     }
   }
 }
@@ -310,8 +338,9 @@ __device__ __forceinline__ void powm_pair(const Grp<G, LL>& g, uint32_t (&X)[W],
   if (role) load_limbs_global<G>(X, cst + CL::OFF_R1, g.gl);          // acc = 1
   wave_lds_fence();
   if (role) lds_store_block(g.B() + g.gl * BLK, X);                   // ... and its B operand stays 1 for the whole ladder
+  const int eff_bits = wave_exponent_bits<G>(lw, exp_bits);
 #pragma unroll 1
-  for (int j = 0; j < exp_bits; j++) {
+  for (int j = 0; j < eff_bits; j++) {
     wave_lds_fence();
     if (!role) lds_store_block(g.B() + g.gl * BLK, X);                // s_j
     wave_lds_fence();
