@@ -207,6 +207,80 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
   R[0] += from_prev<G>((uint32_t)cy, gl);
 }
 
+// ---------------------------------------------------------------- two quotient digits per chain step (latency engine)
+// The one dependency chain through a product is the quotient digit: bottom column -> digit -> broadcast -> N*q into the next
+// column -> carry -> next digit.  A lone wavefront per SIMD (the latency engine's small calls) waits it out W*G times per
+// product.  With a modulus multiple M~~ = M * n2, n2 = -M^-1 mod 2^58, the two low limbs of the operand N are 2^29 - 1 and BOTH
+// digits of a pair of sub-steps follow from the bottom two columns without a multiplication and without each other:
+//     q0 = low29(c[t]),    q1 = low29(c[t+1] + (c[t] >> 29))
+// (c[t] + q0 (2^29 - 1) = (hi + q0) 2^29, so column t hands hi + q0 up; column t+1 then holds c[t+1] + q0 (2^29 - 1) + hi + q0 =
+// c[t+1] + hi (mod 2^29), whatever q0 is).  Two broadcasts go out together and the chain advances two limbs of B per trip.  W is
+// odd (9): a block of W sub-steps is (W-1)/2 pairs and one single step, for which M~~ == -1 (mod 2^29) serves as well.
+// Same R = 2^(29 G W) as montmul, so values move freely between the two products; M~~ < 2^58 M needs 2 M~~ < R / 4, i.e. the
+// modulus 60 bits below the capacity: Paillier's n^2 (4096 bits in 4176, 8192 in 8352) fits, a 2048-bit modulus in 2088 does
+// not (k_setup records which, ConstLayout::OFF_ST + 2).
+template <int G>
+__device__ __forceinline__ void montmul2(uint32_t (&R)[W], const uint32_t (&A)[W], const uint32_t* ldsB, const uint32_t (&N)[W], int gl) {
+  static_assert(!COL_NEEDS_CARE, "the double-digit product is built for the short column window of the latency engine");
+  uint64_t c[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) c[k] = 0;
+#pragma unroll 1
+  for (int s = 0; s < G; s++) {
+#pragma unroll
+    for (int t = 0; t + 1 < W; t += 2) {
+      constexpr int dummy = 0; (void)dummy;
+      const int i0 = t % W, i1 = (t + 1) % W, i2 = (t + 2) % W;
+      const uint32_t b0 = ldsB[s * BLK + t], b1 = ldsB[s * BLK + t + 1];
+      c[i0] += (uint64_t)A[0] * b0;
+      c[i1] += (uint64_t)A[1] * b0;
+      c[i1] += (uint64_t)A[0] * b1;
+      const uint32_t q0 = bcast0<G>((uint32_t)c[i0] & LMASK);
+      const uint32_t q1 = bcast0<G>((uint32_t)(c[i1] + (c[i0] >> LB)) & LMASK);
+#pragma unroll
+      for (int k = 2; k < W; k++) c[(t + k) % W] += (uint64_t)A[k] * b0;
+#pragma unroll
+      for (int k = 1; k < W - 1; k++) c[(t + 1 + k) % W] += (uint64_t)A[k] * b1;
+#pragma unroll
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q0;
+#pragma unroll
+      for (int k = 0; k < W - 1; k++) c[(t + 1 + k) % W] += (uint64_t)N[k] * q1;
+      {
+        const uint64_t v = c[i0];
+        c[i1] += v >> LB;
+        c[i0] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);        // slot i0 is column t + W from here on
+      }
+      c[i0] += (uint64_t)A[W - 1] * b1;                                 // the top products of the second digit
+      c[i0] += (uint64_t)N[W - 1] * q1;
+      {
+        const uint64_t v = c[i1];
+        c[i2] += v >> LB;
+        c[i1] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+      }
+    }
+    if constexpr (W & 1) {
+      constexpr int t = W - 1;
+      const uint32_t b = ldsB[s * BLK + t];
+#pragma unroll
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)A[k] * b;
+      const uint32_t q = bcast0<G>((uint32_t)c[t] & LMASK);
+#pragma unroll
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q;
+      const uint64_t v = c[t];
+      c[(t + 1) % W] += v >> LB;
+      c[t] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+    }
+  }
+  uint64_t cy = 0;
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const uint64_t t = c[k] + cy;
+    R[k] = (uint32_t)t & LMASK;
+    cy = t >> LB;
+  }
+  R[0] += from_prev<G>((uint32_t)cy, gl);
+}
+
 // ---------------------------------------------------------------- representation changes
 // 32-bit words (LDS, `nwords` valid, zero padded up to at least nwords+2) -> this lane's W limbs
 __device__ __forceinline__ void limbs_from_words(uint32_t (&v)[W], const uint32_t* words, int gl) {

@@ -17,7 +17,11 @@ constexpr int TAB = 1 << WIN;
 template <int G> struct ConstLayout {
   static constexpr int L = Geo<G>::L;
   static constexpr int OFF_N = 0, OFF_R2 = L, OFF_R1 = 2 * L, OFF_NR = 3 * L, OFF_MT = 4 * L, OFF_NI = 5 * L, OFF_ST = 5 * L + 12;
-  static constexpr int WORDS = 5 * L + 12 + 4;
+  // status[0] = set-up status, [1] = the fast W = 36 product may be used, [2] = MT2 below is usable
+  // latency engine only: MT2 = M * n2, n2 = -M^-1 mod 2^58 (bigint29.hpp: montmul2)
+  static constexpr bool HAS_MT2 = !COL_NEEDS_CARE && (W & 1);
+  static constexpr int OFF_MT2 = 5 * L + 12 + 4;
+  static constexpr int WORDS = OFF_MT2 + (HAS_MT2 ? L : 0);
 };
 
 // ---- per-group LDS carve-up (uint32 words)
@@ -329,7 +333,10 @@ __device__ __forceinline__ void powm_pair(const Grp<G, LL>& g, uint32_t (&X)[W],
                                           const uint32_t* __restrict__ ew, int role /* 0 = squarer, 1 = accumulator */) {
   using CL = ConstLayout<G>;
   uint32_t NT[W];
-  load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
+  // two quotient digits per chain step (bigint29.hpp: montmul2) when every key of the wavefront has room for the 58-bit multiple
+  bool twodigit = false;
+  if constexpr (CL::HAS_MT2) twodigit = __all(cst[CL::OFF_ST + 2] != 0);
+  load_limbs_global<G>(NT, cst + (twodigit ? CL::OFF_MT2 : CL::OFF_MT), g.gl);
   uint32_t* partner = g.B() + (role ? -LL::WORDS : LL::WORDS);
   const uint32_t* squarerB = role ? partner : g.B();
   const uint32_t* accB = role ? g.B() : partner;
@@ -346,7 +353,9 @@ __device__ __forceinline__ void powm_pair(const Grp<G, LL>& g, uint32_t (&X)[W],
     wave_lds_fence();
     const bool bit = (lw[j >> 5] >> (j & 31)) & 1;
     const uint32_t* b = (role && bit) ? squarerB : g.B();
-    montmul<G, true, COL_NEEDS_CARE>(X, X, b, NT, 1u, g.gl);          // squarer: s * s ; accumulator: acc * (s_j | 1)
+    bool done = false;
+    if constexpr (CL::HAS_MT2) { if (twodigit) { montmul2<G>(X, X, b, NT, g.gl); done = true; } }
+    if (!done) montmul<G, true, COL_NEEDS_CARE>(X, X, b, NT, 1u, g.gl);   // squarer: s * s ; accumulator: acc * (s_j | 1)
   }
   wave_lds_fence();
   if (role) lds_store_block(g.B() + g.gl * BLK, X);
@@ -482,6 +491,28 @@ __global__ void __launch_bounds__(LdsLayoutFull<G>::THREADS) k_setup(const uint3
     wave_lds_fence();
     limbs_from_words(MT, rw, g.gl);
   }
+  // MT2 = M * n2 with the 58-bit n2 = -M^-1 mod 2^58 (montmul2); usable when 2 MT2 stays four times below R
+  [[maybe_unused]] uint32_t MT2[W];
+  [[maybe_unused]] bool mt2_ok = false;
+  if constexpr (CL::HAS_MT2) {
+    wave_lds_fence();
+    if (g.gl == 0) {
+      const uint64_t m0 = (uint64_t)mw[0] | ((uint64_t)mw[1] << 32);
+      uint64_t y = m0;
+#pragma unroll
+      for (int it = 0; it < 6; it++) y *= 2ull - m0 * y;               // 3 -> 6 -> ... -> 192 bits
+      const uint64_t n2 = (0ull - y) & ((1ull << (2 * LB)) - 1);
+      unsigned __int128 carry = 0;
+      for (int w = 0; w < NW + 3; w++) { const unsigned __int128 t = (unsigned __int128)mw[w] * n2 + carry; rw[w] = (uint32_t)t; carry = t >> 32; }
+      for (int w = NW + 3; w < NW + 8; w++) rw[w] = 0;
+    }
+    wave_lds_fence();
+    limbs_from_words(MT2, rw, g.gl);
+    int top = NW - 1;
+    while (top > 0 && mw[top] == 0) top--;
+    const int bl = mw[top] ? top * 32 + (32 - __clz(mw[top])) : 0;
+    mt2_ok = bl + 2 * LB + 3 <= CAP;
+  }
   // X = R^2 mod M (Montgomery form of R).  NR = src * R mod M (Montgomery form of n) for Paillier contexts.
   uint32_t NR[W];
 #pragma unroll
@@ -504,10 +535,12 @@ __global__ void __launch_bounds__(LdsLayoutFull<G>::THREADS) k_setup(const uint3
     store_limbs_global<G>(cst + CL::OFF_R1, R1, g.gl);
     store_limbs_global<G>(cst + CL::OFF_NR, NR, g.gl);
     store_limbs_global<G>(cst + CL::OFF_MT, MT, g.gl);
+    if constexpr (CL::HAS_MT2) store_limbs_global<G>(cst + CL::OFF_MT2, MT2, g.gl);
     if (g.gl == 0) {
       cst[CL::OFF_NI] = g.n1;
       cst[CL::OFF_ST] = (uint32_t)status;
       cst[CL::OFF_ST + 1] = fast_ok ? 1u : 0u;
+      cst[CL::OFF_ST + 2] = mt2_ok ? 1u : 0u;
       if (status && bad_flag) atomicOr(bad_flag, (uint32_t)status);
     }
   }
