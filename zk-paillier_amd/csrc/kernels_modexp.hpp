@@ -156,8 +156,10 @@ template <int G, class LL> __device__ __forceinline__ void canonical_words(const
 
 // in-place product on the Orup multiple: X = X * B() / R.  SAFE selects the column handling (bigint29.hpp "column capacity"):
 // the fast product is exact whenever the key's M~ passed the digit-sum test of k_setup (ConstLayout::OFF_ST + 1).
-template <int G, bool SAFE, class LL> __device__ __forceinline__ void mmo_ip(const Grp<G, LL>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
-  montmul<G, true, SAFE>(X, X, g.B(), NT, 1u, g.gl);
+// TWO (latency engine): NT is the 58-bit multiple and the product takes two quotient digits per chain step (bigint29.hpp: montmul2)
+template <int G, bool SAFE, bool TWO = false, class LL> __device__ __forceinline__ void mmo_ip(const Grp<G, LL>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
+  if constexpr (TWO) montmul2<G>(X, X, g.B(), NT, g.gl);
+  else montmul<G, true, SAFE>(X, X, g.B(), NT, 1u, g.gl);
 }
 
 // Bits the ladders of this wavefront have to walk: the longest exponent among its groups (exponent words of this group in LDS at
@@ -176,13 +178,13 @@ template <int G> __device__ __forceinline__ int wave_exponent_bits(const uint32_
 //     control flow whatever the exponents are.  1.2 t + 30 products, ONE montmul call site: the table T[0] = R mod M
 //     (Montgomery one), T[1] = X, T[k] = T[k-1]*X is built by the first TAB-2 rounds of the same loop that then runs
 //     (nwin-1) rounds of [5 squarings, 1 table product].
-template <int G, bool SAFE, class LL>
+template <int G, bool SAFE, bool TWO = false, class LL>
 __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst,
                                            const uint32_t* __restrict__ ew /* exponent words in global memory, exp_bits/32 of them */) {
   using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
   uint32_t NT[W];
-  load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
+  load_limbs_global<G>(NT, cst + (TWO ? CL::OFF_MT2 : CL::OFF_MT), g.gl);
   {
     uint32_t T[W];
     load_limbs_global<G>(T, cst + CL::OFF_R1, g.gl);
@@ -217,7 +219,7 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
 #pragma unroll 1
   for (;;) {
     if (c > 0 && c % (WIN + 1) == 1) load_limbs_global<G>(X, tab + window((c - 1) / (WIN + 1)) * L, g.gl);
-    mmo_ip<G, SAFE>(g, NT, X);
+    mmo_ip<G, SAFE, TWO>(g, NT, X);
     if (c < 0) {
       store_limbs_global<G>(tab + (c + TROUNDS + 2) * L, X, g.gl);
       if (++c == 0) {
@@ -274,13 +276,13 @@ __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int e
   ops[n] = OP_END;
 }
 
-template <int G, bool SAFE, class LL>
+template <int G, bool SAFE, bool TWO = false, class LL>
 __device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[W], const uint8_t* __restrict__ ops, uint32_t* tab, const uint32_t* cst) {
   using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
   static_assert((1 << (SWIN - 1)) == TAB, "table size");
   uint32_t NT[W];
-  load_limbs_global<G>(NT, cst + CL::OFF_MT, g.gl);
+  load_limbs_global<G>(NT, cst + (TWO ? CL::OFF_MT2 : CL::OFF_MT), g.gl);
   int op = __builtin_amdgcn_readfirstlane((int)ops[0]);
   if (op == OP_ZERO) {
     load_limbs_global<G>(X, cst + CL::OFF_R1, g.gl);
@@ -295,7 +297,7 @@ __device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[
     if (op == OP_END) break;
     const int type = op >> 5, e = op & (TAB - 1);
     if (type == (OP_MUL >> 5) || type == (OP_FIRST >> 5)) load_limbs_global<G>(X, tab + e * L, g.gl);   // B() still holds the running value
-    if (type != (OP_FIRST >> 5)) mmo_ip<G, SAFE>(g, NT, X);
+    if (type != (OP_FIRST >> 5)) mmo_ip<G, SAFE, TWO>(g, NT, X);
     if (type == (OP_TAB >> 5)) store_limbs_global<G>(tab + e * L, X, g.gl);
     else stageB<G>(g, X);
     if (type == (OP_SQ0 >> 5)) load_limbs_global<G>(X, tab, g.gl);
@@ -311,6 +313,14 @@ __device__ __forceinline__ void powm(const Grp<G, LL>& g, uint32_t (&X)[W], int 
                                      const uint32_t* __restrict__ exp_words_global) {
   using CL = ConstLayout<G>;
   const bool fast = !COL_NEEDS_CARE || __all(cst[CL::OFF_ST + 1] != 0);
+  if constexpr (CL::HAS_MT2) {
+    // latency engine: two quotient digits per chain step when every key of the wavefront leaves room for the 58-bit multiple
+    if (__all(cst[CL::OFF_ST + 2] != 0)) {
+      if constexpr (SHARED_EXP) powm_sliding<G, false, true>(g, X, sched, tab, cst);
+      else powm_fixed<G, false, true>(g, X, exp_bits, tab, cst, exp_words_global);
+      return;
+    }
+  }
   if constexpr (SHARED_EXP) {
     if (fast) powm_sliding<G, false>(g, X, sched, tab, cst);
     else powm_sliding<G, true>(g, X, sched, tab, cst);
