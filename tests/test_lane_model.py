@@ -137,3 +137,101 @@ def test_fast_product_bound(G, W):
     assert ((1 << B) + 16) * (W * (1 << B) + 16) + MASK * lim + (1 << 36) < (1 << 64)
     # ... and the bound is not vacuous: with an all-ones modulus operand the analytic bound fails
     assert ((1 << B) + 16) * (W * (1 << B) + 16) + MASK * (W * MASK) + (1 << 36) > (1 << 64)
+
+
+def montmul2(N, G, W, A, Bv, stats):
+    """mirror of montmul2<G> (bigint29.hpp): N = limbs of M~~ = M * n2, n2 = -M^-1 mod 2^58; W odd: (W-1)/2 pairs + one single step"""
+    c = [[0] * W for _ in range(G)]
+
+    def finish(t):
+        lo = [0] * G
+        for j in range(G):
+            v = c[j][t % W]
+            lo[j] = v & MASK
+            c[j][(t + 1) % W] += v >> B
+        assert lo[0] == 0
+        for j in range(G):
+            c[j][t % W] = lo[j + 1] if j + 1 < G else 0
+
+    for s in range(G):
+        t = 0
+        while t + 1 < W:
+            b0, b1 = Bv[s * W + t], Bv[s * W + t + 1]
+            for j in range(G):
+                c[j][t % W] += A[j * W] * b0
+                c[j][(t + 1) % W] += A[j * W + 1] * b0 + A[j * W] * b1
+            q0 = c[0][t % W] & MASK
+            q1 = (c[0][(t + 1) % W] + (c[0][t % W] >> B)) & MASK          # does not wait for q0
+            for j in range(G):
+                for k in range(2, W):
+                    c[j][(t + k) % W] += A[j * W + k] * b0
+                for k in range(1, W - 1):
+                    c[j][(t + 1 + k) % W] += A[j * W + k] * b1
+                for k in range(W):
+                    c[j][(t + k) % W] += N[j * W + k] * q0
+                for k in range(W - 1):
+                    c[j][(t + 1 + k) % W] += N[j * W + k] * q1
+            finish(t)                                                      # slot t is column t + W from here on
+            for j in range(G):
+                c[j][t % W] += A[j * W + W - 1] * b1 + N[j * W + W - 1] * q1
+            finish(t + 1)
+            stats["maxcol"] = max(stats["maxcol"], max(max(r) for r in c))
+            t += 2
+        if W & 1:
+            b = Bv[s * W + W - 1]
+            for j in range(G):
+                for k in range(W):
+                    c[j][(W - 1 + k) % W] += A[j * W + k] * b
+            q = c[0][W - 1] & MASK
+            for j in range(G):
+                for k in range(W):
+                    c[j][(W - 1 + k) % W] += N[j * W + k] * q
+            finish(W - 1)
+            stats["maxcol"] = max(stats["maxcol"], max(max(r) for r in c))
+    out, carries = [], []
+    for j in range(G):
+        cy, r = 0, []
+        for k in range(W):
+            v = c[j][k] + cy
+            r.append(v & MASK)
+            cy = v >> B
+        out.append(r)
+        carries.append(cy)
+    for j in range(1, G):
+        out[j][0] += carries[j - 1]
+    assert carries[G - 1] == 0
+    return [v for r in out for v in r]
+
+
+@pytest.mark.parametrize("bits,G,W", [(4096, 16, 9), (8192, 32, 9), (2048, 8, 9), (900, 4, 9)])
+def test_two_quotient_digits_per_step_model(bits, G, W):
+    """the latency engine's product under the 58-bit Orup multiple: both digits of a pair of sub-steps come from the bottom two
+    columns without a multiplication and without each other; same R as montmul, results < 2 M~~, no column near 2^64.  A modulus
+    within 60 bits of the capacity (2048 bits in 8 x 9 limbs) has no room for M~~: k_setup's flag (ConstLayout::OFF_ST + 2)."""
+    rnd = random.Random(bits + G)
+    M = rnd.getrandbits(bits) | 1 | (1 << (bits - 1))
+    L = G * W
+    R = 1 << (B * L)
+    n2 = (-pow(M, -1, 1 << (2 * B))) % (1 << (2 * B))
+    Mt2 = M * n2
+    assert Mt2 % (1 << (2 * B)) == (1 << (2 * B)) - 1
+    fits = bits + 2 * B + 3 <= B * L                    # k_setup: mt2_ok
+    assert not fits or 4 * (2 * Mt2) < R                # operands < 2 M~~ and R > 4 * that: results stay < 2 M~~
+    if not fits:
+        assert (bits, G) == (2048, 8)
+        return
+    N = to_limbs(Mt2, L)
+    assert N[0] == MASK and N[1] == MASK
+    Rinv = pow(R, -1, M)
+    stats = {"maxcol": 0}
+    n1 = n2 & MASK
+    for _ in range(2):
+        a, b = rnd.randrange(2 * Mt2), rnd.randrange(2 * Mt2)
+        r = montmul2(N, G, W, to_limbs(a, L), to_limbs(b, L), stats)
+        v = from_limbs(r)
+        assert v % M == a * b * Rinv % M and v < 2 * Mt2
+        # the single-digit product on the same multiple gives the same value limb for limb (montmul2 only reorders the schedule)
+        assert r == montmul(N, n1, G, W, to_limbs(a, L), to_limbs(b, L), True, {"maxcol": 0}, safe=False)
+        r2 = montmul2(N, G, W, r, r, stats)
+        assert from_limbs(r2) % M == v * v * Rinv % M
+    assert stats["maxcol"] < (1 << 63)
