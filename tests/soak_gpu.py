@@ -30,16 +30,13 @@ def family(d, bits, kind):
     return d.bits(bits) | (top << (bits - 64)) & top
 
 
-def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    zkp = H.zkp
-    ctx = zkp.Context(0)
-    oracle = oracle_lib.Oracle()
-    oracle.set_threads(min(16, oracle.max_threads()))
+def run(ctx, oracle, tag=b"soak", rounds=3, deadline=None, log=print):
+    """`rounds` rounds (or until time.monotonic() passes `deadline`) of inputs drawn from the DRBG seeded with `tag`; -> items checked"""
+    import time
     total = 0
     for rd in range(rounds):
         for mod_bits, count, exp_bits in ((2048, 4096, 2048), (4096, 1024, 256), (4096, 512, 4096), (8192, 128, 512)):
-            d = pm.Drbg(b"soak-%d-%d-%d" % (rd, mod_bits, exp_bits))
+            d = pm.Drbg(tag + b"-%d-%d-%d" % (rd, mod_bits, exp_bits))
             nl, el = mod_bits // 32, exp_bits // 32
             mods, bases, exps = [], [], []
             for i in range(count):
@@ -53,15 +50,28 @@ def main():
             ctx.modexp(mod_bits, exp_bits, count, b, e, el, m, nl, out)
             ref = oracle.modexp(mod_bits, exp_bits, b, e, el, m, nl)
             bad = [i for i in range(count) if not np.array_equal(out[i], ref[i])]
-            assert not bad, (mod_bits, exp_bits, bad[:5])
+            assert not bad, (tag, mod_bits, exp_bits, bad[:5])
             a2 = L.ints_to_limbs([family(d, mod_bits, (i // 3) % 8) for i in range(count)], nl)
             out2 = np.zeros_like(b)
             ctx.modmul(mod_bits, count, b, a2, m, nl, out2)
-            assert np.array_equal(out2, oracle.modmul(mod_bits, b, a2, m, nl))
+            assert np.array_equal(out2, oracle.modmul(mod_bits, b, a2, m, nl)), (tag, mod_bits)
             total += 2 * count
-        # Paillier Enc with adversarial m, r under per-item keys
+            # ONE exponent and ONE modulus for the whole call (the sliding-window ladder): every base family under a modulus of every family
+            cs = min(count, 256)
+            for fam in (rd % 8, (rd + 3) % 8):
+                m1 = L.ints_to_limbs([max(3, family(d, mod_bits, fam) | 1)], nl)
+                e1 = L.ints_to_limbs([family(d, exp_bits, (fam + rd) % 8)], el)
+                o1 = np.zeros_like(b[:cs])
+                ctx.modexp(mod_bits, exp_bits, cs, b[:cs], e1, 0, m1, 0, o1)
+                r1 = oracle.modexp(mod_bits, exp_bits, b[:cs], np.repeat(e1, cs, axis=0), el, np.repeat(m1, cs, axis=0), nl)
+                assert np.array_equal(o1, r1), (tag, "shared", mod_bits, exp_bits, fam)
+                total += cs
+            if deadline is not None and time.monotonic() > deadline:
+                log("soak: time box reached in round", rd, "after", total, "items")
+                return total
+        # Paillier Enc with adversarial m, r under per-item keys, and under one shared key
         for n_bits, count in ((1024, 512), (2048, 512)):
-            d = pm.Drbg(b"soak-enc-%d-%d" % (rd, n_bits))
+            d = pm.Drbg(tag + b"-enc-%d-%d" % (rd, n_bits))
             kw = n_bits // 32
             ns = [family(d, n_bits, i % 8) | 1 | (1 << (n_bits - 1)) for i in range(count)]
             ms = [family(d, n_bits, (i // 8) % 8) for i in range(count)]
@@ -69,10 +79,23 @@ def main():
             nl, m, r = (L.ints_to_limbs(v, kw) for v in (ns, ms, rs))
             out = np.zeros((count, 2 * kw), np.uint32)
             ctx.paillier_enc(n_bits, count, nl, kw, m, r, out)
-            assert np.array_equal(out, oracle.paillier_enc(n_bits, nl, kw, m, r))
-            total += count
-        print("round", rd, "ok,", total, "items checked so far", flush=True)
-    print("SOAK OK", total)
+            assert np.array_equal(out, oracle.paillier_enc(n_bits, nl, kw, m, r)), (tag, "enc", n_bits)
+            n1 = np.ascontiguousarray(nl[rd % count:rd % count + 1])
+            ctx.paillier_enc(n_bits, count, n1, 0, m, r, out)
+            assert np.array_equal(out, oracle.paillier_enc(n_bits, np.repeat(n1, count, axis=0), kw, m, r)), (tag, "enc shared", n_bits)
+            total += 2 * count
+        log("round", rd, "ok,", total, "items checked so far")
+        if deadline is not None and time.monotonic() > deadline:
+            return total
+    return total
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    ctx = H.zkp.Context(0)
+    oracle = oracle_lib.Oracle()
+    oracle.set_threads(min(16, oracle.max_threads()))
+    print("SOAK OK", run(ctx, oracle, b"soak", rounds, log=lambda *a: print(*a, flush=True)))
 
 
 if __name__ == "__main__":

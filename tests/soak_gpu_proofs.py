@@ -16,30 +16,28 @@ import oracle_lib
 FIELDS = ("c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2", "range", "ciphertext")
 
 
-def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+def run(ctx, oracle, seed=1000, rounds=3, deadline=None, log=print, tag=b"soakp"):
+    """`rounds` rounds (or until `deadline`, time.monotonic()) of prove / tamper / verify; -> proofs checked"""
+    import time
     zkp = H.zkp
-    ctx = zkp.Context(0)
-    oracle = oracle_lib.Oracle()
-    oracle.set_threads(min(16, oracle.max_threads()))
     keys = [H.test_key(512, tag=t)[2] for t in range(6)]
     total = 0
     for rd in range(rounds):
-        rng = np.random.default_rng(1000 + rd)
+        rng = np.random.default_rng(seed + rd)
         n_bits, B = 1024, (48, 1, 5, 300)[rd % 4]          # one proof ... a batch that takes the one-stream verify sequence
         ctx.set_geometry((0, 36, 9)[rd % 3])               # automatic choice / pinned to either engine
         shared = bool(rd % 2)
         klist = [keys[rd % 6]] if shared else [keys[(rd + b) % 6] for b in range(B)]
-        cases = H.build_range_case(b"soakp-%d" % rd, klist, n_bits, B, shared=shared)
+        cases = H.build_range_case(tag + b"-%d-%d" % (seed, rd), klist, n_bits, B, shared=shared)
         for b in range(0, B, 7):
-            cases[b] = H.build_range_case(b"soakp-bad-%d-%d" % (rd, b), [cases[b]["n"]], n_bits, 1, honest=False)[0]
+            cases[b] = H.build_range_case(tag + b"-bad-%d-%d-%d" % (seed, rd, b), [cases[b]["n"]], n_bits, 1, honest=False)[0]
         pb_o, wt = H.fill_batch(cases, n_bits, shared, oracle)
         pb_g = zkp.RangeBatch(n_bits, B, 128, shared_key=shared)
         pb_g.n[:] = pb_o.n; pb_g.range[:] = pb_o.range; pb_g.ciphertext[:] = pb_o.ciphertext
         oracle.range_ni_prove(pb_o.struct(), wt.struct(), None, None, None)
         ctx.range_ni_prove(pb_g.struct(), wt.struct(), None, None, None, device=False)
         for f in FIELDS[:8]:
-            assert np.array_equal(getattr(pb_o, f), getattr(pb_g, f)), (rd, f)
+            assert np.array_equal(getattr(pb_o, f), getattr(pb_g, f)), (seed, rd, f)
         # random tampering: ~half of the proofs get 1..3 random edits
         for b in range(B):
             if rng.random() < 0.5:
@@ -56,10 +54,21 @@ def main():
         vo = np.full(B, 9, np.uint8); vg = np.full(B, 9, np.uint8)
         oracle.range_ni_verify(pb_g.struct(), vo)
         ctx.range_ni_verify(pb_g.struct(), vg, device=False)
-        assert np.array_equal(vo, vg), (rd, list(vo), list(vg))
+        assert np.array_equal(vo, vg), (seed, rd, list(vo), list(vg))
         total += B
-        print("round", rd, "B", B, "ran on", ctx.last_geometry(), "limbs per lane, ok: accepted", int((vo == 1).sum()), "rejected", int((vo == 0).sum()), "of", B, flush=True)
-    print("PROOF SOAK OK", total)
+        log("round", rd, "B", B, "ran on", ctx.last_geometry(), "limbs per lane, ok: accepted", int((vo == 1).sum()), "rejected", int((vo == 0).sum()), "of", B)
+        if deadline is not None and time.monotonic() > deadline:
+            break
+    ctx.set_geometry(0)
+    return total
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    ctx = H.zkp.Context(0)
+    oracle = oracle_lib.Oracle()
+    oracle.set_threads(min(16, oracle.max_threads()))
+    print("PROOF SOAK OK", run(ctx, oracle, 1000, rounds, log=lambda *a: print(*a, flush=True)))
 
 
 if __name__ == "__main__":

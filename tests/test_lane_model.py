@@ -235,3 +235,111 @@ def test_two_quotient_digits_per_step_model(bits, G, W):
         r2 = montmul2(N, G, W, r, r, stats)
         assert from_limbs(r2) % M == v * v * Rinv % M
     assert stats["maxcol"] < (1 << 63)
+
+
+def sqr_sets(W):
+    """bigint29.hpp montsqr: K_t as (k, doubled) pairs — the position itself undoubled, plus a tournament on the other positions"""
+    H = W // 2
+    K = []
+    for t in range(W):
+        ks = [(t, False)]
+        for k in range(W):
+            d = (k - t) % W
+            take = (1 <= d <= H) if W & 1 else (1 <= d < H or (d == H and t < H))
+            if take:
+                ks.append((k, True))
+        K.append(ks)
+    return K
+
+
+def montsqr(N, G, W, A, stats, check=True):
+    """mirror of montsqr<G>: the Orup product of A with itself in which sub-step s multiplies only the limbs of K_(s mod W)"""
+    K = sqr_sets(W)
+    c = [[0] * W for _ in range(G)]
+    for s in range(G):
+        for t in range(W):
+            b = A[s * W + t]
+            for j in range(G):
+                for k, dbl in K[t]:
+                    c[j][(t + k) % W] += A[j * W + k] * (b + b if dbl else b)
+                    stats["mads"] = stats.get("mads", 0) + 1
+            q = c[0][t] & MASK
+            lo = [0] * G
+            for j in range(G):
+                for k in range(W):
+                    c[j][(t + k) % W] += N[j * W + k] * q
+                    stats["mads"] = stats.get("mads", 0) + 1
+                stats["maxcol"] = max(stats["maxcol"], max(c[j]))
+                v = c[j][t]
+                lo[j] = v & MASK
+                c[j][(t + 1) % W] += v >> B
+                stats["maxcol"] = max(stats["maxcol"], c[j][(t + 1) % W])
+            assert not check or lo[0] == 0
+            for j in range(G):
+                c[j][t] = lo[j + 1] if j + 1 < G else 0
+    out, carries = [], []
+    for j in range(G):
+        cy, r = 0, []
+        for k in range(W):
+            v = c[j][k] + cy
+            r.append(v & MASK)
+            cy = v >> B
+        out.append(r)
+        carries.append(cy)
+    for j in range(1, G):
+        out[j][0] += carries[j - 1]
+        assert not check or out[j][0] < (1 << B) + 64
+    assert not check or carries[G - 1] == 0
+    return [v for r in out for v in r]
+
+
+@pytest.mark.parametrize("W", [36, 18, 9])
+def test_squaring_sets_form_a_tournament(W):
+    """every unordered pair of DIFFERENT limb positions is taken by exactly one of its two sub-steps (and doubled); a position
+    takes itself, undoubled: ordered pairs of limbs at equal positions keep both orders"""
+    K = sqr_sets(W)
+    for t in range(W):
+        assert (t, False) in K[t] and all(dbl for k, dbl in K[t] if k != t)
+        for k in range(W):
+            if k != t:
+                assert ((k, True) in K[t]) != ((t, True) in K[k])
+    sizes = sorted(len(ks) for ks in K)
+    assert sizes[0] >= (W + 1) // 2 and sizes[-1] <= W // 2 + 1
+
+
+@pytest.mark.parametrize("bits,G,W", [(4096, 4, 36), (2048, 2, 36), (8192, 8, 36), (4096, 8, 18), (4096, 16, 9)])
+def test_squaring_model_equals_the_product(bits, G, W):
+    """montsqr(X) is montmul(X, X) on the Orup multiple: same value (here even limb for limb), 3/4 of the multiply-adds"""
+    rnd = random.Random(bits + 7 * G)
+    M = rnd.getrandbits(bits) | 1 | (1 << (bits - 1))
+    L = G * W
+    R = 1 << (B * L)
+    n1 = (-pow(M, -1, 1 << B)) % (1 << B)
+    Mt = M * n1
+    N = to_limbs(Mt, L)
+    Rinv = pow(R, -1, M)
+    stats = {"maxcol": 0}
+    x = to_limbs(rnd.randrange(2 * Mt), L)
+    for _ in range(4):                                   # a chain of squarings: almost-normalised outputs fed straight back
+        stats["mads"] = 0
+        r = montsqr(N, G, W, x, stats)
+        ref = montmul(N, n1, G, W, x, x, True, {"maxcol": 0}, safe=False)
+        assert from_limbs(r) == from_limbs(ref) and from_limbs(r) % M == from_limbs(x) ** 2 * Rinv % M and from_limbs(r) < 2 * Mt
+        x = r
+    assert stats["maxcol"] < (1 << 64)
+    assert 0.75 <= stats["mads"] / (2 * L * L) <= 0.78
+
+
+@pytest.mark.parametrize("G,W", [(4, 36), (2, 36)])
+def test_squaring_keeps_the_fast_column_bound(G, W):
+    """operand limbs at their maximum and a modulus operand exactly at COL_FAST_SN_LIMIT: over a column's life the doubled and
+    single products of a lane are at most 2 * 18 (or 2 * 17 + 2) limb products, the same total as the W products of montmul"""
+    lim = fast_sn_limit(W)
+    lane = [MASK] * 27 + [lim - 27 * MASK] + [0] * (W - 28)
+    stats = {"maxcol": 0}
+    montsqr(lane * G, G, W, worst_operands(G, W), stats, check=False)
+    assert (1 << 63) < stats["maxcol"] < (1 << 64)
+    K = sqr_sets(W)
+    for col in range(W):                                 # multiplicity of limb products landing in one column of one lane
+        mult = sum((2 if dbl else 1) for t in range(W) for k, dbl in K[t] if (t + k) % W == col)
+        assert mult == W

@@ -29,7 +29,30 @@ def test_inverse_and_gcd(kw):
         if g == 1:
             assert inv == pow(y, -1, m)
         assert W.wbgcd(y, m, kw, False)[0] == g
-    assert stats["maxcof"] == 0                          # the cofactors stay inside (-m, m): one conditional add at the end
+    assert stats["maxcof"] <= 1 and stats.get("final_passes", 0) <= 2   # the cofactors stay within a small multiple of m
+
+
+def test_cofactor_slightly_above_the_modulus_in_magnitude():
+    """a = M - r for small even r: the balanced correction leaves v = -1.07 M (advisor's vector, round 2).  A single conditional
+    add of M returned a negative number with status OK; the finalisation reduces until 0 <= v < M."""
+    M = 4400505965657808285
+    stats = {"maxcof": 0}
+    g, inv = W.wbgcd(M - 14, M, 8, True, stats)
+    assert g == 1 and inv == pow(M - 14, -1, M) and stats["maxcof"] == 1 and stats["final_passes"] == 2
+    rnd = random.Random(99)
+    hits = 0
+    for bits in (123, 153, 2041, 8192):   # bit lengths congruent to 1..6 mod 30 are where it shows
+        kw = ((bits + 31) // 32 + 7) // 8 * 8
+        for _ in range(40 if bits < 1000 else 6):
+            m = rnd.getrandbits(bits) | 1 | (1 << (bits - 1))
+            for r in (14, 30, 42, 46, 62):
+                if math.gcd(m - r, m) != 1:
+                    continue
+                st = {"maxcof": 0}
+                g, inv = W.wbgcd(m - r, m, kw, True, st)
+                assert g == 1 and inv == pow(m - r, -1, m)
+                hits += st["maxcof"] > 0
+    assert hits > 0                                      # the case is exercised, not just survived
 
 
 def test_gcd_of_values_above_the_modulus_and_zero_low_words():

@@ -92,7 +92,21 @@ def wbgcd(y, m, kw, cof=True, stats=None):
     if g != 1: return g, None
     vv = sunwords(v)
     assert (vv * y - 1) % m == 0
-    return g, vv % m
+    # the kernel's finalisation (kernels_inv.hpp: k_modinv): add m while negative, subtract m while >= m, on kw words + sign word
+    passes = 0
+    while True:
+        top = v[kw] - (1 << 32) if v[kw] >> 31 else v[kw]
+        neg, ge = top < 0, top > 0
+        if top == 0: ge = unwords(v[:kw]) >= m
+        if not neg and not ge: break
+        t = (unwords(v[:kw]) + (m if neg else -m))
+        carry = t >> (32 * kw)                     # +1 / 0 / -1
+        v = words(t & ((1 << (32 * kw)) - 1), kw) + [(v[kw] + carry) & 0xFFFFFFFF]
+        passes += 1
+        assert passes < 256
+    if stats is not None: stats["final_passes"] = max(stats.get("final_passes", 0), passes)
+    assert v[kw] == 0 and unwords(v[:kw]) == vv % m
+    return g, unwords(v[:kw])
 
 if __name__ == "__main__":
     rnd = random.Random(1)

@@ -207,6 +207,70 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
   R[0] += from_prev<G>((uint32_t)cy, gl);
 }
 
+// ---------------------------------------------------------------- Montgomery squaring: X = X * X / R on the Orup multiple
+// 86 % of the products of a ladder are squarings.  A*A holds every cross product a_m a_s twice, but the systolic array pins
+// the product a_m * b_s to lane(m) at sub-step s, so "compute the upper triangle only" would leave the low lanes idle in
+// lockstep and save nothing.  What the array does allow is a choice PER LIMB POSITION: at sub-step s (position t = s mod W
+// inside its block) every lane multiplies only the limbs k of a fixed set K_t by b_s, the same register indices in all lanes.
+// The ordered pair (m, s) is then computed iff (m mod W) is in K_(s mod W), and if the sets form a TOURNAMENT on the W
+// positions — for k != t exactly one of "k in K_t", "t in K_k" holds — every unordered pair of limbs at different positions
+// is computed exactly once, whatever lanes the two limbs live in: those products are doubled (b_s + b_s as the multiplier).
+// Limbs at the SAME position (k == t, different blocks or the true square a_s^2) keep both orders, undoubled.
+// K_t = { t } + { k : (k - t) mod W in 1 .. W/2 - 1 } + { t + W/2 if t < W/2 }: 18 or 19 multiply-adds per sub-step instead of 36,
+// with the sub-step's bookkeeping, quotient digit and N * q half unchanged (54.5 instead of 72 multiply-adds: -24 %).
+// Every product lands in the column and at a sub-step where montmul puts a product of the same column, so the column a
+// quotient digit is read from is complete exactly as before: the digits, and with them the result, are those of
+// montmul(X, X) (tests/test_lane_model.py: same value, column bound).  Column capacity: over a column's life the doubled and
+// single products of a lane add up to at most 2 * 18 (or 2 * 17 + 2) limb products — the FAST bound of "column capacity"
+// above holds unchanged; there is no SAFE variant (keys whose M~ fails the digit-sum test keep montmul for every product).
+#ifndef ZKP_SQR_VARIANT
+#define ZKP_SQR_VARIANT 0
+#endif
+template <int G>
+__device__ __forceinline__ void montsqr(uint32_t (&X)[W], const uint32_t* ldsB /* the staged copy of X */, const uint32_t (&N)[W], int gl) {
+  constexpr int H = W / 2;   // (odd W: distances 1 .. (W-1)/2 form a regular tournament by themselves)
+  uint64_t c[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) c[k] = 0;
+#pragma unroll 1
+  for (int s = 0; s < G; s++) {
+#pragma unroll
+    for (int t = 0; t < W; t++) {
+#if ZKP_SQR_VARIANT & 2
+      if (t % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
+      uint32_t b = ldsB[s * BLK + t];
+      c[(2 * t) % W] += (uint64_t)X[t] * b;
+#if ZKP_SQR_VARIANT & 1
+      asm("v_lshlrev_b32 %0, 1, %0" : "+v"(b));       // doubled in place: the single multiplier is dead from here on
+      const uint32_t b2 = b;
+#else
+      const uint32_t b2 = b + b;
+#endif
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        const int d = (k - t + W) % W;
+        const bool take = (W & 1) ? (d >= 1 && d <= H) : ((d >= 1 && d < H) || (d == H && t < H));
+        if (take) c[(t + k) % W] += (uint64_t)X[k] * b2;
+      }
+      const uint32_t q = bcast0<G>((uint32_t)c[t] & LMASK);
+#pragma unroll
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q;
+      const uint64_t v = c[t];
+      c[(t + 1) % W] += v >> LB;
+      c[t] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+    }
+  }
+  uint64_t cy = 0;
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const uint64_t t = c[k] + cy;
+    X[k] = (uint32_t)t & LMASK;
+    cy = t >> LB;
+  }
+  X[0] += from_prev<G>((uint32_t)cy, gl);
+}
+
 // ---------------------------------------------------------------- two quotient digits per chain step (latency engine)
 // The one dependency chain through a product is the quotient digit: bottom column -> digit -> broadcast -> N*q into the next
 // column -> carry -> next digit.  A lone wavefront per SIMD (the latency engine's small calls) waits it out W*G times per

@@ -9,7 +9,8 @@
 // 31-bit signed coefficients records what the steps did; then the matrix is applied to the full operands in ONE pass:
 //     a' = (f0 a + g0 b) / 2^30,   b' = (f1 a + g1 b) / 2^30          (exact divisions; a sign is fixed up afterwards)
 // and, for the inverse, to the cofactors modulo m in one more pass (u' = (f0 u + g0 v + c m) / 2^30 with the balanced
-// c = -(f0 u + g0 v) / m mod 2^30, so that |u'| < m forever).  len(a) + len(b) shrinks by about 30 bits per round: 258 rounds for
+// c = -(f0 u + g0 v) / m mod 2^30: |u'| <= max(|u|, |v|) + m/2 — the cofactors stay within a small multiple of m, observed
+// < 1.13 m, NOT inside (-m, m); the caller reduces the one it uses).  len(a) + len(b) shrinks by about 30 bits per round: 258 rounds for
 // 4096-bit operands instead of ~5800 bit-serial ones.  b stays odd throughout; the loop ends when a == 0, gcd = b.
 // tools/wbgcd_model.py is the word-for-word Python model of this file (int64 ranges asserted).
 //

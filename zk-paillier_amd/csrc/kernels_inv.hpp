@@ -10,7 +10,7 @@ namespace zkp {
 // ------------------------------------------------------------------------------------------
 // out = a^-1 mod M (curv BigInt::mod_inv -> mpz_invert; multiplication_proof.rs:95,135, correct_message.rs:53,76,141).
 // Word-batched binary extended GCD (kernels_gcd.hpp): ~258 rounds of two passes over 4096-bit operands; the cofactors are kept
-// modulo M as two's complement numbers of kw + 1 words with |u|, |v| < M.  a, b, u, v and a copy of M live in thread-interleaved
+// modulo M as two's complement numbers of kw + 1 words (|u|, |v| stay within a small multiple of M; the result is reduced at the end).  a, b, u, v and a copy of M live in thread-interleaved
 // LDS (word w of lane t at base[w * LANES + t]: conflict-free).  Data-dependent trip counts: lanes of a wavefront wait for the
 // slowest one (the counts differ by a few rounds).
 struct ModinvArgs {
@@ -58,14 +58,31 @@ __global__ void __launch_bounds__(64) k_modinv(ModinvArgs a) {
   bool one = pb[0] == 1;
   for (int w = 1; w < nb; w++) one = one && pb[w * S] == 0;
   if (!one) { a.status[item] = ZKP_INV_NONE; return; }
-  // 1 == A * v (mod M) with -M < v < M
-  const uint32_t addm = (int32_t)pv[kw * S] < 0 ? 0xFFFFFFFFu : 0u;
-  uint32_t carry = 0;
-  for (int w = 0; w < kw; w++) {
-    const uint64_t t = (uint64_t)pv[w * S] + (pm[w * S] & addm) + carry;
-    out[w] = (uint32_t)t;
-    carry = (uint32_t)(t >> 32);
+  // 1 == A * v (mod M).  The balanced correction of a round only keeps |v'| <= max(|u|, |v|) + M/2, not |v| < M: values a little
+  // above M in magnitude occur (a = M - 14: v = -1.07 M), so the residue is reduced properly — add M while v is negative, then
+  // subtract M while v >= M, over the kw words and the sign word (a handful of passes at most; each one moves v towards [0, M)).
+  for (;;) {
+    const int32_t top = (int32_t)pv[kw * S];
+    bool neg = top < 0, ge = top > 0;
+    if (top == 0) {                                    // 0 <= v < 2^(32 kw): compare with M
+      ge = true;                                       // (v == M cannot happen for gcd 1, but would reduce to 0)
+      for (int w = kw - 1; w >= 0; w--) {
+        const uint32_t vw = pv[w * S], mw = pm[w * S];
+        if (vw != mw) { ge = vw > mw; break; }
+      }
+    }
+    if (!neg && !ge) break;
+    if (neg) {
+      uint32_t carry = 0;
+      for (int w = 0; w < kw; w++) { const uint64_t t = (uint64_t)pv[w * S] + pm[w * S] + carry; pv[w * S] = (uint32_t)t; carry = (uint32_t)(t >> 32); }
+      pv[kw * S] += carry;
+    } else {
+      uint32_t borrow = 0;
+      for (int w = 0; w < kw; w++) { const uint64_t t = (uint64_t)pv[w * S] - pm[w * S] - borrow; pv[w * S] = (uint32_t)t; borrow = (uint32_t)(t >> 63); }
+      pv[kw * S] -= borrow;
+    }
   }
+  for (int w = 0; w < kw; w++) out[w] = pv[w * S];
   a.status[item] = ZKP_INV_OK;
 }
 

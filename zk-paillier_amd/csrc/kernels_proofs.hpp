@@ -654,7 +654,23 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
     const uint64_t b = item / ZKP_CORRECT_KEY_M2;
     const uint32_t* cst = a.consts + b * CL::WORDS;
     load_modulus_consts<G>(g, cst);
-    uint32_t X[W], R[W], T[W], RHO[W];
+    uint32_t X[W], R[W], T[W], RHO[W], SIG[W];
+    const int lane = threadIdx.x & 63;
+    const unsigned long long gm = ((1ull << G) - 1) << (lane & ~(G - 1));
+    // sigma^n mod n FIRST: nothing but the ladder's own operands is live across its product loops (rho, which the comparison
+    // needs, is derived afterwards; the modulus is read again) — the register file of the W = 36 loops has no room for bystanders
+    load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
+    stageB<G>(g, T);
+    load_value<G>(g, T, a.sigma + item * kw, kw);
+    mm<G>(g, X, T);
+    if constexpr (PAIR) powm_pair<G>(g, X, a.n_bits, cst, a.n + b * kw, role);
+    else powm<G, false>(g, X, a.n_bits, tab, cst, nullptr, a.n + b * kw);
+    load_modulus_consts<G>(g, cst);
+    stage_one<G>(g);
+    mm<G>(g, R, X);
+    normalize_exact<G>(R, g.gl);
+#pragma unroll
+    for (int k = 0; k < W; k++) SIG[k] = R[k];           // sigma^n as exact limbs of a value <= n
     // rho = (v_lo + v_hi * 2^(32 kw)) mod n with v = MGF output (kw + 8 words)
     const uint32_t* v = a.mgf + item * (uint64_t)(kw + 8);
     load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
@@ -680,27 +696,15 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
     bool is_m = true;
 #pragma unroll
     for (int k = 0; k < W; k++) is_m = is_m && (R[k] == g.N[k]);
-    const int lane = threadIdx.x & 63;
-    const unsigned long long gm = ((1ull << G) - 1) << (lane & ~(G - 1));
     if ((__ballot(is_m) & gm) == gm) {
 #pragma unroll
       for (int k = 0; k < W; k++) R[k] = 0;
     }
 #pragma unroll
     for (int k = 0; k < W; k++) RHO[k] = R[k];           // canonical rho limbs
-    // sigma^n mod n
-    load_limbs_global<G>(T, cst + CL::OFF_R2, g.gl);
-    stageB<G>(g, T);
-    load_value<G>(g, T, a.sigma + item * kw, kw);
-    mm<G>(g, X, T);
-    if constexpr (PAIR) powm_pair<G>(g, X, a.n_bits, cst, a.n + b * kw, role);
-    else powm<G, false>(g, X, a.n_bits, tab, cst, nullptr, a.n + b * kw);
-    stage_one<G>(g);
-    mm<G>(g, R, X);
-    normalize_exact<G>(R, g.gl);
     bool same = true, eqm = true;
 #pragma unroll
-    for (int k = 0; k < W; k++) { same = same && (R[k] == RHO[k]); eqm = eqm && (R[k] == g.N[k]); }
+    for (int k = 0; k < W; k++) { same = same && (SIG[k] == RHO[k]); eqm = eqm && (SIG[k] == g.N[k]); }
     // R == n means the residue 0
     const bool r_is_m = (__ballot(eqm) & gm) == gm;
     bool rho_zero = true;
