@@ -102,6 +102,9 @@ class _OracleEngine:
     def verify(self, pb, verdict):
         assert self.oracle.range_ni_verify(pb.struct(), verdict.numpy()) == 0
 
+    def correct_key_verify(self, n_bits, n, sigma, salt, verdict):
+        verdict.numpy()[:] = self.oracle.correct_key_ni_verify(n_bits, n.numpy().view(np.uint32), np.ascontiguousarray(sigma.numpy().view(np.uint32)), salt)
+
     def before_collective(self):
         pass
 
@@ -161,6 +164,73 @@ def test_bench_step_functions_world_size_2_gloo():
         assert p.exitcode == 0
     assert gathered == expected == [zkp.VERDICT_ACCEPT, zkp.VERDICT_ACCEPT, zkp.VERDICT_REJECT, zkp.VERDICT_ACCEPT]
     assert c1_ok and c2_shape == [world * B, 128, 2 * n_bits // 32]
+
+
+def _sharded_worker(rank, world, port, ret):
+    """the sharded legs of `bench.py --gpus N` (strong scaling): BASELINE configs[3] — NiCorrectKeyProof keys cut into blocks,
+    bench.make_correct_key_step — and a RangeProofNi batch of a size the world does not divide (bench.make_steps with counts:
+    configs[4]'s shape), per-rank compute by the oracle, gathered outputs against the single-process run."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    from helpers import pm, L
+    sys.path.insert(0, H.ROOT)
+    import bench
+    shard = importlib.import_module("zk-paillier_amd.shard")
+    oracle = oracle_lib.Oracle()
+    eng = _OracleEngine(oracle)
+    # configs[3]: 5 keys in all (unequal blocks 3 + 2), one tampered proof
+    keys = [H.test_key(512, tag=t) for t in range(5)]
+    n_arr = L.ints_to_limbs([k[2] for k in keys], 32)
+    sig = np.stack([L.ints_to_limbs(pm.correct_key_proof(k[0], k[1], b"KZen"), 32) for k in keys])
+    sig[3, 7, 0] ^= 1
+    lo, hi = shard.shard_range(len(keys), world, rank)
+    counts = bench.block_counts(len(keys), world)
+    vk = torch.full((hi - lo,), 9, dtype=torch.uint8)
+    step, out = bench.make_correct_key_step(eng, 1024, torch.from_numpy(n_arr[lo:hi].view(np.int32)), torch.from_numpy(np.ascontiguousarray(sig[lo:hi]).view(np.int32)),
+                                            b"KZen", vk, world, counts)
+    step()
+    ck = out["verdict"].tolist()
+    # configs[4]'s shape: 3 proofs in all (blocks 2 + 1), prove + verify with the gathers
+    n = H.test_key(512)[2]
+    cases = H.build_range_case(b"sharded-legs", [n], 1024, 3)
+    cases[2] = H.build_range_case(b"sharded-legs-bad", [n], 1024, 1, honest=False)[0]
+    pb, wt = H.fill_batch(cases, 1024, True, oracle)
+    pb, wt = pb.to("cpu"), wt.to("cpu")
+    plo, phi = shard.shard_range(3, world, rank)
+    loc, wloc = pb.slice(plo, phi), wt.slice(plo, phi)
+    v = torch.zeros(phi - plo, dtype=torch.uint8)
+    p_step, v_step, got = bench.make_steps(eng, loc, wloc, v, world, bench.block_counts(3, world))
+    p_step(); v_step()
+    if rank == 0:
+        ck_full = oracle.correct_key_ni_verify(1024, n_arr, sig, b"KZen").tolist()
+        oracle.range_ni_prove(pb.struct(), wt.struct(), None, None, None)      # (rank 0's block is already proved in place: same bytes again)
+        full = np.zeros(3, np.uint8)
+        oracle.range_ni_verify(pb.struct(), full)
+        ret.put((ck, ck_full, got["verdict"].tolist(), full.tolist(), bool(torch.equal(got["c1"], pb.c1)), list(got["c2"].shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_bench_legs_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ck, ck_full, verdicts, full, c1_ok, c2_shape = ret.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ck == ck_full == [1, 1, 1, 0, 1]
+    assert verdicts == full == [zkp.VERDICT_ACCEPT, zkp.VERDICT_ACCEPT, zkp.VERDICT_REJECT]
+    assert c1_ok and c2_shape == [3, 128, 64]
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
