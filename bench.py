@@ -769,11 +769,11 @@ def run_pmc_shape(args, ctx, synth, torch, dev, sync):
     shape = args.pmc_shape
     if shape == "tabread":
         # calibration of the HBM-side counters on the kernel's own table-read pattern: a known number of bytes (see profiles/README.md)
-        lib = importlib.import_module("zk-paillier_amd").load()
-        nbytes = torch.zeros(1, dtype=torch.int64)
-        st = lib.zkp_debug_table_read(ctx.h, 64, nbytes.data_ptr()) if hasattr(lib, "zkp_debug_table_read") else -1
-        sync()
-        print(json.dumps({"pmc_shape": shape, "status": int(st), "bytes_read": int(nbytes.item())}))
+        ctx.timing_reset(True)
+        rd = ctx.diag_table_traffic(0, 8)
+        wr = ctx.diag_table_traffic(1, 8)
+        kms, launches, _ = ctx.timing_get()
+        print(json.dumps({"pmc_shape": shape, "bytes_read_by_launch_1": rd, "bytes_written_by_launch_2": wr, "kernel": "k_table_traffic<4>", "launches": launches, "ms": kms}))
         return
     if shape in ("enc2048", "enc2048keys", "enc4096", "enc2048full"):
         nb = 4096 if shape == "enc4096" else 2048

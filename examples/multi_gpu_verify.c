@@ -4,6 +4,11 @@
  *
  *   gcc -O2 -I../include multi_gpu_verify.c -L../zk-paillier_amd -lzkp_hip -Wl,-rpath,$PWD/../zk-paillier_amd -o multi_gpu_verify
  *   ./multi_gpu_verify 0 1 2 3        # device ids, one context each (an id may repeat: "0 0" = two contexts on GPU 0)
+ *   ZKP_DEVICES=0,1,2,3,4,5,6,7 ZKP_BATCH=4096 ./multi_gpu_verify      # the same from the environment: a one-command check on an 8-GPU node
+ *
+ * Prints the block and the wall time of every device context for the prove and the verify call (zkp_multi_last_timing), then runs
+ * the SAME batch through ONE context (device of the first id) and compares ciphertexts, responses and verdicts byte for byte:
+ * exit status 0 only if they are identical, 63/64 (B-1 of B) proofs are accepted and the tampered one is rejected.
  *
  * The statements are synthetic: range = 3 * 2^254 so that T = range / 3 = 2^254 needs no division; w1 = T + u, w2 = u with
  * u < 2^200 (range_proof.rs:133-149 draws w1 from [T, 2T) and sets w2 = w1 - T), x < 2^200 < T, randomness below 2^2000 < n.
@@ -45,11 +50,24 @@ static void hex_to_limbs(const char* hex, uint32_t* out, int nlimbs) {
 }
 #define CHECK(call) do { int32_t st_ = (call); if (st_ != ZKP_OK) { fprintf(stderr, "%s -> status %d: %s\n", #call, st_, zkp_multi_last_error_string(m)); return 1; } } while (0)
 
+static void print_timing(zkp_multi* m, const int32_t* devs, const char* what) {
+  for (uint32_t i = 0; i < zkp_multi_size(m); i++) {
+    double ms = 0; uint64_t lo = 0, hi = 0;
+    if (zkp_multi_last_timing(m, i, &ms, &lo, &hi) == ZKP_OK)
+      printf("  %-6s context %u (device %d): proofs [%llu, %llu)  %.1f ms\n", what, i, devs[i], (unsigned long long)lo, (unsigned long long)hi, ms);
+  }
+}
+
 int main(int argc, char** argv) {
   int32_t devs[64]; uint32_t nd = 0;
   for (int i = 1; i < argc && nd < 64; i++) devs[nd++] = atoi(argv[i]);
+  if (!nd && getenv("ZKP_DEVICES")) {                       /* "0,1,2,3" */
+    char* list = strdup(getenv("ZKP_DEVICES"));
+    for (char* t = strtok(list, ", "); t && nd < 64; t = strtok(NULL, ", ")) devs[nd++] = atoi(t);
+    free(list);
+  }
   if (!nd) devs[nd++] = 0;
-  const uint64_t B = 64;
+  const uint64_t B = getenv("ZKP_BATCH") && atoll(getenv("ZKP_BATCH")) > 8 ? (uint64_t)atoll(getenv("ZKP_BATCH")) : 64;
   zkp_multi* m = NULL;
   if (zkp_multi_create(devs, nd, &m) != ZKP_OK) { fprintf(stderr, "zkp_multi_create failed: no gfx950 GPU (there is no CPU fallback)\n"); return 2; }
 
@@ -80,12 +98,30 @@ int main(int argc, char** argv) {
   zkp_range_ni_witness w = {x, r, w1, w2, r1, r2};
   uint8_t* status = calloc(B, 1); uint8_t* verdict = calloc(B, 1);
   CHECK(zkp_multi_range_ni_prove_batch(m, &p, &w, NULL, NULL, status));          /* RangeProofNi::prove x B, sharded by proof index */
+  print_timing(m, devs, "prove");
   rr1[(5 * EF + 0) * KW] ^= 1;                                                      /* tamper proof 5 */
   CHECK(zkp_multi_range_ni_verify_batch(m, &p, verdict));                          /* RangeProofNi::verify_self x B */
+  print_timing(m, devs, "verify");
   unsigned accepted = 0, bad_status = 0;
   for (uint64_t b = 0; b < B; b++) { accepted += verdict[b] == ZKP_VERDICT_ACCEPT; bad_status += status[b] != 0; }
   printf("contexts=%u proofs=%llu accepted=%u rejected=%llu prove_status_errors=%u verdict[5]=%u\n", zkp_multi_size(m), (unsigned long long)B, accepted,
          (unsigned long long)(B - accepted), bad_status, verdict[5]);
+
+  /* the same batch on ONE context: every byte the sharded run produced must come out again */
+  uint32_t *c1s = calloc(rows * 2 * KW, 4), *c2s = calloc(rows * 2 * KW, 4), *sw1 = calloc(rows * KW, 4), *sr1 = calloc(rows * KW, 4), *sw2 = calloc(rows * KW, 4), *sr2 = calloc(rows * KW, 4);
+  uint8_t *skind = calloc(rows, 1), *sjj = calloc(rows, 1), *sverdict = calloc(B, 1), *sstatus = calloc(B, 1);
+  zkp_range_ni_proofs ps = {N_BITS, EF, B, 0, n, range, ct, c1s, c2s, skind, sjj, sw1, sr1, sw2, sr2};
+  zkp_ctx* one = zkp_multi_ctx(m, 0);
+  int mismatches = 0;
+  if (zkp_range_ni_prove_batch(one, &ps, &w, NULL, NULL, sstatus, 0) != ZKP_OK) { fprintf(stderr, "single-context prove failed: %s\n", zkp_last_error_string(one)); return 1; }
+  sr1[(5 * EF + 0) * KW] ^= 1;
+  if (zkp_range_ni_verify_batch(one, &ps, sverdict, 0) != ZKP_OK) { fprintf(stderr, "single-context verify failed: %s\n", zkp_last_error_string(one)); return 1; }
+  mismatches += memcmp(c1, c1s, rows * 2 * KW * 4) != 0; mismatches += memcmp(c2, c2s, rows * 2 * KW * 4) != 0;
+  mismatches += memcmp(kind, skind, rows) != 0; mismatches += memcmp(jj, sjj, rows) != 0;
+  mismatches += memcmp(rw1, sw1, rows * KW * 4) != 0; mismatches += memcmp(rr1, sr1, rows * KW * 4) != 0;
+  mismatches += memcmp(rw2, sw2, rows * KW * 4) != 0; mismatches += memcmp(rr2, sr2, rows * KW * 4) != 0;
+  mismatches += memcmp(verdict, sverdict, B) != 0;
+  printf("single-context cross-check: %s\n", mismatches ? "MISMATCH" : "identical (c1, c2, responses, verdicts)");
   zkp_multi_destroy(m);
-  return (accepted == B - 1 && verdict[5] == ZKP_VERDICT_REJECT && !bad_status) ? 0 : 1;
+  return (accepted == B - 1 && verdict[5] == ZKP_VERDICT_REJECT && !bad_status && !mismatches) ? 0 : 1;
 }

@@ -96,6 +96,10 @@ int32_t zkp_ctx_release_staging(zkp_ctx* ctx);
  * number of modular exponentiations those launches performed. */
 int32_t zkp_timing_reset(zkp_ctx* ctx, int32_t enable);
 int32_t zkp_timing_get(zkp_ctx* ctx, double* out_ms, uint64_t* out_launches, uint64_t* out_modexps);
+/* Diagnostic: moves a KNOWN number of bytes in the access pattern of the ladders' window tables — every lane of the resident
+ * grid reads (mode 0) or writes (mode 1) its block of each entry of its table slot, `passes` times — so that the HBM-side PMC
+ * counters behind the roofline's `traffic` figure can be calibrated (profiles/collect_pmc.sh).  out_bytes = bytes moved. */
+int32_t zkp_diag_table_traffic(zkp_ctx* ctx, int32_t mode, int32_t passes, uint64_t* out_bytes);
 
 /* ------------------------------------------------------------------ L1 primitives
  * out[i] = base[i]^exp[i] mod mod[i].
@@ -347,6 +351,18 @@ int32_t zkp_json_encrypted_pairs_batch(zkp_ctx* ctx, const char* text, const uin
                                        const zkp_range_ni_proofs* p, uint8_t* out_status, uint32_t flags);
 int32_t zkp_json_range_proof_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len,
                                    const zkp_range_ni_proofs* p, uint8_t* out_status, uint32_t flags);
+/* Whole RangeProofNi documents (range_proof_ni.rs:36-44): {"ek":{"n":..},"range":..,"ciphertext":..,"encrypted_pairs":{..},"proof":[..],
+ * "error_factor":N} -> every field of the batch.  encrypted_pairs / proof as above.  ek, range and ciphertext are UN-annotated
+ * in the reference (EncryptionKey of kzen-paillier, bare curv BigInt): their text form is fixed by crates outside the tree, so
+ * `bigint_encoding` names it (a sample written by a Rust build decides, tools/reference_vectors "serde" section).  error_factor
+ * must equal p->error_factor.  p->n_stride = n_bits/32: one key per proof; 0: one shared key, a document under another key is
+ * malformed (RangeProofNi::verify asserts equality, :86).  Writes p->n, p->range and p->ciphertext too (inputs of the other entry
+ * points, hence const in the struct).  HOST pointers only (flags must be 0). */
+#define ZKP_BIGINT_DEC 0u     /* "1234": decimal string (serialize::bigint, serialize.rs:8-33) */
+#define ZKP_BIGINT_HEX 1u     /* "04d2": hex string of the big-endian magnitude */
+#define ZKP_BIGINT_BYTES 2u   /* [4,210]: array of big-endian byte values */
+int32_t zkp_json_range_proof_ni_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len, uint32_t bigint_encoding,
+                                      const zkp_range_ni_proofs* p, uint8_t* out_status, uint32_t flags);
 /* {"sigma_vec":["..", x11]} -> sigma [B][11][n_bits/32] */
 int32_t zkp_json_correct_key_proof_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len, uint32_t n_bits,
                                          uint64_t batch, uint32_t* out_sigma, uint8_t* out_status, uint32_t flags);
@@ -365,6 +381,9 @@ int32_t zkp_multi_destroy(zkp_multi* m);
 uint32_t zkp_multi_size(zkp_multi* m);
 zkp_ctx* zkp_multi_ctx(zkp_multi* m, uint32_t i);            /* context i (owned by m), e.g. for zkp_timing_* */
 const char* zkp_multi_last_error_string(zkp_multi* m);
+/* the most recent batch call, per device context i: the block [lo, hi) of items it was given and the wall time of its share
+ * (staging, launches and the D2H of its output slab), in milliseconds */
+int32_t zkp_multi_last_timing(zkp_multi* m, uint32_t i, double* out_ms, uint64_t* out_lo, uint64_t* out_hi);
 int32_t zkp_multi_range_ni_prove_batch(zkp_multi* m, const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w,
                                        uint8_t* out_e, uint8_t* out_e_len, uint8_t* out_status);
 int32_t zkp_multi_range_ni_verify_batch(zkp_multi* m, const zkp_range_ni_proofs* p, uint8_t* out_verdict);

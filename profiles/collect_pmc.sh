@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes of ONE dominant-kernel shape (run on the GPU box from the repo root):
-#     bash profiles/collect_pmc.sh <shape> <outdir>        shape = enc2048 | enc4096 | ck2048  (bench.py --pmc-shape)
+#     bash profiles/collect_pmc.sh <shape> <outdir>        shape = enc2048 | enc2048full | enc2048keys | enc4096 | ck2048 | tabread  (bench.py --pmc-shape)
+# tabread = the calibration launches (a known number of bytes read, then written, in the table access pattern): aggregate_pmc.py --calibrate
 # Counter sets are collected in separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains besides
 # the kernel trace are combined with --pmc).  Aggregate with profiles/aggregate_pmc.py.
 set -u

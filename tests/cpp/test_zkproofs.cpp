@@ -103,10 +103,7 @@ static void test_batch_survives_crafted_proofs() {   // over-wide prover-chosen 
     Response& m = proofs[2].proof.responses[first(proofs[2], Response::Mask)];
     m.masked_r = m.masked_r + ek.n * BigInt::pow2(80);
   }
-  {  // 3: c_j[i] + n^2 * 2^100 on a Mask row: only the product mod n^2 is used (:324-328) -> still Ok; ciphertext likewise
-    const size_t i = first(proofs[3], Response::Mask);
-    auto& cj = proofs[3].proof.responses[i].j == 1 ? proofs[3].encrypted_pairs.c1[i] : proofs[3].encrypted_pairs.c2[i];
-    cj = cj + ek.nn * BigInt::pow2(100);
+  {  // 3: ciphertext + n^2 * 2^4200: only its product mod n^2 is used (:324-328) and it is not hashed -> still Ok
     proofs[3].ciphertext = proofs[3].ciphertext + ek.nn * wider;
   }
   {  // 4: c1[i] + n^2 on an Open row: compared unreduced (:293-298) -> Err;  w1 over-wide would also fail the range flag
@@ -126,6 +123,47 @@ static void test_batch_survives_crafted_proofs() {   // over-wide prover-chosen 
   bool threw = false;
   try { (void)res[5].is_ok(); } catch (const Panic&) { threw = true; }
   ASSERT(threw);
+}
+
+// c_j[i] + k n^2 on a Mask row.  The row equation only sees the product mod n^2 (range_proof.rs:324-328), but the Fiat-Shamir
+// challenge is hashed over the RAW pairs (range_proof_ni.rs:110-113, utils.rs:9-22): (a) added AFTER the proof was made the
+// challenge changes and the reference rejects; (b) a prover who hashes the raw value itself gets a proof the reference accepts.
+static void test_overwide_pair_on_a_mask_row_follows_the_raw_transcript() {
+  auto [ek, dk] = test_keypair().keys();
+  const BigInt range = BigInt::sample(RANGE_BITS);
+  const BigInt r = BigInt::sample_below(ek.n), x = BigInt::sample_below(range.div_floor(BigInt(3)));
+  const BigInt cx = Paillier::encrypt_with_chosen_randomness(ek, x, r);
+  const BigInt bump = ek.nn * BigInt::pow2(100);
+  {  // (a)
+    RangeProofNi p = RangeProofNi::prove(ek, range, cx, x, r);
+    size_t i = 0;
+    while (p.proof.responses[i].kind != Response::Mask) i++;
+    auto& cj = p.proof.responses[i].j == 1 ? p.encrypted_pairs.c1[i] : p.encrypted_pairs.c2[i];
+    cj = cj + bump;
+    ASSERT(RangeProofNi::verify_batch(ek, {&p})[0].is_err());
+  }
+  bool built = false;
+  for (size_t i = 0; i < 16 && !built; i++) {   // (b): find a row that the challenge over the bumped transcript makes a Mask row
+    auto [pairs, data] = RangeProof::generate_encrypted_pairs(ek, range, RangeProofNi::SECURITY_PARAMETER);
+    pairs.c1[i] = pairs.c1[i] + bump; pairs.c2[i] = pairs.c2[i] + bump;
+    detail::Sha256 sh;
+    sh.update(ek.n);
+    for (auto& c : pairs.c1) sh.update(c);
+    for (auto& c : pairs.c2) sh.update(c);
+    ChallengeBits e; e.bytes = sh.finish().to_bytes();
+    if (e.bytes.size() != 32 || !((e.bytes[i / 8] >> (7 - i % 8)) & 1)) continue;   // bit i clear: row i would be an Open row
+    RangeProofNi p;
+    p.ek = ek; p.range = range; p.ciphertext = cx; p.encrypted_pairs = pairs; p.error_factor = RangeProofNi::SECURITY_PARAMETER;
+    p.proof = RangeProof::generate_proof(ek, x, r, e, range, data, RangeProofNi::SECURITY_PARAMETER);
+    ASSERT(p.proof.responses[i].kind == Response::Mask);
+    ASSERT(RangeProofNi::verify_batch(ek, {&p})[0].is_ok());
+    // ... and next to ordinary proofs in one batch
+    RangeProofNi q = RangeProofNi::prove(ek, range, cx, x, r);
+    auto res = RangeProofNi::verify_batch(ek, {&q, &p, &q});
+    ASSERT(res[0].is_ok() && res[1].is_ok() && res[2].is_ok());
+    built = true;
+  }
+  ASSERT(built);
 }
 
 // ---- correct_key_ni.rs tests (the reference draws a fresh key with Paillier::keypair(); key generation is
@@ -374,6 +412,7 @@ int main() {
   run("range_proof_ni::verify asserts ek/ciphertext", test_verify_asserts_statement, true);
   run("range_proof_ni::batch round trip", test_batch_round_trip);
   run("range_proof_ni::batch survives crafted proofs", test_batch_survives_crafted_proofs);
+  run("range_proof_ni::over-wide pair on a mask row follows the raw transcript", test_overwide_pair_on_a_mask_row_follows_the_raw_transcript);
   run("correct_key_ni::test_correct_zk_proof_no_salt_str", test_correct_zk_proof_no_salt_str);
   run("correct_key_ni::test_correct_zk_proof_with_salt_str", test_correct_zk_proof_with_salt_str);
   run("wi_dlog_proof::test_correct_dlog_proof", test_correct_dlog_proof);

@@ -91,3 +91,26 @@ def test_c_example_prove_and_verify_over_three_contexts():
     out = subprocess.run([_build_c_example(), "0", "0", "0"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "contexts=3 proofs=64 accepted=63 rejected=1 prove_status_errors=0 verdict[5]=0" in out.stdout
+    assert "single-context cross-check: identical" in out.stdout
+    assert out.stdout.count("verify context") == 3 and "proofs [0, 22)" in out.stdout          # per-device blocks and timings are printed
+
+
+def test_c_example_takes_devices_and_batch_from_the_environment():
+    import os
+    import subprocess
+    env = dict(os.environ, ZKP_DEVICES="0,0", ZKP_BATCH="24")
+    out = subprocess.run([_build_c_example()], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "contexts=2 proofs=24 accepted=23 rejected=1" in out.stdout and "proofs [12, 24)" in out.stdout
+
+
+def test_multi_last_timing_reports_blocks(oracle):
+    keys = [H.test_key(1024, tag=t) for t in range(5)]
+    n_arr = L.ints_to_limbs([k[2] for k in keys], 32)
+    sig = np.stack([L.ints_to_limbs(pm.correct_key_proof(k[0], k[1], b"KZen"), 32) for k in keys])
+    m = zkp.MultiContext([0, 0])
+    v = np.full(len(keys), 9, np.uint8)
+    m.correct_key_ni_verify(1024, len(keys), n_arr, sig, b"KZen", v)
+    t = m.last_timing()
+    assert [(lo, hi) for _, lo, hi in t] == [(0, 3), (3, 5)] and all(ms > 0 for ms, _, _ in t)
+    m.close()

@@ -11,7 +11,12 @@ What the checks establish once a real file is present:
   range_ni section                    -> Open rows are Enc known answers; the Open/Mask pattern is the FS challenge bit string
                                          (compute_digest + to_bytes + MSB-first order, N2); verdicts; serde wire format
   correct_key_ni section              -> extract_nroot's residue (sigma is deterministic), the MGF, the verdict
-  dlog section                        -> verify conventions."""
+  dlog section                        -> verify conventions
+  serde section (round 3)             -> the text form of the UN-annotated types (bare curv BigInt, kzen-paillier EncryptionKey,
+                                         DLogStatement, CompositeDLogProof): the samples decide which of the three encodings the
+                                         whole-document reader (zkp_json_range_proof_ni_batch) is given; the "raw" RangeProofNi
+                                         documents then go through it and are verified.
+A section of a present file that no check reads is a FAILURE, not a skip."""
 import json
 import os
 
@@ -64,7 +69,58 @@ def simulated_doc():
     ni = pow(pow(g, -1, n), s, n)
     x, y = pm.dlog_prove(n, g, ni, s, d.bits(512))
     doc["dlog"] = [{"N": dec(n), "g": dec(g), "ni": dec(ni), "secret": dec(s), "x": dec(x), "y": dec(y), "verify": "ok"}]
+    # the "serde" section of round 3: the text forms of the UN-annotated types, with the value next to each sample.  The simulated
+    # document writes them as hex strings of the big-endian magnitude — one of the three forms the reader knows; a real file decides.
+    hx = lambda v: v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big").hex()
+    doc["serde"] = {"bigint_samples": [{"x": dec(v), "json": hx(v)} for v in (0, 255, 256, n)],
+                    "encryption_key": {"n": dec(n), "json": {"n": hx(n)}},
+                    "dlog_statement": {"N": dec(n), "g": dec(g), "ni": dec(ni), "json": {"N": hx(n), "g": hx(g), "ni": hx(ni)}},
+                    "dlog_proof": {"x": dec(x), "y": dec(y), "json": {"x": hx(x), "y": hx(y)}}}
+    for c in doc["range_ni"]:
+        c["raw"] = {"ek": {"n": hx(n)}, "range": hx(D(c["range"])), "ciphertext": hx(D(c["ciphertext"])), "encrypted_pairs": c["encrypted_pairs"],
+                    "proof": c["proof"], "error_factor": c["error_factor"]}
     return doc
+
+
+KNOWN_SECTIONS = {"generator", "to_bytes", "compute_digest", "enc", "range_ni", "correct_key_ni", "dlog", "serde"}
+
+
+def bigint_encoding_of(doc):
+    """which text form the un-annotated BigInt takes in THIS file: decided by the samples whose values are known"""
+    def forms(v):
+        b = v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big")
+        return {zkp.BIGINT_DEC: str(v), zkp.BIGINT_HEX: b.hex(), zkp.BIGINT_BYTES: list(b)}
+    cands = set(forms(0))
+    for smp in doc["serde"]["bigint_samples"]:
+        j = smp["json"]
+        cands &= {e for e, f in forms(D(smp["x"])).items() if (f == j or (isinstance(j, str) and isinstance(f, str) and f.lstrip("0") == j.lower().lstrip("0") and e != zkp.BIGINT_DEC))}
+    assert len(cands) == 1, f"the BigInt samples fit {sorted(cands)} of the known encodings (0 dec, 1 hex, 2 bytes): teach the reader the new form"
+    return cands.pop()
+
+
+def decode_bigint(j, enc):
+    if enc == zkp.BIGINT_DEC:
+        return int(j, 10)
+    if enc == zkp.BIGINT_HEX:
+        return int(j, 16) if j else 0
+    return int.from_bytes(bytes(j), "big")
+
+
+def check_serde_section(doc):
+    """every sample of the un-annotated types decodes to the value printed next to it; no section of the file goes unread"""
+    unknown = set(doc) - KNOWN_SECTIONS
+    assert not unknown, f"sections {sorted(unknown)} of the reference file are not consumed by any check"
+    if "serde" not in doc:
+        return None
+    enc = bigint_encoding_of(doc)
+    sd = doc["serde"]
+    assert set(sd) <= {"bigint_samples", "encryption_key", "dlog_statement", "dlog_proof"}, "unread part of the serde section"
+    ek = sd["encryption_key"]
+    assert decode_bigint(ek["json"]["n"], enc) == D(ek["n"])
+    for part, fields in (("dlog_statement", ("N", "g", "ni")), ("dlog_proof", ("x", "y"))):
+        for f in fields:
+            assert decode_bigint(sd[part]["json"][f], enc) == D(sd[part][f]), (part, f)
+    return enc
 
 
 def width_for(n):
@@ -102,6 +158,13 @@ def batch_from_case(c):
 
 def check_doc_cpu(doc, oracle):
     """every section against the oracle (C/GMP) and the python model"""
+    enc = check_serde_section(doc)
+    for c in doc["range_ni"]:
+        if "raw" in c and enc is not None:                 # the whole-document form agrees with the fields printed beside it
+            raw = c["raw"]
+            assert decode_bigint(raw["ek"]["n"], enc) == D(c["n"]) and decode_bigint(raw["range"], enc) == D(c["range"])
+            assert decode_bigint(raw["ciphertext"], enc) == D(c["ciphertext"])
+            assert raw["encrypted_pairs"] == c["encrypted_pairs"] and raw["proof"] == c["proof"] and raw["error_factor"] == c["error_factor"]
     for t in doc["to_bytes"]:
         assert pm.to_bytes(D(t["x"])).hex() == t["hex"]                                   # N1
     for t in doc["compute_digest"]:
@@ -146,6 +209,23 @@ def check_doc_cpu(doc, oracle):
 
 def check_doc_gpu(doc, ctx):
     """the same sections through the C ABI on the GPU, incl. the serde wire format of the transcripts"""
+    enc = check_serde_section(doc)
+    if enc is not None:
+        # the WHOLE RangeProofNi documents, as the crate wrote them, through zkp_json_range_proof_ni_batch, then verified
+        raws = [c for c in doc["range_ni"] if "raw" in c]
+        if raws:
+            nb = width_for(D(raws[0]["n"]))
+            pw = zkp.RangeBatch(nb, len(raws), int(raws[0]["error_factor"]), shared_key=False)
+            st = np.full(len(raws), 9, np.uint8)
+            ctx.json_range_proof_ni([json.dumps(c["raw"], separators=(",", ":")).encode() for c in raws], enc, pw.struct(), st)
+            assert not st.any()
+            v = np.full(len(raws), 9, np.uint8)
+            ctx.range_ni_verify(pw.struct(), v, device=False)
+            assert [int(x) == zkp.VERDICT_ACCEPT for x in v] == [c["verify_self"] == "ok" for c in raws]
+            for b, c in enumerate(raws):
+                ref, _ = batch_from_case(c)
+                for f in ("range", "ciphertext", "c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2"):
+                    assert np.array_equal(getattr(pw, f)[b], getattr(ref, f)[0]), f
     n = D(doc["enc"]["n"]); nb = width_for(n); kw = nb // 32
     items = doc["enc"]["items"]
     out = np.zeros((len(items), 2 * kw), np.uint32)

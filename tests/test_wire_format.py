@@ -224,3 +224,72 @@ def test_gpu_json_reader_is_as_tolerant_as_serde(ctx):
         assert [L.limbs_to_int(x) for x in pr.resp_w1[b]] == [1, 5] and [L.limbs_to_int(x) for x in pr.resp_r1[b]] == [2, 6]
         assert [L.limbs_to_int(x) for x in pr.resp_w2[b]] == [3, 0] and [L.limbs_to_int(x) for x in pr.resp_r2[b]] == [4, 0]
     assert list(pr.resp_j[0]) == [0, 2] and list(pr.resp_j[4]) == [0, 0]
+
+
+def _enc_bigint(v, enc):
+    """the three candidate text forms of an un-annotated curv BigInt (include/zkp_hip.h: ZKP_BIGINT_*)"""
+    if enc == zkp.BIGINT_DEC:
+        return str(v)
+    b = v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big")
+    return b.hex() if enc == zkp.BIGINT_HEX else list(b)
+
+
+def range_ni_document(case, pr, enc, ef, pretty=False, extra=False):
+    """serde_json text of a whole RangeProofNi (range_proof_ni.rs:36-44): ek / range / ciphertext in the encoding under test,
+    encrypted_pairs / proof in the crate's decimal-string format (serialize.rs)"""
+    resp = []
+    for r in pr["responses"]:
+        if r[0] == "open":
+            resp.append({"Open": {"w1": str(r[1]), "r1": str(r[2]), "w2": str(r[3]), "r2": str(r[4])}})
+        else:
+            resp.append({"Mask": {"j": r[1], "masked_x": str(r[2]), "masked_r": str(r[3])}})
+    ek = {"n": _enc_bigint(case["n"], enc)}
+    if extra:
+        ek["nn"] = _enc_bigint(case["n"] ** 2, enc)           # a fuller EncryptionKey: unknown fields are skipped
+    doc = {"ek": ek, "range": _enc_bigint(case["range"], enc), "ciphertext": _enc_bigint(pr["ciphertext"], enc),
+           "encrypted_pairs": {"c1": [str(v) for v in pr["c1"]], "c2": [str(v) for v in pr["c2"]]}, "proof": resp, "error_factor": ef}
+    return json.dumps(doc, indent=2 if pretty else None, separators=None if pretty else (",", ":")).encode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("enc", [zkp.BIGINT_DEC, zkp.BIGINT_HEX, zkp.BIGINT_BYTES], ids=["dec", "hex", "bytes"])
+def test_gpu_whole_range_proof_ni_documents(ctx, oracle, enc):
+    """whole RangeProofNi documents -> the SoA batch -> verify: the three candidate encodings of the un-annotated fields, per-proof
+    and shared keys, and the documents serde would refuse"""
+    n_bits, ef, kw = 1024, 128, 32
+    keys = [H.test_key(1024, tag=t)[2] for t in range(2)]
+    docs, cases = [], []
+    for b in range(3):
+        c = H.build_range_case(b"whole-doc-%d" % b, [keys[b % 2]], n_bits, 1, honest=(b != 2))[0]
+        ct = pm.enc(c["n"], c["x"], c["r"])
+        pr = pm.range_ni_prove(c["n"], c["range"], ct, c["x"], c["r"], c["w1"], c["w2"], c["r1"], c["r2"])
+        pr["ciphertext"] = ct
+        cases.append((c, pr))
+        docs.append(range_ni_document(c, pr, enc, ef, pretty=(b == 1), extra=(b == 0)))
+    good = docs[0]
+    bad = [good.replace(b'"error_factor":128', b'"error_factor":40'), good.replace(b'"range"', b'"rnge"'), good.replace(b'"ek"', b'"ek":{"n":"1"},"ek"', 1),
+           good[:-1], good.replace(b'"ciphertext":', b'"ciphertext":null,"x":', 1)]
+    all_docs = docs + bad
+    B = len(all_docs)
+    pg = zkp.RangeBatch(n_bits, B, ef, shared_key=False)
+    st = np.full(B, 9, np.uint8)
+    ctx.json_range_proof_ni(all_docs, enc, pg.struct(), st)
+    assert list(st) == [0, 0, 0] + [zkp.VERDICT_MALFORMED] * len(bad)
+    for b, (c, pr) in enumerate(cases):
+        assert L.limbs_to_int(pg.n[b]) == c["n"] and L.limbs_to_int(pg.range[b]) == c["range"] and L.limbs_to_int(pg.ciphertext[b]) == pr["ciphertext"]
+        assert [L.limbs_to_int(x) for x in pg.c1[b]] == pr["c1"] and [L.limbs_to_int(x) for x in pg.c2[b]] == pr["c2"]
+        assert H.responses_from_batch(pg, b) == pr["responses"]
+    assert not pg.range[3:].any() and not pg.c1[3:].any()
+    v = np.full(3, 9, np.uint8)
+    ctx.range_ni_verify(pg.slice(0, 3).struct(), v, device=False)
+    assert list(v) == [zkp.VERDICT_ACCEPT, zkp.VERDICT_ACCEPT, zkp.VERDICT_REJECT]
+    # one shared key: the document under the other key is what RangeProofNi::verify's assert_eq!(ek) panics on
+    ps = zkp.RangeBatch(n_bits, 3, ef, shared_key=True)
+    st = np.full(3, 9, np.uint8)
+    ctx.json_range_proof_ni(docs, enc, ps.struct(), st)
+    assert list(st) == [0, zkp.VERDICT_MALFORMED, 0] and L.limbs_to_int(ps.n[0]) == keys[0]
+    # a value wider than the field, in every encoding
+    wide = dict(cases[0][0]); wide["range"] = 1 << 1030
+    st = np.full(1, 9, np.uint8)
+    ctx.json_range_proof_ni([range_ni_document(wide, cases[0][1], enc, ef)], enc, zkp.RangeBatch(n_bits, 1, ef, shared_key=False).struct(), st)
+    assert list(st) == [zkp.VERDICT_MALFORMED]

@@ -16,7 +16,9 @@
 //!   "range_ni": [{"n","range","ciphertext","x","r","honest", "encrypted_pairs": <serde>, "proof": <serde>,
 //!                 "error_factor", "verify_self": "ok"|"err", "raw": <serde_json of the whole RangeProofNi>}],
 //!   "correct_key_ni": [{"p","q","n","salt_hex","sigma_vec":[..],"verify":"ok"|"err"}],
-//!   "dlog": [{"N","g","ni","secret","x","y","verify":"ok"|"err"}] }
+//!   "dlog": [{"N","g","ni","secret","x","y","verify":"ok"|"err"}],
+//!   "serde": {"bigint_samples":[{"x","json":<serde of a bare BigInt>}], "encryption_key":{"n","json":<serde of EncryptionKey>},
+//!             "dlog_statement":{"N","g","ni","json"}, "dlog_proof":{"x","y","json"}} }
 use std::env;
 use std::fs;
 
@@ -134,10 +136,32 @@ fn main() {
         dlog.push(json!({"N": dec(&st.N), "g": dec(&st.g), "ni": dec(&st.ni), "secret": dec(&s), "x": dec(&proof.x), "y": dec(&proof.y), "verify": v}));
     }
 
+    // Text forms of the UN-annotated types (no #[serde(with = ...)] in the crate: range_proof_ni.rs:36-44 `ek`, `range`,
+    // `ciphertext`; wi_dlog_proof.rs:32-43): whatever curv's BigInt and kzen-paillier's EncryptionKey serialize as, with the value
+    // in decimal next to every sample so that a reader can tell the encodings apart.
+    let samples: Vec<Value> = [BigInt::zero(), BigInt::from(255), BigInt::from(256), ek.n.clone()]
+        .iter()
+        .map(|x| json!({"x": dec(x), "json": serde_json::to_value(x).unwrap()}))
+        .collect();
+    let serde_section = {
+        let n_tilde = ek.n.clone();
+        let h1 = BigInt::sample_below(&(&n_tilde - &BigInt::one()));
+        let s = BigInt::sample(256);
+        let ni = BigInt::mod_pow(&BigInt::mod_inv(&h1, &n_tilde).unwrap(), &s, &n_tilde);
+        let st = DLogStatement { N: n_tilde, g: h1, ni };
+        let pr = CompositeDLogProof::prove(&st, &s);
+        json!({
+            "bigint_samples": samples,
+            "encryption_key": {"n": dec(&ek.n), "json": serde_json::to_value(&ek).unwrap()},
+            "dlog_statement": {"N": dec(&st.N), "g": dec(&st.g), "ni": dec(&st.ni), "json": serde_json::to_value(&st).unwrap()},
+            "dlog_proof": {"x": dec(&pr.x), "y": dec(&pr.y), "json": serde_json::to_value(&pr).unwrap()},
+        })
+    };
+
     let doc = json!({
         "generator": "tools/reference_vectors (zk-paillier 0.4.4 + curv-kzen 0.10 / rust-gmp-kzen + kzen-paillier 0.4.3)",
         "to_bytes": to_bytes, "compute_digest": digests, "enc": {"n": dec(&ek.n), "items": enc_items},
-        "range_ni": range_ni, "correct_key_ni": ck, "dlog": dlog,
+        "range_ni": range_ni, "correct_key_ni": ck, "dlog": dlog, "serde": serde_section,
     });
     fs::write(&out_path, serde_json::to_string(&doc).unwrap()).unwrap();
     println!("wrote {}", out_path);

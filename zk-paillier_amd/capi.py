@@ -51,6 +51,7 @@ EXPORTS = {
     "zkp_ctx_release_staging": (C.c_int32, [C.c_void_p]),
     "zkp_timing_reset": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_timing_get": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "zkp_diag_table_traffic": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     "zkp_modexp_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                      C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
     "zkp_modmul_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -77,6 +78,7 @@ EXPORTS = {
     "zkp_limbs_to_decimal_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "zkp_json_encrypted_pairs_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_uint32]),
     "zkp_json_range_proof_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p, C.c_uint32]),
+    "zkp_json_range_proof_ni_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(RangeNiProofs), C.c_void_p, C.c_uint32]),
     "zkp_json_correct_key_proof_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]),
     "zkp_correct_key_ni_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
@@ -99,6 +101,7 @@ EXPORTS = {
     "zkp_multi_size": (C.c_uint32, [C.c_void_p]),
     "zkp_multi_ctx": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "zkp_multi_last_error_string": (C.c_char_p, [C.c_void_p]),
+    "zkp_multi_last_timing": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "zkp_ctx_create_on_stream": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "zkp_ctx_set_geometry": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_ctx_last_geometry": (C.c_int32, [C.c_void_p]),
@@ -141,6 +144,7 @@ class DecItem(C.Structure):
 
 
 DEC_OK, DEC_INVALID, DEC_NEGATIVE, DEC_OVERFLOW = 0, 1, 2, 3
+BIGINT_DEC, BIGINT_HEX, BIGINT_BYTES = 0, 1, 2
 
 
 class ZkpError(RuntimeError):
@@ -186,6 +190,15 @@ class MultiContext:
 
     def size(self):
         return self.lib.zkp_multi_size(self.h)
+
+    def last_timing(self):
+        """[(ms, lo, hi)] per device context for the most recent batch call"""
+        out = []
+        for i in range(self.size()):
+            ms, lo, hi = C.c_double(), C.c_uint64(), C.c_uint64()
+            self.check(self.lib.zkp_multi_last_timing(self.h, i, C.byref(ms), C.byref(lo), C.byref(hi)))
+            out.append((ms.value, lo.value, hi.value))
+        return out
 
     def range_ni_prove(self, proofs, wit, out_e=None, out_e_len=None, out_status=None):
         self.check(self.lib.zkp_multi_range_ni_prove_batch(self.h, C.byref(proofs), C.byref(wit), ptr(out_e), ptr(out_e_len), ptr(out_status)))
@@ -251,6 +264,12 @@ class Context:
         ms, launches, modexps = C.c_double(), C.c_uint64(), C.c_uint64()
         self.check(self.lib.zkp_timing_get(self.h, C.byref(ms), C.byref(launches), C.byref(modexps)))
         return ms.value, launches.value, modexps.value
+
+    def diag_table_traffic(self, mode: int, passes: int) -> int:
+        """a known amount of window-table traffic (reads: mode 0, writes: mode 1) for PMC calibration -> bytes moved"""
+        n = C.c_uint64()
+        self.check(self.lib.zkp_diag_table_traffic(self.h, mode, passes, C.byref(n)))
+        return n.value
 
     # ---- L1 primitives (buffers: numpy arrays = host pointers, torch cuda tensors = device pointers)
     @staticmethod
@@ -400,6 +419,12 @@ class Context:
         buf, off, ln = self._json_docs(docs)
         self.check(self.lib.zkp_json_range_proof_batch(self.h, C.cast(buf, C.c_void_p), ptr(off), ptr(ln), C.byref(proofs), ptr(out_status),
                                                        ZKP_F_DEVICE_PTRS if device else 0))
+
+    def json_range_proof_ni(self, docs, bigint_encoding: int, proofs, out_status):
+        """whole RangeProofNi documents -> every field of the (host) batch; bigint_encoding: BIGINT_DEC / BIGINT_HEX / BIGINT_BYTES
+        for the un-annotated ek.n, range, ciphertext"""
+        buf, off, ln = self._json_docs(docs)
+        self.check(self.lib.zkp_json_range_proof_ni_batch(self.h, C.cast(buf, C.c_void_p), ptr(off), ptr(ln), bigint_encoding, C.byref(proofs), ptr(out_status), 0))
 
     def json_correct_key_proof(self, docs, n_bits, out_sigma, out_status):
         buf, off, ln = self._json_docs(docs)

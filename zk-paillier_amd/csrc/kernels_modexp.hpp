@@ -8,8 +8,21 @@
 
 namespace zkp {
 
-constexpr int WIN = 5;                 // fixed window width (table of 32 Montgomery powers in HBM/L2)
-constexpr int TAB = 1 << WIN;
+// window widths (compile-time; the defaults are the measured optimum, -DZKP_WIN / -DZKP_SWIN build the table-residency
+// experiments of DESIGN.md §8): fixed windows of WIN bits over all 2^WIN powers (per-item exponents), sliding windows of up
+// to SWIN bits over the 2^(SWIN-1) odd powers (one exponent per launch; the schedule byte carries the table index in 5 bits)
+#ifndef ZKP_WIN
+#define ZKP_WIN 5
+#endif
+#ifndef ZKP_SWIN
+#define ZKP_SWIN 6
+#endif
+constexpr int WIN = ZKP_WIN;           // fixed window width
+constexpr int SWIN = ZKP_SWIN;         // widest sliding window
+constexpr int TABF = 1 << WIN;         // table entries of the fixed-window ladder
+constexpr int TABS = 1 << (SWIN - 1);  // ... of the sliding-window ladder
+constexpr int TAB = TABF > TABS ? TABF : TABS;   // entries per table slot in HBM (Montgomery powers of one exponentiation in flight)
+static_assert(TABS <= 32 && WIN >= 2 && WIN <= 7, "window widths");
 
 // ---- per-modulus constants in global memory (uint32 words):
 //   N29[L] | R2[L] | R1[L] | NR[L] | MT[L] | n1[12] | status[4]
@@ -170,6 +183,9 @@ template <int G, bool SAFE, bool TWO = false, class LL> __device__ __forceinline
 #ifndef ZKP_KILL_LIVE
 #define ZKP_KILL_LIVE 1
 #endif
+#ifndef ZKP_SQR_OWN_PATH
+#define ZKP_SQR_OWN_PATH 1
+#endif
 template <bool SAFE, bool TWO> constexpr bool ladder_squares() { return ZKP_SQR && !SAFE && !TWO; }
 template <int G, class LL> __device__ __forceinline__ void msq_ip(const Grp<G, LL>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
   montsqr<G>(X, g.B(), NT, g.gl);
@@ -222,9 +238,9 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
     const int bit = wi * WIN;
     const int w0 = bit >> 5, off = bit & 31;
     const uint64_t x = (uint64_t)lw[w0] | ((uint64_t)lw[w0 + 1] << 32);
-    return (int)((x >> off) & (TAB - 1));
+    return (int)((x >> off) & (TABF - 1));
   };
-  constexpr int TROUNDS = TAB - 2;
+  constexpr int TROUNDS = TABF - 2;
   // ONE counter: c < 0 counts the table rounds up to zero, then c counts the remaining products of the main part down to zero
   // (window w = (c - 1) / (WIN + 1) from the top one down, the table product when (c - 1) % (WIN + 1) == 0).
   // the table stores of this lane are re-read by this lane only: program order suffices
@@ -262,7 +278,6 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
 //       0x40|e   X = tab[e] ; X = X * B ; B = X        (multiply the running value, still staged, by X0^(2e+1))
 //       0xFE     exponent is zero: X = R1              0xFF  end
 //     ~ t + t/7 + 33 products.
-constexpr int SWIN = 6;
 constexpr uint8_t OP_END = 0xFF, OP_ZERO = 0xFE, OP_FIRST = 0x80, OP_MUL = 0x40, OP_TAB = 0x20, OP_SQ0 = 0x60;
 constexpr int SCHED_BYTES_PER_EXP_BIT = 2, SCHED_EXTRA_BYTES = 128;
 
@@ -273,7 +288,7 @@ __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int e
   while (i >= 0 && !bit(i)) i--;
   if (i < 0) { ops[0] = OP_ZERO; ops[1] = OP_END; return; }
   ops[n++] = OP_SQ0;
-  for (int e = 1; e < TAB; e++) ops[n++] = (uint8_t)(OP_TAB | e);
+  for (int e = 1; e < TABS; e++) ops[n++] = (uint8_t)(OP_TAB | e);
   bool started = false;
   while (i >= 0) {
     if (!bit(i)) { ops[n++] = 0; i--; continue; }
@@ -295,7 +310,6 @@ template <int G, bool SAFE, bool TWO = false, class LL>
 __device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[W], const uint8_t* __restrict__ ops, uint32_t* tab, const uint32_t* cst) {
   using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
-  static_assert((1 << (SWIN - 1)) == TAB, "table size");
   uint32_t NT[W];
   load_limbs_global<G>(NT, cst + (TWO ? CL::OFF_MT2 : CL::OFF_MT), g.gl);
   int op = __builtin_amdgcn_readfirstlane((int)ops[0]);
@@ -310,10 +324,21 @@ __device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[
   for (int i = 0;; i++) {
     op = __builtin_amdgcn_readfirstlane((int)ops[i]);
     if (op == OP_END) break;
-    const int type = op >> 5, e = op & (TAB - 1);
+#if ZKP_SQR_OWN_PATH
+    if constexpr (ladder_squares<SAFE, TWO>()) {
+      // the squarings (6 of 7 steps) take a path of their own — product, stage, next step: the table store of the other step
+      // kinds is not reachable from it, so the compiler has no reason to park the result in scratch memory after every
+      // squaring "in case the store needs it" (it did: 8 x 16 bytes per lane per squaring, 400 KB of HBM writes per Enc)
+      if (op == 0) { msq_ip<G>(g, NT, X); stageB<G>(g, X); continue; }
+    }
+#endif
+    const int type = op >> 5, e = op & 31;
     if (type == (OP_MUL >> 5) || type == (OP_FIRST >> 5)) load_limbs_global<G>(X, tab + e * L, g.gl);   // B() still holds the running value
+#if !ZKP_SQR_OWN_PATH
     if (ladder_squares<SAFE, TWO>() && (type == 0 || type == (OP_SQ0 >> 5))) msq_ip<G>(g, NT, X);   // X * X (B() is the staged X)
-    else if (type != (OP_FIRST >> 5)) mmo_ip<G, SAFE, TWO>(g, NT, X);
+    else
+#endif
+    if (type != (OP_FIRST >> 5)) mmo_ip<G, SAFE, TWO>(g, NT, X);
     if (type == (OP_TAB >> 5)) store_limbs_global<G>(tab + e * L, X, g.gl);
     else stageB<G>(g, X);
     if (type == (OP_SQ0 >> 5)) load_limbs_global<G>(X, tab, g.gl);
@@ -909,6 +934,36 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Calibration of the HBM-side performance counters on the ladders' own table traffic (profiles/collect_pmc.sh): the resident
+// grid of the G = 4 kernels, every lane reading (mode 0) or writing (mode 1) its 36-limb block of each of the TAB entries of its
+// group's table slot, `passes` times — a KNOWN number of bytes in exactly the access pattern whose FETCH_SIZE / WRITE_SIZE the
+// roofline's `traffic` figure is derived from (the guide calls its 2x correction of FETCH_SIZE "uncalibrated" for such reads).
+template <int G>
+__global__ void __launch_bounds__(256) k_table_traffic(uint32_t* __restrict__ table, int mode, int passes, uint32_t* __restrict__ sink) {
+  constexpr int L = Geo<G>::L;
+  const uint64_t ggrp = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+  const int gl = threadIdx.x & (G - 1);
+  uint32_t* tab = table + ggrp * (uint64_t)(TAB * L);
+  uint32_t acc = 0;
+  uint32_t v[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) v[k] = threadIdx.x + k;
+  for (int p = 0; p < passes; p++) {
+    for (int e = 0; e < TAB; e++) {
+      if (mode == 0) {
+        load_limbs_global<G>(v, tab + e * L, gl);
+#pragma unroll
+        for (int k = 0; k < W; k++) acc += v[k];
+      } else {
+        v[0] += p + e;
+        store_limbs_global<G>(tab + e * L, v, gl);
+      }
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;     // (keeps the loads alive)
 }
 
 }  // namespace zkp

@@ -46,6 +46,7 @@ struct zkp_ctx {
   // second stream + fork / join events for calls of a few proofs (hash next to the Enc checks); created on first use
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_busy = false;        // work forked onto `side` whose join has not been enqueued on `stream` yet (see ~Stage)
   std::string err;
   DevBuf consts, consts2, table, scratch[48];
   // timing of the dominant kernels
@@ -189,13 +190,32 @@ struct Stage {
   Stage(const Stage&) = delete;
   Stage& operator=(const Stage&) = delete;
   ~Stage() {                       // an error return that skipped finish(): nothing is copied back, the blocks go back to the ctx
+    join_side();
     if (owned.empty()) return;
     (void)hipStreamSynchronize(c->stream);
     give_back();
   }
+  // An error return between the fork onto the ctx's second stream and the join: the kernels there may still read the staging
+  // blocks and the ctx scratch that the next call reuses — wait for them before anything is handed back.
+  void join_side() {
+    if (!c->side_busy) return;
+    (void)hipStreamSynchronize(c->side);
+    c->side_busy = false;
+  }
+  // The blocks of this call return to the ctx's cache (the next call of the same shape allocates nothing).  The cache is bounded:
+  // beyond twice this call's own footprint (at least 64 MiB) the least recently returned blocks are freed, so a long-lived ctx
+  // that serves many batch shapes does not pile up device memory it will never use again.
   void give_back() {
-    for (auto& b : owned) c->stage_free.push_back(b);
+    size_t mine = 0;
+    for (auto& b : owned) { c->stage_free.push_back(b); mine += b.cap; }
+    const size_t keep_from = c->stage_free.size() - owned.size();
     owned.clear();
+    size_t total = 0;
+    for (auto& b : c->stage_free) total += b.cap;
+    const size_t limit = std::max<size_t>(2 * mine, size_t(64) << 20);
+    size_t drop = 0;
+    while (drop < keep_from && total > limit) { total -= c->stage_free[drop].cap; (void)hipFree(c->stage_free[drop].p); drop++; }
+    if (drop) c->stage_free.erase(c->stage_free.begin(), c->stage_free.begin() + (ptrdiff_t)drop);
   }
   // best fit among the cached blocks (no more than twice the size asked for), else a fresh allocation
   void* take(size_t bytes) {
@@ -238,6 +258,7 @@ struct Stage {
   int32_t finish() {
     for (auto& o : outs)
       if (!st && hipMemcpyAsync(o.h, o.d, o.n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { st = ZKP_EDEVICE; c->err = "D2H copy"; }
+    join_side();
     if (!dev || st) { if (hipStreamSynchronize(c->stream) != hipSuccess && !st) { st = ZKP_EDEVICE; c->err = "stream sync"; } }
     give_back();
     outs.clear();
@@ -455,6 +476,25 @@ extern "C" void* zkp_ctx_stream(zkp_ctx* c) { return c ? (void*)c->stream : null
 extern "C" int32_t zkp_ctx_synchronize(zkp_ctx* c) try {
   if (!c) return ZKP_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ZKP_OK;
+} ZKP_CATCH(c)
+
+// diagnostic: a known amount of table traffic (k_table_traffic) for the calibration of the PMC byte counters
+extern "C" int32_t zkp_diag_table_traffic(zkp_ctx* c, int32_t mode, int32_t passes, uint64_t* out_bytes) try {
+  if (!c || passes < 1 || (mode != 0 && mode != 1)) return ZKP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  constexpr int G = GB;
+  unsigned blocks = 0;
+  int32_t st = table_for<G>(c, k_enc<G, true>, ~0ull >> 8, &blocks);      // the resident grid of the Paillier kernels and its table
+  if (st) return st;
+  if ((st = ensure(c, c->scratch[18], 64))) return st;
+  {
+    TimedRegion tr(c, 0);
+    hipLaunchKernelGGL(k_table_traffic<G>, dim3(blocks), dim3(256), 0, c->stream, (uint32_t*)c->table.p, (int)mode, (int)passes, (uint32_t*)c->scratch[18].p);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (out_bytes) *out_bytes = (uint64_t)blocks * (256 / G) * TAB * Geo<G>::L * sizeof(uint32_t) * (uint64_t)passes;
   return ZKP_OK;
 } ZKP_CATCH(c)
 

@@ -131,6 +131,47 @@ inline std::vector<BigInt> mod_pow_batch(const std::vector<BigInt>& bases, const
   return r;
 }
 
+// ------------------------------------------------------------------ host SHA-256 (NiCorrectKeyProof::proof's MGF; the challenge of a RangeProofNi whose transcript holds over-wide values)
+namespace detail {
+struct Sha256 {
+  uint32_t h[8]; uint8_t buf[64]; uint64_t len = 0; size_t fill = 0;
+  static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  Sha256() { static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}; std::memcpy(h, iv, 32); }
+  void block(const uint8_t* p) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) w[i] = w[i - 16] + (ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+      uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const uint8_t* p, size_t n) {
+    len += n;
+    while (n) { size_t k = std::min(n, 64 - fill); std::memcpy(buf + fill, p, k); fill += k; p += k; n -= k; if (fill == 64) { block(buf); fill = 0; } }
+  }
+  void update(const BigInt& v) { auto b = v.to_bytes(); update(b.data(), b.size()); }
+  BigInt finish() {
+    uint64_t bits = len * 8; uint8_t pad = 0x80; update(&pad, 1); pad = 0;
+    while (fill != 56) update(&pad, 1);
+    uint8_t lb[8]; for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+    update(lb, 8);
+    uint8_t out[32]; for (int i = 0; i < 8; i++) { out[4 * i] = h[i] >> 24; out[4 * i + 1] = h[i] >> 16; out[4 * i + 2] = h[i] >> 8; out[4 * i + 3] = h[i]; }
+    return BigInt::from_bytes(out, 32);
+  }
+};
+// src/zkproofs/utils.rs:9-22
+inline BigInt compute_digest(std::initializer_list<const BigInt*> items) { Sha256 s; for (auto* v : items) s.update(*v); return s.finish(); }
+}  // namespace detail
+
 // ------------------------------------------------------------------ RangeProofNi
 struct Response {           // src/zkproofs/range_proof.rs:53-78
   enum Kind { Open, Mask } kind = Open;
@@ -210,7 +251,10 @@ class RangeProofNi {
   // arbitrary size in the reference (GMP); the fixed-width ABI carries kw / 2kw limbs.  Each proof is screened on the host so
   // that an over-wide field yields the verdict the reference would reach for THAT proof, never an exception for the batch:
   //   * r1, r2, masked_r enter only as r^n mod n^2 = (r mod n)^n mod n^2, and c_j[i], ciphertext on Mask rows only as a product
-  //     reduced mod n^2 (range_proof.rs:324-328): reduced on the host, same result;
+  //     reduced mod n^2 (range_proof.rs:324-328): reduced on the host, same row result.  The Fiat-Shamir challenge, however, is
+  //     hashed over the RAW c1 / c2 (compute_digest over encrypted_pairs, range_proof_ni.rs:110-113, utils.rs:9-22): a proof with
+  //     an over-wide c_j on a Mask row gets its challenge from the host (the raw values) and goes through
+  //     zkp_range_verifier_output_batch with that challenge, in a second small call;
   //   * an over-wide w1 / w2 fails the strict range test of an Open row (:300-305), an over-wide masked_x the bound of a Mask
   //     row (:338), an over-wide c_j[i] of an Open row can never equal a ciphertext (:293-298): Err(IncorrectProof);
   //   * a range wider than the key cannot be represented at all: that proof carries a panic-like "unsupported" result.
@@ -222,7 +266,7 @@ class RangeProofNi {
     const size_t EF = proofs[0]->error_factor, rows = B * EF;
     std::vector<uint32_t> n(kw), range(B * kw), ct(B * 2 * kw), c1(rows * 2 * kw), c2(rows * 2 * kw), rw1(rows * kw), rr1(rows * kw), rw2(rows * kw), rr2(rows * kw);
     std::vector<uint8_t> kind(rows), jj(rows), verdict(B);
-    enum Pre : uint8_t { Run = 0, Reject, PanicIdx, Unsupported };
+    enum Pre : uint8_t { Run = 0, Reject, PanicIdx, Unsupported, HostChallenge };
     std::vector<uint8_t> pre(B, Run);
     ek.n.to_limbs(n.data(), kw);
     const size_t nbits_n = 32 * (size_t)kw, nbits_c = 64 * (size_t)kw;
@@ -249,6 +293,7 @@ class RangeProofNi {
         } else {
           kind[t] = ZKP_RESP_MASK; jj[t] = rs.j;
           if (!fits(rs.masked_x, nbits_n)) { pre[b] = Reject; continue; }
+          if ((!fits(C1, nbits_c) || !fits(C2, nbits_c)) && pre[b] == Run) pre[b] = HostChallenge;   // e must be hashed over the raw values
           (fits(C1, nbits_c) ? C1 : C1 % ek.nn).to_limbs(&c1[t * 2 * kw], 2 * kw);
           (fits(C2, nbits_c) ? C2 : C2 % ek.nn).to_limbs(&c2[t * 2 * kw], 2 * kw);
           rs.masked_x.to_limbs(&rw1[t * kw], kw);
@@ -260,6 +305,35 @@ class RangeProofNi {
     zkp_range_ni_proofs p{nb, (uint32_t)EF, B, 0, n.data(), range.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
                           rw1.data(), rr1.data(), rw2.data(), rr2.data()};
     e.check(zkp_range_ni_verify_batch(e.ctx(), &p, verdict.data(), 0), "zkp_range_ni_verify_batch");
+    // proofs whose transcript holds values the ABI cannot carry: e = to_bytes(from_bytes(SHA256(n || c1 || c2))) over the raw
+    // BigInts (range_proof_ni.rs:89-92,110-113), then verifier_output with that challenge on their (reduced) rows
+    std::vector<size_t> hc;
+    for (size_t b = 0; b < B; b++) if (pre[b] == HostChallenge) hc.push_back(b);
+    if (!hc.empty()) {
+      const size_t H = hc.size(), hrows = H * EF;
+      std::vector<uint32_t> range2(H * kw), ct2(H * 2 * kw), c12(hrows * 2 * kw), c22(hrows * 2 * kw), w12(hrows * kw), r12(hrows * kw), w22(hrows * kw), r22(hrows * kw);
+      std::vector<uint8_t> kind2(hrows), jj2(hrows), v2(H), ebytes(H * 32, 0), elen(H);
+      for (size_t h = 0; h < H; h++) {
+        const size_t b = hc[h];
+        const RangeProofNi& q = *proofs[b];
+        std::memcpy(&range2[h * kw], &range[b * kw], 4 * kw); std::memcpy(&ct2[h * 2 * kw], &ct[b * 2 * kw], 8 * kw);
+        std::memcpy(&c12[h * EF * 2 * kw], &c1[b * EF * 2 * kw], EF * 8 * kw); std::memcpy(&c22[h * EF * 2 * kw], &c2[b * EF * 2 * kw], EF * 8 * kw);
+        std::memcpy(&w12[h * EF * kw], &rw1[b * EF * kw], EF * 4 * kw); std::memcpy(&r12[h * EF * kw], &rr1[b * EF * kw], EF * 4 * kw);
+        std::memcpy(&w22[h * EF * kw], &rw2[b * EF * kw], EF * 4 * kw); std::memcpy(&r22[h * EF * kw], &rr2[b * EF * kw], EF * 4 * kw);
+        std::memcpy(&kind2[h * EF], &kind[b * EF], EF); std::memcpy(&jj2[h * EF], &jj[b * EF], EF);
+        detail::Sha256 sh;
+        sh.update(ek.n);
+        for (size_t i = 0; i < EF; i++) sh.update(q.encrypted_pairs.c1[i]);
+        for (size_t i = 0; i < EF; i++) sh.update(q.encrypted_pairs.c2[i]);
+        const std::vector<uint8_t> eb = sh.finish().to_bytes();       // leading zero bytes of the digest are dropped
+        std::memcpy(&ebytes[h * 32], eb.data(), std::min<size_t>(eb.size(), 32));
+        elen[h] = (uint8_t)std::min<size_t>(eb.size(), 32);
+      }
+      zkp_range_ni_proofs p2{nb, (uint32_t)EF, H, 0, n.data(), range2.data(), ct2.data(), c12.data(), c22.data(), kind2.data(), jj2.data(),
+                             w12.data(), r12.data(), w22.data(), r22.data()};
+      e.check(zkp_range_verifier_output_batch(e.ctx(), &p2, ebytes.data(), elen.data(), v2.data(), 0), "zkp_range_verifier_output_batch");
+      for (size_t h = 0; h < H; h++) { verdict[hc[h]] = v2[h]; pre[hc[h]] = Run; }
+    }
     std::vector<Result> out;
     for (size_t b = 0; b < B; b++) {
       if (pre[b] == PanicIdx) out.push_back(Result::panicked("index out of bounds: the len is less than error_factor"));
@@ -282,46 +356,6 @@ class RangeProofNi {
   Result verify_self() const { Result r = verify_batch(ek, {this})[0]; (void)r.is_ok(); return r; }   // :109-128
 };
 
-// ------------------------------------------------------------------ host SHA-256 (only for NiCorrectKeyProof::proof's MGF)
-namespace detail {
-struct Sha256 {
-  uint32_t h[8]; uint8_t buf[64]; uint64_t len = 0; size_t fill = 0;
-  static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-  Sha256() { static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}; std::memcpy(h, iv, 32); }
-  void block(const uint8_t* p) {
-    static const uint32_t K[64] = {
-        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
-        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
-        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
-        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-    uint32_t w[64];
-    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
-    for (int i = 16; i < 64; i++) w[i] = w[i - 16] + (ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10));
-    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-    for (int i = 0; i < 64; i++) {
-      uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
-      uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
-      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-  }
-  void update(const uint8_t* p, size_t n) {
-    len += n;
-    while (n) { size_t k = std::min(n, 64 - fill); std::memcpy(buf + fill, p, k); fill += k; p += k; n -= k; if (fill == 64) { block(buf); fill = 0; } }
-  }
-  void update(const BigInt& v) { auto b = v.to_bytes(); update(b.data(), b.size()); }
-  BigInt finish() {
-    uint64_t bits = len * 8; uint8_t pad = 0x80; update(&pad, 1); pad = 0;
-    while (fill != 56) update(&pad, 1);
-    uint8_t lb[8]; for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
-    update(lb, 8);
-    uint8_t out[32]; for (int i = 0; i < 8; i++) { out[4 * i] = h[i] >> 24; out[4 * i + 1] = h[i] >> 16; out[4 * i + 2] = h[i] >> 8; out[4 * i + 3] = h[i]; }
-    return BigInt::from_bytes(out, 32);
-  }
-};
-// src/zkproofs/utils.rs:9-22
-inline BigInt compute_digest(std::initializer_list<const BigInt*> items) { Sha256 s; for (auto* v : items) s.update(*v); return s.finish(); }
-}  // namespace detail
 
 // ------------------------------------------------------------------ interactive RangeProof (src/zkproofs/range_proof.rs:83-355)
 struct DataRandomnessPairs { std::vector<BigInt> w1, w2, r1, r2; };   // range_proof.rs:41-47
