@@ -288,12 +288,20 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs", file=sys.stderr)
         sys.exit(2)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # ZKP_BENCH_SHARED_GPU=1: every rank on cuda:0 and the collectives over gloo (RCCL refuses two ranks on one GPU) — a FUNCTIONAL
+    # check of the N > 1 code path on a 1-GPU box (tools/dev/bench_two_ranks_one_gpu.sh); its timings mean nothing and the line says so
+    shared_gpu = os.environ.get("ZKP_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         print(f"bench.py: rank {rank} needs cuda:{local_rank} but {torch.cuda.device_count()} GPUs are visible", file=sys.stderr)
         sys.exit(2)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
+    if shared_gpu:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)      # backend "nccl" IS RCCL on ROCm
     ctx = zkp.Context(local_rank)          # raises if the HIP library / a gfx950 GPU is missing
     lpl = int(zkp.load().zkp_build_limbs_per_lane())
     ctx.set_geometry(lpl)                  # every batch leg runs on the throughput engine, whatever --batch says (the latency engine is measured in configs[0])
@@ -318,8 +326,10 @@ def main():
         dist.barrier()
         sync()
 
+    cdev = torch.device("cpu") if shared_gpu else dev      # where the scalars of the control collectives live
+
     def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -437,7 +447,7 @@ def main():
                    timed_reps=timed_reps, enc_roofline=enc_roofline, lpl=lpl, np=np, world=world, rank=rank, pb=pb, wt=wt)
         other, same = other_configs(env)
         ok = ok and same
-    okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
     dist.all_reduce(okt, op=dist.ReduceOp.MIN)          # a failed self-check on ANY rank fails the line
     ok = bool(okt.item())
 
@@ -446,7 +456,8 @@ def main():
         out = {"metric": f"RangeProofNi proofs/sec + verifies/sec, n=2048, batch={args.batch} {per} (value = verifies/sec; proofs/sec in prove.value)", "value": value, "unit": "verifies/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32 (29-bit limbs, u64 accumulate)",
-               "data": "synthetic", "verdicts_ok": ok,
+               "data": "synthetic" + (" — FUNCTIONAL CHECK ONLY: all ranks share ONE GPU, collectives over gloo (ZKP_BENCH_SHARED_GPU=1); timings are meaningless" if shared_gpu else ""),
+               "verdicts_ok": ok,
                "config": {"workload": f"BASELINE.json configs[1]: batch={args.batch} RangeProofNi verify {per}, n={n_bits} (reference fixture key), "
                                       f"128 rows/proof, 1/64 of the proofs tampered; prove leg = configs[2]",
                           "parallelism": f"proof-index sharding x{world}, one RCCL all-gather per step of verdicts (verify) and c1/c2 slabs (prove) via zk-paillier_amd/shard.py",

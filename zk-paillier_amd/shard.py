@@ -18,6 +18,10 @@ def all_gather_slabs(local, world: int, counts=None):
     import torch.distributed as dist
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local            # no process group: nothing to exchange (with one, the degenerate gather still runs: same code at every N)
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # device-resident slabs under the gloo backend (several ranks sharing one GPU in a functional check of the N > 1 path:
+        # RCCL refuses that): the exchange goes through host memory
+        return all_gather_slabs(local.cpu(), world, counts).to(local.device)
     if counts is None:
         out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
