@@ -37,16 +37,52 @@ sys.path.insert(0, ROOT)
 
 # The VALU roofline is measured, the guides list no integer peak: v_mad_u64_u32, 16 independent accumulators, 8 waves/SIMD,
 # 256 CUs (csrc/microbench).  profiles/mad_sustained_r02.jsonl: kernels of 0.13 s, 1 s and 4 s all issue 3.354-3.361e13
-# lane-MAC/s: that SUSTAINED rate is the peak the launches of this bench (0.5-19 s each) are priced against.  The instruction
-# issues once per 4 cycles per SIMD (one pass of a 64-lane wavefront over 16 lanes): at the nominal 2.4 GHz that would be
-# 3.93e13 — the sustained figure is the same pipe at the ~2.05 GHz the chip holds under this load (`roofline.clock`: the
-# shader clock sampled while the timed steps run).  Kernels of 16 ms read 3.474e13 (profiles/valu_rates_long_r01.jsonl;
-# round 1 used that figure).  All three fractions are reported.
+# lane-MAC/s: that SUSTAINED rate is the peak the launches of this bench (0.5-19 s each) are priced against.
+# Round 3 repeated the measurement with the shader clock sampled beside it (tools/dev/mad_peak_with_clock.py,
+# profiles/r03/mad_sustained_with_clock_r03.jsonl): the multiply-add loop runs at the FULL clock (2.395 GHz, 1.15 kW) and the
+# instruction takes 4.68 cycles per wavefront per SIMD — the figure is a property of the pipe, not of a throttled clock.  The
+# engine's kernels draw more power (random operands, LDS, DPP: 1.34 kW) and hold 2.2-2.3 GHz, so `roofline` also reports the
+# pipe's rate AT THE CLOCK SAMPLED DURING THE RUN and the fraction of it that the EXECUTED multiply-adds fill.
+# Kernels of 16 ms read 3.474e13 (profiles/valu_rates_long_r01.jsonl; round 1 used that figure).
 PEAK_LIMB_MAC_PER_S = 3.361e13
 PEAK_LIMB_MAC_PER_S_16MS_KERNELS = 3.474e13
-NOMINAL_CLOCK_GHZ = 2.4
-MAD_ISSUE_CYCLES = 4                      # v_mad_u64_u32: one issue per 4 cycles per SIMD (wave64 over a 16-lane SIMD)
-PEAK_LIMB_MAC_PER_S_NOMINAL_CLOCK = 256 * 4 * 64 / MAD_ISSUE_CYCLES * NOMINAL_CLOCK_GHZ * 1e9      # 3.93e13
+MAD_CYCLES_PER_WAVE_INSTR = 4.68          # v_mad_u64_u32 per wavefront per SIMD, measured at a sampled 2.395 GHz
+MAD_PEAK_CLOCK_GHZ = 2.395                # the clock the sustained peak was measured at
+
+
+def mad_pipe_rate(clock_ghz):
+    """lane multiply-adds per second of 256 CUs x 4 SIMDs at `clock_ghz`"""
+    return 256 * 4 * 64 / MAD_CYCLES_PER_WAVE_INSTR * clock_ghz * 1e9
+
+
+def sliding_ladder_products(exponent: int, swin: int = 6):
+    """(squarings, other products) of the sliding-window ladder for `exponent` — the script of csrc/kernels_modexp.hpp:
+    k_sliding_schedule (2^(swin-1) odd powers: one squaring-by-product + 2^(swin-1) - 1 table products, then windows)"""
+    if exponent == 0:
+        return 0, 0
+    bits = bin(exponent)[2:]
+    sq, mul, i, started = 0, 1 << (swin - 1), 0, False       # X0^2 (computed by the general product) + the table rounds
+    while i < len(bits):
+        if bits[i] == "0":
+            sq += 1; i += 1; continue
+        j = min(i + swin, len(bits))
+        while bits[j - 1] == "0":
+            j -= 1
+        if started:
+            sq += j - i; mul += 1
+        started = True
+        i = j
+    return sq, mul
+
+
+def executed_lane_mads_per_enc(n: int, n_bits: int, verify: bool):
+    """lane multiply-adds the shared-key kernel EXECUTES for one Enc (29-bit limbs: L = 144 / 288): squarings at 54.5, products
+    at 72 multiply-adds per lane per sub-step, plus the 9 (verify) / 5 (Enc) general products of the script around the ladder"""
+    L29 = 144 if n_bits <= 2048 else 288
+    sq, mul = sliding_ladder_products(n)
+    return L29 * (L29 // 36) * (54.5 * sq + 72.0 * (mul + (9 if verify else 5)))      # L sub-steps x L/36 lanes x multiply-adds per lane per sub-step
+
+
 HBM_PEAK_GBS = 8000.0
 
 
@@ -363,7 +399,7 @@ def main():
             out.append((max_over_ranks(dt), kms, launches, me))
         return out
 
-    def enc_roofline(kms, launches, modexps, nb, kernel, clock=None):
+    def enc_roofline(kms, launches, modexps, nb, kernel, clock=None, executed_per_enc=None):
         ach = modexps * enc_limb_macs(nb) / (kms * 1e-3) if kms else 0.0
         per, src = pmc_traffic_per_modexp(kernel.split(" (")[0])            # the kernel's name as rocprofv3 prints it
         rec, _ = pmc_record(kernel.split(" (")[0])
@@ -373,7 +409,6 @@ def main():
                "peak_note": "sustained v_mad_u64_u32 issue rate measured with 1-4 s kernels (profiles/mad_sustained_r02.jsonl); `achieved` counts every product of a ladder, "
                             "squarings included, as 2L^2+L limb-MACs (SURVEY 8(d)) — the squaring kernel executes 3/4 of that, so 1.0 is not a ceiling",
                "frac_vs_16ms_kernel_peak": ach / PEAK_LIMB_MAC_PER_S_16MS_KERNELS, "peak_16ms_kernels": PEAK_LIMB_MAC_PER_S_16MS_KERNELS / 1e12,
-               "frac_vs_nominal_clock_peak": ach / PEAK_LIMB_MAC_PER_S_NOMINAL_CLOCK, "peak_nominal_clock": PEAK_LIMB_MAC_PER_S_NOMINAL_CLOCK / 1e12,
                "traffic": per * per_launch if per else None,
                "traffic_note": (f"HBM-side bytes per Enc from {src} (separate rocprofv3 --pmc passes; FETCH_SIZE factor as calibrated there) x Enc of the launch; "
                                 f"algorithmic operand bytes are ~{bytes_per_enc} B per Enc" if per else "no aggregated PMC file for this kernel under profiles/"),
@@ -382,7 +417,14 @@ def main():
         if clock:
             out["clock"] = clock
             out["clock_ghz"] = clock["mean_ghz"]
-            out["frac_vs_issue_rate_at_sampled_clock"] = ach / (256 * 4 * 64 / MAD_ISSUE_CYCLES * clock["mean_ghz"] * 1e9)
+            out["peak_clock_ghz"] = MAD_PEAK_CLOCK_GHZ
+            out["mad_pipe_rate_at_sampled_clock"] = mad_pipe_rate(clock["mean_ghz"]) / 1e12
+            out["frac_vs_mad_pipe_at_sampled_clock"] = ach / mad_pipe_rate(clock["mean_ghz"])
+            if executed_per_enc:
+                out["executed_lane_mads_per_enc"] = executed_per_enc
+                out["executed_mads_over_mad_pipe_at_sampled_clock"] = modexps * executed_per_enc / (kms * 1e-3) / mad_pipe_rate(clock["mean_ghz"])
+                out["executed_note"] = ("multiply-adds the kernel really issues (squarings at 3/4 of a product, 29-bit limbs) over what the v_mad_u64_u32 pipe can issue at the "
+                                        "clock sampled during these steps: ~1.0 means the multiply-add pipe itself is full")
         elif rec and "effective_clock_ghz" in rec.get("_derived", {}):
             out["clock_ghz"] = rec["_derived"]["effective_clock_ghz"]
             out["clock_note"] = "GRBM_GUI_ACTIVE / wall time of the PMC pass of this kernel (profiles/aggregate_pmc.py)"
@@ -429,7 +471,7 @@ def main():
     if "c1" in gathered:
         ok = ok and bool(torch.equal(gathered["c1"][my_lo:my_lo + B], pb.c1))
     value = B_total * args.steps / dt
-    roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc<{144 // lpl}, true> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer; sliding-window ladder, squarings at 3/4 of a product)", clk.summary())
+    roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc<{144 // lpl}, true> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer; sliding-window ladder, squarings at 3/4 of a product)", clk.summary(), executed_lane_mads_per_enc(n, n_bits, True))
     ms_per_step = 1e3 * dt / args.steps
     gathered.clear()
 
@@ -616,7 +658,6 @@ def other_configs(env):
                "modexp_per_s_per_gpu": me_k / (kms_k * 1e-3), "all_rejected_as_expected": all_rej,
                "roofline": {"bound": "valu", "kernel": f"k_ck_check<{72 // lpl}>", "kernel_ms": kms_k, "achieved": ach_k / 1e12, "peak": PEAK_LIMB_MAC_PER_S / 1e12, "unit": "Tlimb-MAC/s",
                             "frac": ach_k / PEAK_LIMB_MAC_PER_S, "frac_vs_16ms_kernel_peak": ach_k / PEAK_LIMB_MAC_PER_S_16MS_KERNELS,
-                            "frac_vs_nominal_clock_peak": ach_k / PEAK_LIMB_MAC_PER_S_NOMINAL_CLOCK,
                             "traffic": (lambda per: per[0] * me_k if per[0] else None)(pmc_traffic_per_modexp(f"k_ck_check<{72 // lpl}>"))},
                "parallelism": f"key-index blocks x{world} + one all-gather of the verdict bytes"}
         rec["frac"] = rec["roofline"]["frac"]

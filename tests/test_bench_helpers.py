@@ -40,3 +40,27 @@ def test_pmc_lookup_reads_the_committed_profiles():
 def test_argument_defaults_are_the_baseline_sizes():
     a = bench.parse_args([])
     assert (a.gpus, a.batch, a.n_bits, a.big_batch, a.distinct_batch) == (1, 4096, 2048, 4096, 4096)
+
+
+def test_executed_work_figure_follows_the_kernel_script():
+    """bench.sliding_ladder_products mirrors k_sliding_schedule (csrc/kernels_modexp.hpp): squarings and other products of the
+    fixture key's ladder; the executed multiply-adds per Enc are below the algorithmic 8.085e7 (squarings at 3/4)"""
+    def sched(n, swin=6):                      # the device routine, bit for bit
+        bit = lambda i: (n >> i) & 1
+        sq, mul, i, started = 0, 32, n.bit_length() - 1, False
+        while i >= 0:
+            if not bit(i):
+                sq += 1; i -= 1; continue
+            l = max(i - swin + 1, 0)
+            while not bit(l):
+                l += 1
+            if started:
+                sq += i - l + 1; mul += 1
+            started = True
+            i = l - 1
+        return sq, mul
+    for n in (synth.BENCH_N, synth.bench_key_4096()[2], 1, 0b1000001, (1 << 77) - 1):
+        assert bench.sliding_ladder_products(n) == sched(n), n
+    ex = bench.executed_lane_mads_per_enc(synth.BENCH_N, 2048, True)
+    assert 7.7e7 < ex < 7.9e7 < bench.enc_limb_macs(2048)
+    assert abs(bench.mad_pipe_rate(bench.MAD_PEAK_CLOCK_GHZ) / bench.PEAK_LIMB_MAC_PER_S - 1) < 0.01      # the two peak figures are one measurement
