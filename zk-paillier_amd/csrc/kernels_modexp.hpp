@@ -178,7 +178,7 @@ template <int G, bool SAFE, bool TWO = false, class LL> __device__ __forceinline
 // multiply-adds of a product).  Ladders of the fast product only: the throughput engine's W = 36 kernels are bound by the
 // multiply-add pipe; the latency engine's chains are not (ZKP_SQR=0 builds the ladders without it, for A/B runs).
 #ifndef ZKP_SQR
-#define ZKP_SQR (ZKP_W == 36)
+#define ZKP_SQR 1
 #endif
 #ifndef ZKP_KILL_LIVE
 #define ZKP_KILL_LIVE 1

@@ -157,8 +157,10 @@ static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits) {
     // 62 against 70 ms, 8192 keys: 101 against 96; CompositeDLogProof 16384 proofs = 4 per SIMD: 11 against 18 ms
     const uint64_t limbs = mod_bits <= 2048 ? 72 : mod_bits <= 4096 ? 144 : 288;
     const uint64_t lanes = limbs / (uint64_t)c->lat->limbs_per_lane;
-    const uint64_t waves_per_simd = mod_bits <= 2048 ? 6 : 3;
-    take = items <= (waves_per_simd * 4 * (uint64_t)c->cus * 64) / lanes;
+    // (round 3, both engines with squarings where their product allows: RangeProofNi n = 2048 32 proofs 40.7 / 37.5 ms against 49.2 / 44.4,
+    // 48 proofs 55.3 / 54.9 against 49.5 / 44.2 -> 2.5 waves per SIMD; NiCorrectKeyProof 4096 keys 56.9 against 59.0 ms, 8192 keys 90 against 81)
+    const uint64_t half_waves_per_simd = mod_bits <= 2048 ? 12 : 5;
+    take = 2 * items <= (half_waves_per_simd * 4 * (uint64_t)c->cus * 64) / lanes;
   }
   if (take) c->last_geometry = c->lat->limbs_per_lane;
   return take;
@@ -554,16 +556,24 @@ static int32_t modexp_core(zkp_ctx* c, uint32_t exp_bits, uint64_t count, const 
       return ZKP_OK;
     }
   }
-  if ((st = table_for<G>(c, k_modexp<G, true>, count, &blocks))) return st;
+  // One exponent for the whole call: the sliding-window ladder (5 % fewer products) on the latency engine, whose calls are
+  // chains; on the throughput engine the fixed-window kernel, reading the one exponent with stride 0, is as fast or faster
+  // (65 536 exponentiations, 4096 / 2048-bit moduli: 171.1 / 46.4 ms against 172.4 / 49.7 ms, tools/dev/perf_ladders.py: k_modexp's
+  // sliding variant keeps scratch accesses in its product loops, k_enc's does not) — one kernel less to build and to keep fast.
+  constexpr bool SLIDING_MODEXP = !COL_NEEDS_CARE;
+  if ((st = table_for<G>(c, k_modexp<G, false>, count, &blocks))) return st;
   const uint8_t* sched = nullptr;
-  if (exp_stride == 0 && (st = build_schedule(c, exp, exp_bits, &sched))) return st;
+  if (SLIDING_MODEXP && exp_stride == 0 && (st = build_schedule(c, exp, exp_bits, &sched))) return st;
   unsigned long long* wc = nullptr;
   if ((st = fresh_work_counter(c, &wc))) return st;
   ModexpArgs a{base, exp, exp_stride, (const uint32_t*)c->consts.p, per_item_mod ? (uint64_t)CL::WORDS : 0, out, (uint32_t*)c->table.p, count, (int)exp_bits, io_words, out_words ? out_words : io_words, sched, wc, {}, 0};
   {
     TimedRegion tr(c, count);
-    if (a.sched) hipLaunchKernelGGL((k_modexp<G, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
-    else hipLaunchKernelGGL((k_modexp<G, false>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
+    bool launched = false;
+    if constexpr (SLIDING_MODEXP) {
+      if (a.sched) { hipLaunchKernelGGL((k_modexp<G, true>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a); launched = true; }
+    }
+    if (!launched) hipLaunchKernelGGL((k_modexp<G, false>), dim3(blocks), dim3(256), LL::BYTES_PER_BLOCK, c->stream, a);
   }
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
