@@ -114,3 +114,30 @@ def test_multi_last_timing_reports_blocks(oracle):
     t = m.last_timing()
     assert [(lo, hi) for _, lo, hi in t] == [(0, 3), (3, 5)] and all(ms > 0 for ms, _, _ in t)
     m.close()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_share_the_one_gpu(scaling):
+    """`bench.py --gpus 2` end to end on the 1-GPU box: both ranks on cuda:0, collectives over gloo (ZKP_BENCH_SHARED_GPU=1) — the
+    whole N > 1 code path (rank blocks of unequal size, every sharded leg, the gathers, the max-over-ranks timing, the JSON line)
+    with real kernels; only RCCL itself is not exercised.  Timings are meaningless and the line says so."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ZKP_BENCH_SHARED_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "2", "--scaling", scaling, "--batch", "66", "--steps", "1", "--warmup", "0", "--cpu-sample", "0",
+           "--no-pcie-leg", "--big-batch", "9", "--distinct-batch", "34", "--ck-batch", "1025", "--interactive-batch", "33", "--other-reps", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["verdicts_ok"] and "FUNCTIONAL CHECK ONLY" in d["data"]
+    assert d["config"]["proofs_total"] == (132 if scaling == "weak" else 66) and d["config"]["proofs_per_rank"] == (66 if scaling == "weak" else 33)
+    legs = d["other_configs"]
+    ck = [v for k, v in legs.items() if "configs[3]" in k][0]
+    big = [v for k, v in legs.items() if "configs[4]" in k][0]
+    assert ck["n_gpus"] == 2 and ck["keys_per_rank"] == 513 and ck["all_rejected_as_expected"]          # 1025 keys: blocks of 513 + 512
+    assert big["n_gpus"] == 2 and big["batch_per_rank"] == 5 and big["verdicts_ok"]                       # 9 proofs: blocks of 5 + 4
+    assert all(v.get("verdicts_ok", True) and v.get("all_accepted", True) for v in legs.values())
