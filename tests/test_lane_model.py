@@ -343,3 +343,92 @@ def test_squaring_keeps_the_fast_column_bound(G, W):
     for col in range(W):                                 # multiplicity of limb products landing in one column of one lane
         mult = sum((2 if dbl else 1) for t in range(W) for k, dbl in K[t] if (t + k) % W == col)
         assert mult == W
+
+
+def montsqr2(N, G, W, A, stats):
+    """mirror of montsqr2<G> (bigint29.hpp): montmul2's schedule — both digits of a pair of sub-steps first — over the products the
+    squaring tournament keeps"""
+    K = sqr_sets(W)
+    mult = {(t, k): (2 if dbl else 1) for t in range(W) for k, dbl in K[t]}
+    c = [[0] * W for _ in range(G)]
+
+    def finish(t):
+        lo = [0] * G
+        for j in range(G):
+            v = c[j][t % W]
+            lo[j] = v & MASK
+            c[j][(t + 1) % W] += v >> B
+        assert lo[0] == 0
+        for j in range(G):
+            c[j][t % W] = lo[j + 1] if j + 1 < G else 0
+
+    def mads(j, tt, b, cols):
+        for k in range(W):
+            if (tt + k) in cols and (tt, k) in mult:
+                c[j][(tt + k) % W] += A[j * W + k] * b * mult[(tt, k)]
+                stats["mads"] = stats.get("mads", 0) + 1
+
+    for s in range(G):
+        t = 0
+        while t + 1 < W:
+            b0, b1 = A[s * W + t], A[s * W + t + 1]
+            for j in range(G):
+                mads(j, t, b0, (t, t + 1)); mads(j, t + 1, b1, (t + 1,))
+            q0 = c[0][t % W] & MASK
+            q1 = (c[0][(t + 1) % W] + (c[0][t % W] >> B)) & MASK
+            for j in range(G):
+                mads(j, t, b0, range(t + 2, t + W)); mads(j, t + 1, b1, range(t + 2, t + W))
+                for k in range(W):
+                    c[j][(t + k) % W] += N[j * W + k] * q0
+                for k in range(W - 1):
+                    c[j][(t + 1 + k) % W] += N[j * W + k] * q1
+            finish(t)
+            for j in range(G):
+                mads(j, t + 1, b1, (t + W,))
+                c[j][t % W] += N[j * W + W - 1] * q1
+            finish(t + 1)
+            stats["maxcol"] = max(stats["maxcol"], max(max(r) for r in c))
+            t += 2
+        if W & 1:
+            tt = W - 1
+            for j in range(G):
+                mads(j, tt, A[s * W + tt], range(tt, tt + W))
+            q = c[0][tt] & MASK
+            for j in range(G):
+                for k in range(W):
+                    c[j][(tt + k) % W] += N[j * W + k] * q
+            finish(tt)
+    out, carries = [], []
+    for j in range(G):
+        cy, r = 0, []
+        for k in range(W):
+            v = c[j][k] + cy
+            r.append(v & MASK)
+            cy = v >> B
+        out.append(r)
+        carries.append(cy)
+    for j in range(1, G):
+        out[j][0] += carries[j - 1]
+    assert carries[G - 1] == 0
+    return [v for r in out for v in r]
+
+
+@pytest.mark.parametrize("bits,G,W", [(4096, 16, 9), (8192, 32, 9), (900, 4, 9)])
+def test_double_digit_squaring_model(bits, G, W):
+    """montsqr2(X) == montmul2(X, X) (values; 5 + 9 instead of 9 + 9 multiply-adds per lane per sub-step), no column near 2^64"""
+    rnd = random.Random(bits * 3 + G)
+    M = rnd.getrandbits(bits) | 1 | (1 << (bits - 1))
+    L = G * W
+    n2 = (-pow(M, -1, 1 << (2 * B))) % (1 << (2 * B))
+    Mt2 = M * n2
+    assert bits + 2 * B + 3 <= B * L
+    N = to_limbs(Mt2, L)
+    stats = {"maxcol": 0}
+    x = to_limbs(rnd.randrange(2 * Mt2), L)
+    for _ in range(4):
+        stats["mads"] = 0
+        r = montsqr2(N, G, W, x, stats)
+        assert from_limbs(r) == from_limbs(montmul2(N, G, W, x, x, {"maxcol": 0})) and from_limbs(r) < 2 * Mt2
+        x = r
+    assert stats["maxcol"] < (1 << 63)
+    assert stats["mads"] == L * G * 5                    # the A half: 5 of 9 limbs per lane per sub-step

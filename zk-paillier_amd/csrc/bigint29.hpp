@@ -223,9 +223,6 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
 // montmul(X, X) (tests/test_lane_model.py: same value, column bound).  Column capacity: over a column's life the doubled and
 // single products of a lane add up to at most 2 * 18 (or 2 * 17 + 2) limb products — the FAST bound of "column capacity"
 // above holds unchanged; there is no SAFE variant (keys whose M~ fails the digit-sum test keep montmul for every product).
-#ifndef ZKP_SQR_VARIANT
-#define ZKP_SQR_VARIANT 0
-#endif
 template <int G>
 __device__ __forceinline__ void montsqr(uint32_t (&X)[W], const uint32_t* ldsB /* the staged copy of X */, const uint32_t (&N)[W], int gl) {
   constexpr int H = W / 2;   // (odd W: distances 1 .. (W-1)/2 form a regular tournament by themselves)
@@ -236,17 +233,9 @@ __device__ __forceinline__ void montsqr(uint32_t (&X)[W], const uint32_t* ldsB /
   for (int s = 0; s < G; s++) {
 #pragma unroll
     for (int t = 0; t < W; t++) {
-#if ZKP_SQR_VARIANT & 2
-      if (t % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
-      uint32_t b = ldsB[s * BLK + t];
+      const uint32_t b = ldsB[s * BLK + t];
       c[(2 * t) % W] += (uint64_t)X[t] * b;
-#if ZKP_SQR_VARIANT & 1
-      asm("v_lshlrev_b32 %0, 1, %0" : "+v"(b));       // doubled in place: the single multiplier is dead from here on
-      const uint32_t b2 = b;
-#else
-      const uint32_t b2 = b + b;
-#endif
+      const uint32_t b2 = b + b;      // (doubling in place by inline asm, and scheduling barriers every 4 sub-steps, were measured: +-1 %)
 #pragma unroll
       for (int k = 0; k < W; k++) {
         const int d = (k - t + W) % W;
@@ -343,6 +332,85 @@ __device__ __forceinline__ void montmul2(uint32_t (&R)[W], const uint32_t (&A)[W
     cy = t >> LB;
   }
   R[0] += from_prev<G>((uint32_t)cy, gl);
+}
+
+// ---------------------------------------------------------------- the squaring of the double-digit product (latency engine)
+// montmul2's schedule — both quotient digits of a pair of sub-steps from the bottom two columns, before the bulk of the pair's
+// products — with montsqr's tournament deciding which products exist at all and which are doubled.  W is odd (9): distances
+// 1 .. (W-1)/2 form a regular tournament; 5 instead of 9 multiply-adds in the A half of every sub-step.
+// sqr_mult(t, k): what limb k is multiplied by at position t of a block: 0 = not at all, 1 = b (same position), 2 = 2 b
+constexpr int sqr_mult(int t, int k) {
+  if (k == t) return 1;
+  const int d = (k - t + W) % W, H = W / 2;
+  const bool take = (W & 1) ? (d >= 1 && d <= H) : ((d >= 1 && d < H) || (d == H && t < H));
+  return take ? 2 : 0;
+}
+template <int G>
+__device__ __forceinline__ void montsqr2(uint32_t (&X)[W], const uint32_t* ldsB /* the staged copy of X */, const uint32_t (&N)[W], int gl) {
+  static_assert(!COL_NEEDS_CARE, "the double-digit product is built for the short column window of the latency engine");
+  uint64_t c[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) c[k] = 0;
+  // c[col] += X[k] * (b | 2 b), or nothing: the position pair (tt, k) decides at compile time
+  // (plain `if`: t and k are indices of fully unrolled loops, the conditions fold to constants)
+#define ZKP_SQ(tt, k, col, b1x, b2x) do { const int m_ = sqr_mult((tt), (k)); if (m_ == 1) c[(col)] += (uint64_t)X[(k)] * (b1x); \
+                                           else if (m_ == 2) c[(col)] += (uint64_t)X[(k)] * (b2x); } while (0)
+#pragma unroll 1
+  for (int s = 0; s < G; s++) {
+#pragma unroll
+    for (int t = 0; t + 1 < W; t += 2) {
+      const int i0 = t % W, i1 = (t + 1) % W, i2 = (t + 2) % W;
+      const uint32_t b0 = ldsB[s * BLK + t], b1 = ldsB[s * BLK + t + 1];
+      const uint32_t b0d = b0 + b0, b1d = b1 + b1;
+      ZKP_SQ(t, 0, i0, b0, b0d);                                         // the products of columns t and t + 1 first: they decide the digits
+      ZKP_SQ(t, 1, i1, b0, b0d);
+      ZKP_SQ(t + 1, 0, i1, b1, b1d);
+      const uint32_t q0 = bcast0<G>((uint32_t)c[i0] & LMASK);
+      const uint32_t q1 = bcast0<G>((uint32_t)(c[i1] + (c[i0] >> LB)) & LMASK);
+#pragma unroll
+      for (int k = 2; k < W; k++) ZKP_SQ(t, k, (t + k) % W, b0, b0d);
+#pragma unroll
+      for (int k = 1; k < W - 1; k++) ZKP_SQ(t + 1, k, (t + 1 + k) % W, b1, b1d);
+#pragma unroll
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q0;
+#pragma unroll
+      for (int k = 0; k < W - 1; k++) c[(t + 1 + k) % W] += (uint64_t)N[k] * q1;
+      {
+        const uint64_t v = c[i0];
+        c[i1] += v >> LB;
+        c[i0] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);        // slot i0 is column t + W from here on
+      }
+      ZKP_SQ(t + 1, W - 1, i0, b1, b1d);                                 // the top products of the second digit
+      c[i0] += (uint64_t)N[W - 1] * q1;
+      {
+        const uint64_t v = c[i1];
+        c[i2] += v >> LB;
+        c[i1] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+      }
+    }
+    if constexpr (W & 1) {
+      constexpr int t = W - 1;
+      const uint32_t b = ldsB[s * BLK + t];
+      const uint32_t bd = b + b;
+#pragma unroll
+      for (int k = 0; k < W; k++) ZKP_SQ(t, k, (t + k) % W, b, bd);
+      const uint32_t q = bcast0<G>((uint32_t)c[t] & LMASK);
+#pragma unroll
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q;
+      const uint64_t v = c[t];
+      c[(t + 1) % W] += v >> LB;
+      c[t] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+    }
+  }
+#undef ZKP_SQ
+  uint64_t cy = 0;
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const uint64_t t = c[k] + cy;
+    X[k] = (uint32_t)t & LMASK;
+    cy = t >> LB;
+  }
+  X[0] += from_prev<G>((uint32_t)cy, gl);
 }
 
 // ---------------------------------------------------------------- representation changes

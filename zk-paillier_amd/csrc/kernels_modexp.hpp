@@ -175,20 +175,16 @@ template <int G, bool SAFE, bool TWO = false, class LL> __device__ __forceinline
   else montmul<G, true, SAFE>(X, X, g.B(), NT, 1u, g.gl);
 }
 // in-place SQUARING on the Orup multiple: X = X * X / R with B() == the staged copy of X (bigint29.hpp: montsqr, 3/4 of the
-// multiply-adds of a product).  Ladders of the fast product only: the throughput engine's W = 36 kernels are bound by the
-// multiply-add pipe; the latency engine's chains are not (ZKP_SQR=0 builds the ladders without it, for A/B runs).
+// multiply-adds of a product; bigint29.hpp: montsqr2 for the latency engine's double-digit product).  Ladders of the fast
+// products only.  ZKP_SQR=0 builds the ladders without it, for A/B runs.
 #ifndef ZKP_SQR
 #define ZKP_SQR 1
 #endif
-#ifndef ZKP_KILL_LIVE
-#define ZKP_KILL_LIVE 1
-#endif
-#ifndef ZKP_SQR_OWN_PATH
-#define ZKP_SQR_OWN_PATH 1
-#endif
-template <bool SAFE, bool TWO> constexpr bool ladder_squares() { return ZKP_SQR && !SAFE && !TWO; }
-template <int G, class LL> __device__ __forceinline__ void msq_ip(const Grp<G, LL>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
-  montsqr<G>(X, g.B(), NT, g.gl);
+
+template <bool SAFE, bool TWO> constexpr bool ladder_squares() { return ZKP_SQR && !SAFE; }
+template <int G, bool TWO = false, class LL> __device__ __forceinline__ void msq_ip(const Grp<G, LL>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
+  if constexpr (TWO) montsqr2<G>(X, g.B(), NT, g.gl);      // NT is the 58-bit multiple (latency engine)
+  else montsqr<G>(X, g.B(), NT, g.gl);
 }
 
 // Bits the ladders of this wavefront have to walk: the longest exponent among its groups (exponent words of this group in LDS at
@@ -249,7 +245,7 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
   for (;;) {
     const bool tabmul = c > 0 && c % (WIN + 1) == 1;
     if (tabmul) load_limbs_global<G>(X, tab + window((c - 1) / (WIN + 1)) * L, g.gl);
-    if (ladder_squares<SAFE, TWO>() && c > 0 && !tabmul) msq_ip<G>(g, NT, X);     // B() is the staged X: a squaring
+    if (ladder_squares<SAFE, TWO>() && c > 0 && !tabmul) msq_ip<G, TWO>(g, NT, X);     // B() is the staged X: a squaring
     else mmo_ip<G, SAFE, TWO>(g, NT, X);
     if (c < 0) {
       store_limbs_global<G>(tab + (c + TROUNDS + 2) * L, X, g.gl);
@@ -324,21 +320,15 @@ __device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[
   for (int i = 0;; i++) {
     op = __builtin_amdgcn_readfirstlane((int)ops[i]);
     if (op == OP_END) break;
-#if ZKP_SQR_OWN_PATH
     if constexpr (ladder_squares<SAFE, TWO>()) {
       // the squarings (6 of 7 steps) take a path of their own — product, stage, next step: the table store of the other step
       // kinds is not reachable from it, so the compiler has no reason to park the result in scratch memory after every
       // squaring "in case the store needs it" (it did: 8 x 16 bytes per lane per squaring, 400 KB of HBM writes per Enc)
-      if (op == 0) { msq_ip<G>(g, NT, X); stageB<G>(g, X); continue; }
+      if (op == 0) { msq_ip<G, TWO>(g, NT, X); stageB<G>(g, X); continue; }
     }
-#endif
     const int type = op >> 5, e = op & 31;
     if (type == (OP_MUL >> 5) || type == (OP_FIRST >> 5)) load_limbs_global<G>(X, tab + e * L, g.gl);   // B() still holds the running value
-#if !ZKP_SQR_OWN_PATH
-    if (ladder_squares<SAFE, TWO>() && (type == 0 || type == (OP_SQ0 >> 5))) msq_ip<G>(g, NT, X);   // X * X (B() is the staged X)
-    else
-#endif
-    if (type != (OP_FIRST >> 5)) mmo_ip<G, SAFE, TWO>(g, NT, X);
+    if (type != (OP_FIRST >> 5)) mmo_ip<G, SAFE, TWO>(g, NT, X);   // (the one squaring X0 * X0 of the table build takes the product too)
     if (type == (OP_TAB >> 5)) store_limbs_global<G>(tab + e * L, X, g.gl);
     else stageB<G>(g, X);
     if (type == (OP_SQ0 >> 5)) load_limbs_global<G>(X, tab, g.gl);
@@ -675,9 +665,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
     if constexpr (PAIR) powm_pair<G>(g, X, ZKP_SEG(exp_bits), cst, ZKP_SEG(exp) + item * ZKP_SEG(exp_stride), role);
     else powm<G, SHARED_EXP>(g, X, ZKP_SEG(exp_bits), tab, cst, a.sched, ZKP_SEG(exp) + item * ZKP_SEG(exp_stride));
 #undef ZKP_SEG
-#if ZKP_KILL_LIVE
     load_modulus_consts<G>(g, cst);      // (read again rather than kept across the ladder: see k_enc)
-#endif
     // leave the Montgomery domain: montmul(X, 1) <= M
     stage_one<G>(g);
     mm<G>(g, R, X);
@@ -863,14 +851,12 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
       if (s == 1) {
         if constexpr (PAIR) powm_pair<G>(g, X, a.n_bits, cst, pn, role);
         else powm<G, SHARED_EXP>(g, X, a.n_bits, tab, cst, a.sched, pn);             // exponent = n (read from global memory by the fixed-window ladder)
-#if ZKP_KILL_LIVE
         // Nothing but X needs to survive the ladder: the modulus is read again and the script's other values are (re)defined here,
         // so that the register allocator sees them dead across the ladder's product loops instead of parking them around (and,
         // with two product bodies in the ladder, inside) those loops.
         load_modulus_consts<G>(g, cst);
 #pragma unroll
         for (int k = 0; k < W; k++) { Y[k] = 0; C[k] = 0; }
-#endif
         continue;
       }
       // ---- operands
