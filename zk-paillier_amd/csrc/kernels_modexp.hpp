@@ -17,12 +17,19 @@ namespace zkp {
 #ifndef ZKP_SWIN
 #define ZKP_SWIN 6
 #endif
-constexpr int WIN = ZKP_WIN;           // fixed window width
+#ifndef ZKP_WIN_KEY
+#define ZKP_WIN_KEY 6
+#endif
+constexpr int WIN = ZKP_WIN;           // fixed window width of the general exponentiation (k_modexp: exponents of 256 bits and up)
+// ... of the ladders whose exponent is a KEY (k_enc with per-proof keys, k_ck_check: n_bits = 1024 .. 4096): at 2048 bits 6-bit
+// windows cost 62 + 342 table products against the 30 + 410 of 5-bit ones (A/B on one box: k_ck_check<2> +0.9 %, distinct-key
+// prove / verify +1.3 / +1.5 %); a 256-bit exponent (CompositeDLogProof's ni^e) would pay 32 more than it saves, hence two widths
+constexpr int WIN_KEY = ZKP_WIN_KEY;
 constexpr int SWIN = ZKP_SWIN;         // widest sliding window
-constexpr int TABF = 1 << WIN;         // table entries of the fixed-window ladder
-constexpr int TABS = 1 << (SWIN - 1);  // ... of the sliding-window ladder
-constexpr int TAB = TABF > TABS ? TABF : TABS;   // entries per table slot in HBM (Montgomery powers of one exponentiation in flight)
-static_assert(TABS <= 32 && WIN >= 2 && WIN <= 7, "window widths");
+constexpr int TABS = 1 << (SWIN - 1);  // table entries of the sliding-window ladder
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int TAB = cmax(cmax(1 << WIN, 1 << WIN_KEY), TABS);   // entries per table slot in HBM (Montgomery powers of one exponentiation in flight)
+static_assert(TABS <= 32 && WIN >= 2 && WIN <= 7 && WIN_KEY >= 2 && WIN_KEY <= 7, "window widths");
 
 // ---- per-modulus constants in global memory (uint32 words):
 //   N29[L] | R2[L] | R1[L] | NR[L] | MT[L] | n1[12] | status[4]
@@ -203,11 +210,12 @@ template <int G> __device__ __forceinline__ int wave_exponent_bits(const uint32_
 //     control flow whatever the exponents are.  1.2 t + 30 products, ONE montmul call site: the table T[0] = R mod M
 //     (Montgomery one), T[1] = X, T[k] = T[k-1]*X is built by the first TAB-2 rounds of the same loop that then runs
 //     (nwin-1) rounds of [5 squarings, 1 table product].
-template <int G, bool SAFE, bool TWO = false, class LL>
+template <int G, bool SAFE, bool TWO = false, int WIN = zkp::WIN, class LL>
 __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst,
                                            const uint32_t* __restrict__ ew /* exponent words in global memory, exp_bits/32 of them */) {
   using CL = ConstLayout<G>;
   constexpr int L = Geo<G>::L;
+  constexpr int TABF = 1 << WIN;         // table entries of this ladder (WIN: the template parameter, the width of this kernel's windows)
   uint32_t NT[W];
   load_limbs_global<G>(NT, cst + (TWO ? CL::OFF_MT2 : CL::OFF_MT), g.gl);
   {
@@ -339,7 +347,7 @@ __device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[
 // every one of its groups may (uniform control flow; per-key batches mix keys inside a wavefront).
 // SHARED_EXP: the launch has ONE exponent (sliding-window script `sched`), else every item has its own (fixed windows).  Each
 // kernel is instantiated for one kind only: both ladders in one kernel cost registers in the hot loops.
-template <int G, bool SHARED_EXP, class LL>
+template <int G, bool SHARED_EXP, int WINF = zkp::WIN, class LL>
 __device__ __forceinline__ void powm(const Grp<G, LL>& g, uint32_t (&X)[W], int exp_bits, uint32_t* tab, const uint32_t* cst, const uint8_t* sched,
                                      const uint32_t* __restrict__ exp_words_global) {
   using CL = ConstLayout<G>;
@@ -348,7 +356,7 @@ __device__ __forceinline__ void powm(const Grp<G, LL>& g, uint32_t (&X)[W], int 
     // latency engine: two quotient digits per chain step when every key of the wavefront leaves room for the 58-bit multiple
     if (__all(cst[CL::OFF_ST + 2] != 0)) {
       if constexpr (SHARED_EXP) powm_sliding<G, false, true>(g, X, sched, tab, cst);
-      else powm_fixed<G, false, true>(g, X, exp_bits, tab, cst, exp_words_global);
+      else powm_fixed<G, false, true, WINF>(g, X, exp_bits, tab, cst, exp_words_global);
       return;
     }
   }
@@ -356,8 +364,8 @@ __device__ __forceinline__ void powm(const Grp<G, LL>& g, uint32_t (&X)[W], int 
     if (fast) powm_sliding<G, false>(g, X, sched, tab, cst);
     else powm_sliding<G, true>(g, X, sched, tab, cst);
   } else {
-    if (fast) powm_fixed<G, false>(g, X, exp_bits, tab, cst, exp_words_global);
-    else powm_fixed<G, true>(g, X, exp_bits, tab, cst, exp_words_global);
+    if (fast) powm_fixed<G, false, false, WINF>(g, X, exp_bits, tab, cst, exp_words_global);
+    else powm_fixed<G, true, false, WINF>(g, X, exp_bits, tab, cst, exp_words_global);
   }
 }
 
@@ -625,7 +633,10 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_modexp(ModexpArgs a) {
   Grp<G> g;
   grp_init<G>(g, lds_raw);
   const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
-  uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
+  // (the table slot of a group is as wide as THIS kernel's ladder needs: a wider stride spreads the resident grid's tables over
+  // more memory and costs the ladders 2 % — measured when all slots were sized for the 64 entries of the 6-bit key windows)
+  constexpr int TSLOT = SHARED_EXP ? TABS : (1 << WIN);
+  uint32_t* tab = a.table + ggrp * (uint64_t)(TSLOT * L);
   // wavefronts claim 64/G consecutive items at a time; surplus groups recompute the last item and skip the store
   const int lane = threadIdx.x & 63;
   for (;;) {
@@ -783,7 +794,8 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
   Grp<G> g;
   grp_init<G>(g, lds_raw);
   const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
-  uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
+  constexpr int TSLOT = SHARED_EXP ? TABS : (1 << WIN_KEY);      // (see k_modexp)
+  uint32_t* tab = a.table + ggrp * (uint64_t)(TSLOT * L);
   const int kw = a.n_bits / 32;
   const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
   const int lane = threadIdx.x & 63;
@@ -850,7 +862,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
     for (int s = 0; s < nsteps; s++) {
       if (s == 1) {
         if constexpr (PAIR) powm_pair<G>(g, X, a.n_bits, cst, pn, role);
-        else powm<G, SHARED_EXP>(g, X, a.n_bits, tab, cst, a.sched, pn);             // exponent = n (read from global memory by the fixed-window ladder)
+        else powm<G, SHARED_EXP, WIN_KEY>(g, X, a.n_bits, tab, cst, a.sched, pn);    // exponent = n (read from global memory by the fixed-window ladder)
         // Nothing but X needs to survive the ladder: the modulus is read again and the script's other values are (re)defined here,
         // so that the register allocator sees them dead across the ladder's product loops instead of parking them around (and,
         // with two product bodies in the ladder, inside) those loops.
@@ -924,7 +936,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // Calibration of the HBM-side performance counters on the ladders' own table traffic (profiles/collect_pmc.sh): the resident
-// grid of the G = 4 kernels, every lane reading (mode 0) or writing (mode 1) its 36-limb block of each of the TAB entries of its
+// grid of the G = 4 kernels, every lane reading (mode 0) or writing (mode 1) its 36-limb block of each of the TABS entries of its
 // group's table slot, `passes` times — a KNOWN number of bytes in exactly the access pattern whose FETCH_SIZE / WRITE_SIZE the
 // roofline's `traffic` figure is derived from (the guide calls its 2x correction of FETCH_SIZE "uncalibrated" for such reads).
 template <int G>
@@ -932,13 +944,13 @@ __global__ void __launch_bounds__(256) k_table_traffic(uint32_t* __restrict__ ta
   constexpr int L = Geo<G>::L;
   const uint64_t ggrp = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
   const int gl = threadIdx.x & (G - 1);
-  uint32_t* tab = table + ggrp * (uint64_t)(TAB * L);
+  uint32_t* tab = table + ggrp * (uint64_t)(TABS * L);          // the slots of the shared-key Enc kernel
   uint32_t acc = 0;
   uint32_t v[W];
 #pragma unroll
   for (int k = 0; k < W; k++) v[k] = threadIdx.x + k;
   for (int p = 0; p < passes; p++) {
-    for (int e = 0; e < TAB; e++) {
+    for (int e = 0; e < TABS; e++) {
       if (mode == 0) {
         load_limbs_global<G>(v, tab + e * L, gl);
 #pragma unroll

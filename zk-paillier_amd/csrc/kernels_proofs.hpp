@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
   Grp<G> g;
   grp_init<G>(g, lds_raw);
   const uint64_t ggrp = (uint64_t)blockIdx.x * LL::GROUPS_PER_BLOCK + (threadIdx.x / G);
-  uint32_t* tab = a.table + ggrp * (uint64_t)(TAB * L);
+  uint32_t* tab = a.table + ggrp * (uint64_t)((1 << WIN_KEY) * L);
   const int kw = a.n_bits / 32;
   const int lane0 = threadIdx.x & 63;
   for (;;) {
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_ck_check(CkCheckArgs a) {
     load_value<G>(g, T, a.sigma + item * kw, kw);
     mm<G>(g, X, T);
     if constexpr (PAIR) powm_pair<G>(g, X, a.n_bits, cst, a.n + b * kw, role);
-    else powm<G, false>(g, X, a.n_bits, tab, cst, nullptr, a.n + b * kw);
+    else powm<G, false, WIN_KEY>(g, X, a.n_bits, tab, cst, nullptr, a.n + b * kw);
     load_modulus_consts<G>(g, cst);
     stage_one<G>(g);
     mm<G>(g, R, X);

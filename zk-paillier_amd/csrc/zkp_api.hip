@@ -496,7 +496,7 @@ extern "C" int32_t zkp_diag_table_traffic(zkp_ctx* c, int32_t mode, int32_t pass
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (out_bytes) *out_bytes = (uint64_t)blocks * (256 / G) * TAB * Geo<G>::L * sizeof(uint32_t) * (uint64_t)passes;
+  if (out_bytes) *out_bytes = (uint64_t)blocks * (256 / G) * TABS * Geo<G>::L * sizeof(uint32_t) * (uint64_t)passes;
   return ZKP_OK;
 } ZKP_CATCH(c)
 
