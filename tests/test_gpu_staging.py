@@ -40,3 +40,17 @@ def test_staging_cache_does_not_grow_with_the_number_of_shapes(zkp):
         ctx.release_staging()
     finally:
         ctx.close()
+
+
+def test_diag_table_traffic_moves_the_bytes_it_reports(zkp):
+    """zkp_diag_table_traffic: the calibration aid of profiles/collect_pmc.sh (a known number of bytes in the ladders' table access
+    pattern) — here only that it runs in both modes and reports resident groups x 32 entries x 576 B x passes"""
+    ctx = zkp.Context(0)
+    try:
+        rd = ctx.diag_table_traffic(0, 2)
+        wr = ctx.diag_table_traffic(1, 3)
+        assert rd > 0 and rd % (32 * 576 * 2) == 0 and wr * 2 == rd * 3
+        with pytest.raises(zkp.ZkpError):
+            ctx.diag_table_traffic(2, 1)
+    finally:
+        ctx.close()
