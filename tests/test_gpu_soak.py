@@ -12,7 +12,7 @@ import time
 import numpy as np
 import pytest
 
-import helpers as H
+import helpers as H  # noqa: F401  (puts the repo root and tests/ on sys.path)
 from helpers import pm, L
 import soak_gpu
 import soak_gpu_proofs

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-import helpers as H
+import helpers as H  # noqa: F401  (puts the repo root and tests/ on sys.path)
 from helpers import pm, L
 
 pytestmark = pytest.mark.gpu

@@ -9,11 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 src = os.path.join(ROOT, "zk-paillier_amd", "csrc", "microbench", "mad_sustained.hip")
 exe = "/tmp/mad_sustained"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", src, "-o", exe])
-freq = power = None
-for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
-    # the GPU that is visible to this container is the one whose clock moves; pick by a short probe below
-    pass
-cands = [h for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.exists(os.path.join(h, "freq1_input"))]
+# sysfs hwmon of the GPU this process sees as device 0 (the box exposes the hwmon of every GPU of its node): by PCI bus id
 import ctypes
 hip = ctypes.CDLL("libamdhip64.so"); buf = ctypes.create_string_buffer(64)
 assert hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0
