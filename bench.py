@@ -294,7 +294,7 @@ def parse_args(argv=None):
     ap.add_argument("--ck-batch", type=int, default=65536, help="keys IN ALL of the NiCorrectKeyProof leg (configs[3]); 0 = skip")
     ap.add_argument("--interactive-batch", type=int, default=4096, help="proofs IN ALL of the interactive RangeProof leg (error factor 40, benches/all.rs:10-53); 0 = skip")
     ap.add_argument("--no-pcie-leg", action="store_true")
-    ap.add_argument("--pmc-shape", choices=["enc2048", "enc2048keys", "enc4096", "ck2048", "enc2048full", "tabread"], default=None,
+    ap.add_argument("--pmc-shape", choices=["enc2048", "enc2048keys", "enc4096", "enc4096b1024", "ck2048", "ck2048full", "enc2048full", "tabread"], default=None,
                     help="run ONE short launch shape only (for rocprofv3 --pmc passes, profiles/collect_pmc.sh)")
     return ap.parse_args(argv)
 
@@ -827,10 +827,10 @@ def run_pmc_shape(args, ctx, synth, torch, dev, sync):
         kms, launches, _ = ctx.timing_get()
         print(json.dumps({"pmc_shape": shape, "bytes_read_by_launch_1": rd, "bytes_written_by_launch_2": wr, "kernel": "k_table_traffic<4>", "launches": launches, "ms": kms}))
         return
-    if shape in ("enc2048", "enc2048keys", "enc4096", "enc2048full"):
-        nb = 4096 if shape == "enc4096" else 2048
-        Bx = 128 if shape == "enc4096" else (4096 if shape == "enc2048full" else 512)
-        nkey = synth.bench_key_4096()[2] if shape == "enc4096" else (synth.distinct_keys_2048(Bx) if shape == "enc2048keys" else synth.BENCH_N)
+    if shape in ("enc2048", "enc2048keys", "enc4096", "enc4096b1024", "enc2048full"):
+        nb = 4096 if shape.startswith("enc4096") else 2048
+        Bx = {"enc4096": 128, "enc4096b1024": 1024, "enc2048full": 4096}.get(shape, 512)
+        nkey = synth.bench_key_4096()[2] if nb == 4096 else (synth.distinct_keys_2048(Bx) if shape == "enc2048keys" else synth.BENCH_N)
         pbx, wtx = synth.synth_range_inputs(nkey, nb, Bx, seed=5, device=dev)
         sync()
         ctx.paillier_enc(nb, Bx, pbx.n, 0 if isinstance(nkey, int) else nb // 32, wtx.x, wtx.r, pbx.ciphertext); sync()
@@ -842,7 +842,7 @@ def run_pmc_shape(args, ctx, synth, torch, dev, sync):
         print(json.dumps({"pmc_shape": shape, "verify_launch_modexps": me, "verify_launch_ms": kms, "all_modexps_of_the_kernel": me + Bx + 2 * Bx * 128,
                           "all_accepted": bool((v == 1).all().item())}))
     else:
-        Bk, kwk = 8192, 64
+        Bk, kwk = (65536 if shape == "ck2048full" else 8192), 64
         g = torch.Generator(device=dev); g.manual_seed(7)
         nk = torch.randint(-2**31, 2**31 - 1, (Bk, kwk), dtype=torch.int32, device=dev, generator=g); nk[:, 0] |= 1; nk[:, -1] |= -2**31
         sg = torch.randint(-2**31, 2**31 - 1, (Bk, 11, kwk), dtype=torch.int32, device=dev, generator=g); sg[:, :, -1] &= 0x3FFFFFFF
