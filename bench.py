@@ -43,6 +43,8 @@ sys.path.insert(0, ROOT)
 # instruction takes 4.68 cycles per wavefront per SIMD — the figure is a property of the pipe, not of a throttled clock.  The
 # engine's kernels draw more power (random operands, LDS, DPP: 1.34 kW) and hold 2.2-2.3 GHz, so `roofline` also reports the
 # pipe's rate AT THE CLOCK SAMPLED DURING THE RUN and the fraction of it that the EXECUTED multiply-adds fill.
+# (The same pure loop with RANDOM operands — csrc/microbench/mad_random_operands.hip — is held at 2.24 GHz too and reaches 2.84e13:
+# multiplying data that toggles costs the clock; profiles/r03/mad_random_operands_with_clock_r03.jsonl.)
 # Kernels of 16 ms read 3.474e13 (profiles/valu_rates_long_r01.jsonl; round 1 used that figure).
 PEAK_LIMB_MAC_PER_S = 3.361e13
 PEAK_LIMB_MAC_PER_S_16MS_KERNELS = 3.474e13

@@ -6,8 +6,9 @@ every kernel: lane-MAD/s, the mean clock during the kernel, and cycles per wave 
 import glob, json, os, subprocess, sys, threading, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src = os.path.join(ROOT, "zk-paillier_amd", "csrc", "microbench", "mad_sustained.hip")
-exe = "/tmp/mad_sustained"
+name = sys.argv[1] if len(sys.argv) > 1 else "mad_sustained"          # or: mad_random_operands
+src = os.path.join(ROOT, "zk-paillier_amd", "csrc", "microbench", name + ".hip")
+exe = "/tmp/" + name
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", src, "-o", exe])
 # sysfs hwmon of the GPU this process sees as device 0 (the box exposes the hwmon of every GPU of its node): by PCI bus id
 import ctypes
