@@ -48,6 +48,10 @@ sys.path.insert(0, ROOT)
 # Kernels of 16 ms read 3.474e13 (profiles/valu_rates_long_r01.jsonl; round 1 used that figure).
 PEAK_LIMB_MAC_PER_S = 3.361e13
 PEAK_LIMB_MAC_PER_S_16MS_KERNELS = 3.474e13
+# csrc/microbench/mad_operand_order.hip: the pure loop with the ENGINE's operand pattern — random 29-bit limbs, one multiplicand fixed for
+# runs of 4 / 16 instructions — is held at 2.22-2.24 GHz and 1.28-1.30 kW and issues 3.07-3.17e13 lane-MAD/s (profiles/r03/mad_operand_order_r03.jsonl):
+# the roofline of a kernel that multiplies data of this kind on this board
+PEAK_LIMB_MAC_PER_S_ENGINE_LIKE_OPERANDS = 3.12e13
 MAD_CYCLES_PER_WAVE_INSTR = 4.68          # v_mad_u64_u32 per wavefront per SIMD, measured at a sampled 2.395 GHz
 MAD_PEAK_CLOCK_GHZ = 2.395                # the clock the sustained peak was measured at
 
@@ -423,6 +427,8 @@ def main():
             out["mad_pipe_rate_at_sampled_clock"] = mad_pipe_rate(clock["mean_ghz"]) / 1e12
             out["frac_vs_mad_pipe_at_sampled_clock"] = ach / mad_pipe_rate(clock["mean_ghz"])
             if executed_per_enc:
+                out["peak_engine_like_operands"] = PEAK_LIMB_MAC_PER_S_ENGINE_LIKE_OPERANDS / 1e12
+                out["executed_mads_over_peak_engine_like_operands"] = modexps * executed_per_enc / (kms * 1e-3) / PEAK_LIMB_MAC_PER_S_ENGINE_LIKE_OPERANDS
                 out["executed_lane_mads_per_enc"] = executed_per_enc
                 out["executed_mads_over_mad_pipe_at_sampled_clock"] = modexps * executed_per_enc / (kms * 1e-3) / mad_pipe_rate(clock["mean_ghz"])
                 out["executed_note"] = ("multiply-adds the kernel really issues (squarings at 3/4 of a product, 29-bit limbs) over what the v_mad_u64_u32 pipe can issue at the "
