@@ -165,7 +165,11 @@ constexpr uint64_t COL_FAST_SN_LIMIT = ((~0ull) - (1ull << 36) - ((1ull << LB) +
 // the quotient digit is then just the low limb of the bottom column, one multiply less per sub-step.  The
 // result is correct modulo M (not reduced below M~): used inside exponentiation ladders only.
 // SAFE: see "column capacity" above (no effect for W <= 31).
-template <int G, bool ORUP = false, bool SAFE = true>
+// SCHED_FENCE > 0: a scheduling barrier every SCHED_FENCE sub-steps.  The machine scheduler runs the quotient-digit chain several
+// sub-steps ahead of the bulk of the multiply-adds; in the loop of the sliding-window ladder, next to the squaring body, that look-ahead
+// cost 11 (G = 4) / 27 (G = 8) scratch accesses per block of the product.  Fenced every 12 sub-steps the block holds one, and the
+// shared-key kernels gain 0.5 % (n = 2048) / 1.6 % (n = 4096) — the fixed-window ladder loses 1.4 % with it and stays unfenced.
+template <int G, bool ORUP = false, bool SAFE = true, int SCHED_FENCE = 0>
 __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W], const uint32_t* ldsB,
                                         const uint32_t (&N)[W], uint32_t n1, int gl) {
   uint64_t c[W];
@@ -177,6 +181,7 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
   for (int s = 0; s < G; s++) {
 #pragma unroll
     for (int t = 0; t < W; t++) {
+      if constexpr (SCHED_FENCE > 0) { if (t % SCHED_FENCE == 0 && t) __builtin_amdgcn_sched_barrier(0); }
       const uint32_t b = ldsB[s * BLK + t];
 #pragma unroll
       for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)A[k] * b;

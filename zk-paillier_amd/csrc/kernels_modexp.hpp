@@ -177,9 +177,9 @@ template <int G, class LL> __device__ __forceinline__ void canonical_words(const
 // in-place product on the Orup multiple: X = X * B() / R.  SAFE selects the column handling (bigint29.hpp "column capacity"):
 // the fast product is exact whenever the key's M~ passed the digit-sum test of k_setup (ConstLayout::OFF_ST + 1).
 // TWO (latency engine): NT is the 58-bit multiple and the product takes two quotient digits per chain step (bigint29.hpp: montmul2)
-template <int G, bool SAFE, bool TWO = false, class LL> __device__ __forceinline__ void mmo_ip(const Grp<G, LL>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
+template <int G, bool SAFE, bool TWO = false, int SCHED_FENCE = 0, class LL> __device__ __forceinline__ void mmo_ip(const Grp<G, LL>& g, const uint32_t (&NT)[W], uint32_t (&X)[W]) {
   if constexpr (TWO) montmul2<G>(X, X, g.B(), NT, g.gl);
-  else montmul<G, true, SAFE>(X, X, g.B(), NT, 1u, g.gl);
+  else montmul<G, true, SAFE, SCHED_FENCE>(X, X, g.B(), NT, 1u, g.gl);
 }
 // in-place SQUARING on the Orup multiple: X = X * X / R with B() == the staged copy of X (bigint29.hpp: montsqr, 3/4 of the
 // multiply-adds of a product; bigint29.hpp: montsqr2 for the latency engine's double-digit product).  Ladders of the fast
@@ -336,7 +336,8 @@ __device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[
     }
     const int type = op >> 5, e = op & 31;
     if (type == (OP_MUL >> 5) || type == (OP_FIRST >> 5)) load_limbs_global<G>(X, tab + e * L, g.gl);   // B() still holds the running value
-    if (type != (OP_FIRST >> 5)) mmo_ip<G, SAFE, TWO>(g, NT, X);   // (the one squaring X0 * X0 of the table build takes the product too)
+    // (the one squaring X0 * X0 of the table build takes the product too; the fence: bigint29.hpp montmul, W = 36 fast product only)
+    if (type != (OP_FIRST >> 5)) mmo_ip<G, SAFE, TWO, (COL_NEEDS_CARE && !SAFE) ? 12 : 0>(g, NT, X);
     if (type == (OP_TAB >> 5)) store_limbs_global<G>(tab + e * L, X, g.gl);
     else stageB<G>(g, X);
     if (type == (OP_SQ0 >> 5)) load_limbs_global<G>(X, tab, g.gl);
