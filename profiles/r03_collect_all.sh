@@ -1,17 +1,18 @@
 #!/bin/bash
 # Round-3 PMC evidence in one go (run on the GPU box from the repo root): bash profiles/r03_collect_all.sh [libtag]
 #   1. tabread: calibration of FETCH_SIZE / WRITE_SIZE on a known number of bytes in the table access pattern
-#   2. the dominant kernels at their bench shapes (enc2048full = B 4096, the FULL headline shape)
-#   3. aggregation with the calibrated factors and the effective clock -> gpurun_out/pmc_r03/*.json (copy into profiles/)
+#   2. the dominant kernels at LONG launch shapes (enc2048full = B 4096, the full headline shape; 1024 proofs at n = 4096; 65 536 keys):
+#      short launches count the idle tail of the grid as cycles
+#   3. aggregation with the calibrated factors and the effective clock -> gpurun_out/pmc_r03_<tag>/*.json (copy into profiles/)
 TAG=${1:-final}
 OUT=gpurun_out/pmc_r03_$TAG
 mkdir -p $OUT
-for shape in tabread enc2048full enc2048keys enc4096 ck2048; do
+for shape in tabread enc2048full enc2048keys enc4096b1024 ck2048full; do
   bash profiles/collect_pmc.sh $shape $OUT/$shape > $OUT/collect_$shape.log 2>&1
 done
 python profiles/aggregate_pmc.py --calibrate $OUT/tabread > $OUT/r03_pmc_calibration.json
 python profiles/aggregate_pmc.py $OUT/enc2048full "k_enc<4, true" --calib $OUT/r03_pmc_calibration.json > $OUT/r03_pmc_${TAG}_enc2048_shared_b4096.json
 python profiles/aggregate_pmc.py $OUT/enc2048keys "k_enc<4, false" --calib $OUT/r03_pmc_calibration.json > $OUT/r03_pmc_${TAG}_enc2048_keys.json
-python profiles/aggregate_pmc.py $OUT/enc4096 "k_enc<8, true" --calib $OUT/r03_pmc_calibration.json > $OUT/r03_pmc_${TAG}_enc4096.json
-python profiles/aggregate_pmc.py $OUT/ck2048 "k_ck_check<2" --calib $OUT/r03_pmc_calibration.json > $OUT/r03_pmc_${TAG}_ck2048.json
+python profiles/aggregate_pmc.py $OUT/enc4096b1024 "k_enc<8, true" --calib $OUT/r03_pmc_calibration.json > $OUT/r03_pmc_${TAG}_enc4096_b1024.json
+python profiles/aggregate_pmc.py $OUT/ck2048full "k_ck_check<2" --calib $OUT/r03_pmc_calibration.json > $OUT/r03_pmc_${TAG}_ck2048_b65536.json
 ls -la $OUT/*.json
