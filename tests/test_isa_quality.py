@@ -34,6 +34,8 @@ def hot_blocks(text, kernel):
                     reason="no device assembly beside the built library (run __graft_entry__.build())")
 def test_product_loops_of_the_ladders_are_free_of_scratch_accesses():
     text = open(ISA).read()
+    for extra in ("isa_keys_enc.s", "isa_keys_ck.s"):          # the translation units of the per-item-exponent kernels (zkp_kernels_keys.hip)
+        text += open(os.path.join(os.path.dirname(ISA), extra)).read()
     # (kernel, most scratch accesses tolerated in the squaring block, ... in the ladder's product block)
     for kernel, sq_max, mul_max in (("k_enc<4, true, false>", 0, 2), ("k_enc<4, false, false>", 0, 0), ("k_ck_check<2, false>", 0, 0),
                                     ("k_enc<8, true, false>", 0, 2), ("k_modexp<4, false, false, false>", 0, 0), ("k_modexp<2, false, false, false>", 0, 0)):

@@ -24,6 +24,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// (kernels that are not templates are defined in the headers under #ifndef ZKP_TEMPLATE_KERNELS_ONLY: a translation unit that only
+// instantiates template kernels — zkp_kernels_keys.hip — leaves them out, the one copy that is launched is the one of zkp_api.hip)
+
 namespace zkp {
 
 #ifndef ZKP_W

@@ -285,6 +285,7 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
 constexpr uint8_t OP_END = 0xFF, OP_ZERO = 0xFE, OP_FIRST = 0x80, OP_MUL = 0x40, OP_TAB = 0x20, OP_SQ0 = 0x60;
 constexpr int SCHED_BYTES_PER_EXP_BIT = 2, SCHED_EXTRA_BYTES = 128;
 
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int exp_bits, uint8_t* __restrict__ ops) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   auto bit = [&](int i) -> int { return (int)((exp_words[i >> 5] >> (i & 31)) & 1u); };
@@ -309,6 +310,7 @@ __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int e
   }
   ops[n] = OP_END;
 }
+#endif
 
 template <int G, bool SAFE, bool TWO = false, class LL>
 __device__ __forceinline__ void powm_sliding(const Grp<G, LL>& g, uint32_t (&X)[W], const uint8_t* __restrict__ ops, uint32_t* tab, const uint32_t* cst) {

@@ -60,6 +60,7 @@ __device__ __forceinline__ void hash_stage_value(uint32_t* tile, int row_stride,
   wave_lds_fence();
 }
 
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(HASH_PROOFS) k_range_hash(RangeHashArgs a) {
   extern __shared__ __align__(16) uint32_t hash_lds[];
   const int lane = threadIdx.x;
@@ -118,6 +119,7 @@ __global__ void __launch_bounds__(HASH_PROOFS) k_range_hash(RangeHashArgs a) {
   uint32_t carry = 0;
   for (uint32_t w = 0; w < a.kw; w++) { const uint32_t v = t1[w]; t2[w] = (v << 1) | carry; carry = v >> 31; }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // The same challenge, ONE WAVEFRONT PER PROOF: for calls of a few proofs, where the one-lane-per-proof kernel above leaves 63
@@ -265,6 +267,7 @@ struct WaveSha {
   }
 };
 
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(64) k_range_hash_wave(RangeHashArgs a) {
   extern __shared__ __align__(16) uint32_t hash_lds[];
   const int lane = threadIdx.x;
@@ -316,6 +319,7 @@ __global__ void __launch_bounds__(64) k_range_hash_wave(RangeHashArgs a) {
   uint32_t carry = 0;
   for (uint32_t w = 0; w < a.kw; w++) { const uint32_t v = t1[w]; t2[w] = (v << 1) | carry; carry = v >> 31; }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Verify planning: one thread per (proof, row).  Applies the kind/bit match and the range
@@ -334,6 +338,7 @@ struct VerifyPlanArgs {
 // in front of an almost empty GPU: e == nullptr builds the work list from the response kinds alone (an Open row always costs
 // two Enc checks, a Mask row one; rows whose kind contradicts the challenge bit reject the proof whatever their Encs say), so
 // that k_enc can start while the hash runs on a second stream; item_proof == nullptr applies the predicates only.
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(256) k_verify_plan(VerifyPlanArgs a) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const bool in = t < a.batch * a.ef;
@@ -381,6 +386,7 @@ __global__ void __launch_bounds__(256) k_verify_plan(VerifyPlanArgs a) {
     a.item_row[base + before + k] = (i << 1) | k;
   }
 }
+#endif
 
 // Joins the two strands of a small verify call: verdict[] holds what the hash + predicate strand decided, enc_verdict[] what
 // the Enc checks of the kind-derived work list found.  The result is what the one-stream sequence writes: a failed Enc check
@@ -389,6 +395,7 @@ __global__ void __launch_bounds__(256) k_verify_plan(VerifyPlanArgs a) {
 struct VerdictMergeArgs {
   uint8_t* verdict; const uint8_t* enc_verdict; const uint8_t* e; const uint8_t* resp_kind; uint32_t ef; uint64_t batch;
 };
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(256) k_verdict_merge(VerdictMergeArgs a) {
   const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= a.batch) return;
@@ -402,6 +409,7 @@ __global__ void __launch_bounds__(256) k_verdict_merge(VerdictMergeArgs a) {
   }
   if (any) a.verdict[b] = ZKP_VERDICT_MALFORMED;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Prove: generate_proof (range_proof.rs:210-252), one group (n context) per (proof, row).
@@ -500,6 +508,7 @@ struct CkHashArgs {
 
 __device__ __forceinline__ void sha_put_u32_as_bigint(Sha256& s, uint32_t v) { s.put_bigint(&v, 1); }
 
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(256) k_ck_hash(CkHashArgs a) {
   __shared__ uint32_t shabuf[16 * 256];
   const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -560,9 +569,11 @@ __global__ void __launch_bounds__(256) k_ck_hash(CkHashArgs a) {
   }
   a.verdict[b] = coprime ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
 }
+#endif
 
 // The same per key on ONE WAVEFRONT, for calls of a few keys (one thread per key spends ~12 ms, mostly in the 830 trial
 // divisions): lane i < 11 derives rho_i (its seed hash and mask blocks), and all 64 lanes share the primes.
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(64) k_ck_hash_wave(CkHashArgs a) {
   __shared__ uint32_t shabuf[16 * 64];
   const uint64_t b = blockIdx.x;
@@ -620,6 +631,7 @@ __global__ void __launch_bounds__(64) k_ck_hash_wave(CkHashArgs a) {
   const bool all = __all(coprime);
   if (lane == 0) a.verdict[b] = all ? ZKP_VERDICT_ACCEPT : ZKP_VERDICT_REJECT;
 }
+#endif
 
 // (2) one group (n context) per (proof, i): sigma_i^n mod n  ==  mask_generation(..) mod n  (:84,:92,:95)
 struct CkCheckArgs {
@@ -733,6 +745,7 @@ struct DlogHashArgs {
 };
 
 constexpr int DLOG_THREADS = 64;
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(DLOG_THREADS) k_dlog_hash(DlogHashArgs a) {
   extern __shared__ __align__(16) uint32_t dlog_lds[];   // [16][64] SHA block buffers | [2*kw][64] gcd operands
   uint32_t* shabuf = dlog_lds;
@@ -787,9 +800,11 @@ __global__ void __launch_bounds__(DLOG_THREADS) k_dlog_hash(DlogHashArgs a) {
     }
   }
 }
+#endif
 
 // final comparison x ==? g^y * ni^e mod N (:83-90): plain word compare, only ACCEPT can be downgraded
 struct DlogCmpArgs { const uint32_t* x; const uint32_t* t; const uint32_t* consts; uint64_t const_stride; int st_off; uint32_t kw; uint64_t batch; uint8_t* verdict; };
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(256) k_dlog_compare(DlogCmpArgs a) {
   const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= a.batch) return;
@@ -799,6 +814,7 @@ __global__ void __launch_bounds__(256) k_dlog_compare(DlogCmpArgs a) {
   if (a.consts[b * a.const_stride + a.st_off] != 0) { a.verdict[b] = ZKP_VERDICT_MALFORMED; return; }
   if (!same) a.verdict[b] = ZKP_VERDICT_REJECT;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // ZeroProof / CiphertextProof (zero_enc_proof.rs:44-94, correct_ciphertext.rs:42-97):
@@ -811,6 +827,7 @@ struct SigmaHashArgs {
   const uint32_t* x; const uint32_t* x_prime; uint32_t* z1; uint32_t z1w;   // nullable
 };
 
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(256) k_sigma_hash(SigmaHashArgs a) {
   __shared__ uint32_t shabuf[16 * 256];
   const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -841,6 +858,7 @@ __global__ void __launch_bounds__(256) k_sigma_hash(SigmaHashArgs a) {
     }
   }
 }
+#endif
 
 // VerlinProof challenge e = H(n || c || c' || phi_x || phi_a) (verlin_proof.rs:78-84, 102-108) and, for prove,
 // the three integer responses z = x e + a (:85-87).
@@ -849,6 +867,7 @@ struct VerlinHashArgs {
   uint32_t kw; uint64_t batch; uint32_t* e;
   const uint32_t* x[3]; const uint32_t* a[3]; uint32_t* z[3]; uint32_t zw;   // nullable
 };
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(256) k_verlin_hash(VerlinHashArgs a) {
   __shared__ uint32_t shabuf[16 * 256];
   const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -878,9 +897,11 @@ __global__ void __launch_bounds__(256) k_verlin_hash(VerlinHashArgs a) {
     }
   }
 }
+#endif
 
 // verdict[b] = (lhs[b] == rhs[b]) word for word (`c_z == c_z_test`, zero_enc_proof.rs:90, correct_ciphertext.rs:93)
 struct WordsCmpArgs { const uint32_t* lhs; const uint32_t* rhs; const uint32_t* consts; uint64_t const_stride; int st_off; uint32_t words; uint64_t batch; uint8_t* verdict; };
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void __launch_bounds__(256) k_words_compare(WordsCmpArgs a) {
   const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= a.batch) return;
@@ -890,5 +911,6 @@ __global__ void __launch_bounds__(256) k_words_compare(WordsCmpArgs a) {
   if (a.consts[b * a.const_stride + a.st_off] != 0) v = ZKP_VERDICT_MALFORMED;   // even key: Montgomery path undefined
   a.verdict[b] = v;
 }
+#endif
 
 }  // namespace zkp

@@ -288,6 +288,14 @@ struct TimedRegion {
 // ---- geometry helpers -----------------------------------------------------------------------
 // lanes per big integer: 72 / 144 / 288 limbs of 29 bits over W limbs per lane
 constexpr int GA = 72 / W, GB = 144 / W, GC = 288 / W;
+#ifdef ZKP_SPLIT_TU
+// compiled in zkp_kernels_keys.hip under another machine-scheduler strategy (see there); launched from here
+extern template __global__ void zkp::k_enc<GA, false, false>(EncArgs);
+extern template __global__ void zkp::k_enc<GB, false, false>(EncArgs);
+extern template __global__ void zkp::k_enc<GC, false, false>(EncArgs);
+extern template __global__ void zkp::k_ck_check<GA, false>(CkCheckArgs);
+extern template __global__ void zkp::k_ck_check<GB, false>(CkCheckArgs);
+#endif
 static int group_for_bits(uint32_t mod_bits) { return mod_bits <= 2048 ? GA : mod_bits <= 4096 ? GB : mod_bits <= 8192 ? GC : 0; }
 
 template <int G, class K> static int resident_blocks(zkp_ctx* c, K kernel) {
