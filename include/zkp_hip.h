@@ -96,10 +96,7 @@ int32_t zkp_ctx_release_staging(zkp_ctx* ctx);
  * number of modular exponentiations those launches performed. */
 int32_t zkp_timing_reset(zkp_ctx* ctx, int32_t enable);
 int32_t zkp_timing_get(zkp_ctx* ctx, double* out_ms, uint64_t* out_launches, uint64_t* out_modexps);
-/* Diagnostic: moves a KNOWN number of bytes in the access pattern of the ladders' window tables — every lane of the resident
- * grid reads (mode 0) or writes (mode 1) its block of each entry of its table slot, `passes` times — so that the HBM-side PMC
- * counters behind the roofline's `traffic` figure can be calibrated (profiles/collect_pmc.sh).  out_bytes = bytes moved. */
-int32_t zkp_diag_table_traffic(zkp_ctx* ctx, int32_t mode, int32_t passes, uint64_t* out_bytes);
+/* (Profiler calibration aids are NOT part of this boundary: include/zkp_hip_diag.h.) */
 
 /* ------------------------------------------------------------------ L1 primitives
  * out[i] = base[i]^exp[i] mod mod[i].

@@ -181,6 +181,72 @@ def range_ni_verify(proof, n, ciphertext) -> bool:
                            proof["ciphertext"], proof["error_factor"])
 
 
+# ----------------------------------------------------------------------------- signed, arbitrary-precision values
+# A deserialised proof holds attacker-chosen BigInts of any size and either sign (decimal strings with a leading '-',
+# serialize.rs:8-31).  The functions above assume the honest domain; these restate the reference's operators on ANY integers:
+#   Rust `%` on BigInt            -> truncated remainder, sign of the dividend          [upstream, recalled]  (tdiv_r)
+#   BigInt::mod_pow               -> mpz_powm: result in [0, m) for a negative base    [upstream, recalled]  (Python pow agrees)
+#   BigInt::to_bytes              -> the magnitude                                      [upstream, recalled]
+
+def tdiv_r(a: int, m: int) -> int:
+    """a % m as Rust's BigInt does it (mpz_tdiv_r): |a| mod |m| with the sign of a"""
+    r = abs(a) % abs(m)
+    return -r if a < 0 else r
+
+
+def enc_signed(n: int, m: int, r: int) -> int:
+    """kzen-paillier's Enc on any integers m, r (n > 0): rn = mod_pow(r, n, nn); gm = (m*n + 1) % nn; c = gm*rn % nn"""
+    nn = n * n
+    rn = pow(r, n, nn)
+    gm = tdiv_r(m * n + 1, nn)
+    return tdiv_r(gm * rn, nn)
+
+
+def to_bytes_magnitude(x: int) -> bytes:
+    return to_bytes(abs(x))
+
+
+def fs_challenge_signed(n, c1, c2) -> bytes:
+    h = hashlib.sha256()
+    for v in [n] + list(c1) + list(c2):
+        h.update(to_bytes_magnitude(v))
+    return to_bytes(from_bytes(h.digest()))
+
+
+def range_ni_verify_signed(n, rng_q, cipher_x, error_factor, c1, c2, responses):
+    """RangeProofNi::verify_self (range_proof_ni.rs:109-128 -> range_proof.rs:254-355) on arbitrary integers.
+    Returns True / False, or raises IndexError where the reference panics."""
+    assert n > 0
+    nn = n * n
+    e = fs_challenge_signed(n, c1, c2)
+    third = rng_q // 3              # div_floor (Python // is floored)
+    two_thirds = 2 * third
+    oks = []
+    for i in range(error_factor):
+        if i >= 8 * len(e):
+            raise IndexError("bits_of_e")
+        ei = challenge_bit(e, i)
+        resp = responses[i]
+        if (not ei) and resp[0] == "open":
+            _, w1, r1, w2, r2 = resp
+            res = enc_signed(n, w1, r1) == c1[i]
+            if enc_signed(n, w2, r2) != c2[i]:
+                res = False
+            if not ((w2 < third and third < w1 < two_thirds) or (w1 < third and third < w2 < two_thirds)):
+                res = False
+            oks.append(res)
+        elif ei and resp[0] == "mask":
+            _, j, mx, mr = resp
+            c = tdiv_r((c1[i] if j == 1 else c2[i]) * cipher_x, nn)
+            res = c == enc_signed(n, mx, mr)
+            if mx < third or mx > two_thirds:
+                res = False
+            oks.append(res)
+        else:
+            oks.append(False)
+    return all(oks)
+
+
 def sample_range_inputs(drbg: Drbg, n: int, rng_q: int, ef: int = SECURITY_PARAMETER):
     """Deterministic stand-in for range_proof.rs:133-159 (sample_range / swap / sample_below)."""
     third = rng_q // 3

@@ -457,6 +457,96 @@ int32_t oracle_range_verifier_output_batch(const zkp_range_ni_proofs* p, const u
   return range_verify_core(p, e, e_len, out_verdict);
 }
 
+/* ------------------------------------------------------------------ RangeProofNi::verify_self on SIGNED, ARBITRARY-PRECISION values
+ * Every field of a deserialised proof is an attacker-chosen curv BigInt: any size, either sign (the decimal-string serde of
+ * serialize.rs:8-31 goes through mpz_set_str, which takes a leading '-').  The fixed-width entry points above cannot even state such
+ * a proof; this one restates range_proof_ni.rs:109-128 -> range_proof.rs:254-355 over mpz_t exactly as the reference's BigInt does
+ * (SURVEY N4/N5), one proof per call, every value a decimal string:
+ *   `a * b % m` and `(m*n + 1) % nn`  -> mpz_tdiv_r (Rust `%` on BigInt: truncated, sign of the dividend) [upstream, recalled]
+ *   BigInt::mod_pow                   -> mpz_powm (result in [0, m) for a negative base)                 [upstream, recalled]
+ *   range.div_floor(3)                -> mpz_fdiv_q
+ *   comparisons / equality            -> mpz_cmp on the signed values
+ *   to_bytes in compute_digest        -> magnitude only (mpz_export ignores the sign)                    [upstream, recalled]
+ * n must be positive (ek is the verifier's own key in RangeProofNi::verify; mod_pow asserts a non-negative exponent).
+ * kind[i]: ZKP_RESP_OPEN / ZKP_RESP_MASK; f1..f4[i]: w1, r1, w2, r2 of an Open row; masked_x, masked_r, -, - of a Mask row.
+ * n_c1 / n_c2 / n_resp are the stored lengths: an index past them is the reference's panic (range_proof.rs:274,293,296).
+ * returns ZKP_VERDICT_*; -1 when a string does not parse. */
+static int set_dec(mpz_t z, const char* s) { return s && mpz_set_str(z, s, 10) == 0; }
+int32_t oracle_range_ni_verify_decimal(const char* n_s, const char* range_s, const char* cipher_s, uint32_t error_factor,
+                                       const char* const* c1_s, uint32_t n_c1, const char* const* c2_s, uint32_t n_c2,
+                                       const uint8_t* kind, const uint8_t* j, const char* const* f1, const char* const* f2,
+                                       const char* const* f3, const char* const* f4, uint32_t n_resp, uint8_t* out_e, uint8_t* out_e_len) {
+  mpz_t zn, znn, cx, third, two_thirds, w1, r1, w2, r2, c, ex, u, z;
+  mpz_inits(zn, znn, cx, third, two_thirds, w1, r1, w2, r2, c, ex, u, z, NULL);
+  int32_t verdict = ZKP_VERDICT_ACCEPT;
+  if (!set_dec(zn, n_s) || !set_dec(z, range_s) || !set_dec(cx, cipher_s) || mpz_sgn(zn) <= 0) { verdict = -1; goto done; }
+  mpz_mul(znn, zn, zn);
+  mpz_fdiv_q_ui(third, z, 3);       /* range.div_floor(3), range_proof.rs:264 */
+  mpz_mul_ui(two_thirds, third, 2); /* :265 */
+  { /* e = to_bytes(compute_digest(n, c1.., c2..)) over ALL stored elements (range_proof_ni.rs:110-113) */
+    sha256_t s; uint8_t d[32];
+    sha256_init(&s);
+    hash_mpz(&s, zn);
+    for (uint32_t i = 0; i < n_c1; i++) { if (!set_dec(z, c1_s[i])) { verdict = -1; goto done; } hash_mpz(&s, z); }
+    for (uint32_t i = 0; i < n_c2; i++) { if (!set_dec(z, c2_s[i])) { verdict = -1; goto done; } hash_mpz(&s, z); }
+    sha256_final(&s, d);
+    uint32_t lead = 0;
+    while (lead < 31 && d[lead] == 0) lead++;
+    uint8_t e[32] = {0};
+    uint32_t elen = 32 - lead;
+    memcpy(e, d + lead, elen);
+    if (out_e) memcpy(out_e, e, 32);
+    if (out_e_len) *out_e_len = (uint8_t)elen;
+    for (uint32_t i = 0; i < error_factor; i++) { /* no early exit: a later row may still panic (par_iter + collect, :270-348) */
+      if (i >= elen * 8 || i >= n_resp) { verdict = ZKP_VERDICT_MALFORMED; break; } /* bits_of_e[i] / responses[i] */
+      int ei = challenge_bit(e, i), res = 1;
+      if (!set_dec(w1, f1[i]) || !set_dec(r1, f2[i])) { verdict = -1; goto done; }
+      if (!ei && kind[i] == ZKP_RESP_OPEN) { /* :277-313 */
+        if (!set_dec(w2, f3[i]) || !set_dec(r2, f4[i])) { verdict = -1; goto done; }
+        if (i >= n_c1 || i >= n_c2) { verdict = ZKP_VERDICT_MALFORMED; break; }
+        enc_mpz(c, zn, znn, w1, r1, u);
+        set_dec(ex, c1_s[i]);
+        if (mpz_cmp(c, ex) != 0) res = 0;
+        enc_mpz(c, zn, znn, w2, r2, u);
+        set_dec(ex, c2_s[i]);
+        if (mpz_cmp(c, ex) != 0) res = 0;
+        int flag = (mpz_cmp(w2, third) < 0 && mpz_cmp(w1, third) > 0 && mpz_cmp(w1, two_thirds) < 0) ||
+                   (mpz_cmp(w1, third) < 0 && mpz_cmp(w2, third) > 0 && mpz_cmp(w2, two_thirds) < 0); /* :300-305 */
+        if (!flag) res = 0;
+      } else if (ei && kind[i] == ZKP_RESP_MASK) { /* :315-343 */
+        if (j[i] == 1 ? i >= n_c1 : i >= n_c2) { verdict = ZKP_VERDICT_MALFORMED; break; }
+        set_dec(ex, j[i] == 1 ? c1_s[i] : c2_s[i]); /* any j != 1 selects c2, :324-328 */
+        mpz_mul(ex, ex, cx);
+        mpz_tdiv_r(ex, ex, znn);
+        enc_mpz(c, zn, znn, w1, r1, u); /* :330-334 */
+        if (mpz_cmp(c, ex) != 0) res = 0;
+        if (mpz_cmp(w1, third) < 0 || mpz_cmp(w1, two_thirds) > 0) res = 0; /* :338 */
+      } else {
+        res = 0; /* :345 */
+      }
+      if (!res) verdict = ZKP_VERDICT_REJECT;
+    }
+  }
+done:
+  mpz_clears(zn, znn, cx, third, two_thirds, w1, r1, w2, r2, c, ex, u, z, NULL);
+  return verdict;
+}
+
+/* The signed Enc alone: c = ((m*n + 1) % nn) * (r^n mod nn) % nn with the reference's operators, decimal in and out
+ * (out must hold the digits of nn plus sign and terminator). */
+int32_t oracle_enc_decimal(const char* n_s, const char* m_s, const char* r_s, char* out, uint64_t out_cap) {
+  mpz_t zn, znn, m, r, c, t;
+  mpz_inits(zn, znn, m, r, c, t, NULL);
+  int32_t st = -1;
+  if (set_dec(zn, n_s) && set_dec(m, m_s) && set_dec(r, r_s) && mpz_sgn(zn) > 0) {
+    mpz_mul(znn, zn, zn);
+    enc_mpz(c, zn, znn, m, r, t);
+    if (mpz_sizeinbase(c, 10) + 2 <= out_cap) { mpz_get_str(out, 10, c); st = 0; }
+  }
+  mpz_clears(zn, znn, m, r, c, t, NULL);
+  return st;
+}
+
 /* ------------------------------------------------------------------ NiCorrectKeyProof */
 
 /* utils.rs:9-22 over an array of mpz */

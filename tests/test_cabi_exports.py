@@ -21,8 +21,8 @@ def lib():
     return zkp.load()
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "zkp_hip.h")).read()
+def declared_functions(header="zkp_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(zkp_[a-z0-9_]+)\s*\(", text)))
 
@@ -34,6 +34,17 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/zkp_hip.h but not exported by libzkp_hip.so"
         assert n in zkp.EXPORTS, f"{n} has no ctypes signature in capi.EXPORTS"
     assert sorted(zkp.EXPORTS) == names
+
+
+def test_diagnostics_live_in_their_own_header(lib):
+    """the boundary header declares nothing a profiler needs; include/zkp_hip_diag.h is bound separately, symmetrically"""
+    diag = declared_functions("zkp_hip_diag.h")
+    assert diag and not set(diag) & set(declared_functions()), "a diagnostic is declared in the boundary header"
+    assert all(n.startswith("zkp_diag_") for n in diag)
+    assert not [n for n in declared_functions() if "diag" in n]
+    assert sorted(zkp.DIAG_EXPORTS) == diag
+    for n in diag:
+        assert hasattr(lib, n)
 
 
 def test_no_oracle_or_gmp_dependency(lib):

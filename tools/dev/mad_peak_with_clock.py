@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 name = sys.argv[1] if len(sys.argv) > 1 else "mad_sustained"          # or: mad_random_operands
 src = os.path.join(ROOT, "zk-paillier_amd", "csrc", "microbench", name + ".hip")
 exe = "/tmp/" + name
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", src, "-o", exe])
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-mllvm", "-pragma-unroll-threshold=200000", src, "-o", exe])
 # sysfs hwmon of the GPU this process sees as device 0 (the box exposes the hwmon of every GPU of its node): by PCI bus id
 import ctypes
 hip = ctypes.CDLL("libamdhip64.so"); buf = ctypes.create_string_buffer(64)
@@ -24,7 +24,7 @@ def sampler():
         except (OSError, ValueError): pass
         stop.wait(0.02)
 t = threading.Thread(target=sampler, daemon=True); t.start()
-p = subprocess.Popen([exe], stdout=subprocess.PIPE, text=True)
+p = subprocess.Popen([exe] + sys.argv[2:], stdout=subprocess.PIPE, text=True)
 last = time.monotonic()
 for line in p.stdout:
     now = time.monotonic()
@@ -34,6 +34,9 @@ for line in p.stdout:
     if win:
         ghz = sum(s[1] for s in win) / len(win)
         rec.update({"clock_ghz_mean": round(ghz, 4), "clock_samples": len(win), "power_w_mean": round(sum(s[2] for s in win) / len(win), 1),
-                    "cycles_per_wave_instr_per_simd_at_sampled_clock": round(ghz * 1e9 * 256 * 4 * 64 / rec["lane_mad_per_s"], 3)})
+                    "cycles_per_wave_instr_per_simd_at_sampled_clock": round(ghz * 1e9 * 256 * 4 * 64 / rec["lane_mad_per_s"], 3),
+                    "lane_mad_per_s_over_16_lanes_per_clk_per_simd": round(rec["lane_mad_per_s"] / (16 * 1024 * ghz * 1e9), 4)})
+        if "valu_instr_per_mad" in rec:
+            rec["cycles_per_valu_instr_per_simd_at_sampled_clock"] = round(rec["cycles_per_wave_instr_per_simd_at_sampled_clock"] / rec["valu_instr_per_mad"], 3)
     print(json.dumps(rec), flush=True)
 stop.set(); p.wait()

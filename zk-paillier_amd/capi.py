@@ -39,6 +39,12 @@ class RangeNiWitness(C.Structure):
                 ("r1", C.c_void_p), ("r2", C.c_void_p)]
 
 
+# include/zkp_hip_diag.h: measurement tooling, not the boundary
+DIAG_EXPORTS = {
+    "zkp_diag_table_traffic": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
+}
+
+# include/zkp_hip.h: the boundary
 EXPORTS = {
     # name: (restype, argtypes)
     "zkp_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
@@ -51,7 +57,6 @@ EXPORTS = {
     "zkp_ctx_release_staging": (C.c_int32, [C.c_void_p]),
     "zkp_timing_reset": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_timing_get": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "zkp_diag_table_traffic": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     "zkp_modexp_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                      C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
     "zkp_modmul_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -130,7 +135,7 @@ def load():
         except ImportError:
             pass
         lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in EXPORTS.items():
+        for name, (res, args) in list(EXPORTS.items()) + list(DIAG_EXPORTS.items()):
             fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/zkp_hip.h"
+#include "../../include/zkp_hip_diag.h"
 #include "kernels_modexp.hpp"
 #include "kernels_proofs.hpp"
 #include "kernels_inv.hpp"
