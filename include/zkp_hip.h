@@ -341,24 +341,37 @@ int32_t zkp_limbs_to_decimal_batch(zkp_ctx* ctx, const uint32_t* src, uint64_t s
  * space between tokens (to_string_pretty), object fields in any order, unknown fields skipped, string escapes decoded; duplicate
  * or missing fields, a Response with more than one variant key and values of the wrong JSON type are errors, as they are for serde.
  * The tokenising runs on the host (threads), every number is converted on the GPU into p->c1/c2 (pairs) or p->resp_*
- * (proof); p->error_factor rows are expected.  out_status[b]: 0, or ZKP_VERDICT_MALFORMED when document b is not of the
- * expected shape, has another row count, or holds a number the ABI cannot carry (see ZKP_DEC_*): those proofs stay on the
- * caller's CPU path.  ZKP_F_DEVICE_PTRS applies to the p-> arrays and out_status; text and offsets are host memory. */
+ * (proof); p->error_factor rows are expected.  out_status[b]:
+ *   ZKP_DOC_OK        converted;
+ *   ZKP_DOC_INVALID   document b is not a value of the expected type (serde_json::from_str is Err in Rust);
+ *   ZKP_DOC_HOST_PATH a well-formed document that this fixed layout cannot carry: a negative or over-wide integer (see ZKP_DEC_*), or
+ *                     another number of rows.  It IS a valid value of the reference's type and has a verdict there: the caller parses
+ *                     it itself (host/zkproofs.hpp: serde_json::range_proof_ni_from_str; bindings/rust: serde) and verifies it through
+ *                     the host path that handles signed integers of any size (RangeProofNi::verify_batch).  Its rows here are zero.
+ * ZKP_F_DEVICE_PTRS applies to the p-> arrays and out_status; text and offsets are host memory. */
+#define ZKP_DOC_OK 0
+#define ZKP_DOC_INVALID 2      /* == ZKP_VERDICT_MALFORMED */
+#define ZKP_DOC_HOST_PATH 3
 int32_t zkp_json_encrypted_pairs_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len,
                                        const zkp_range_ni_proofs* p, uint8_t* out_status, uint32_t flags);
 int32_t zkp_json_range_proof_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len,
                                    const zkp_range_ni_proofs* p, uint8_t* out_status, uint32_t flags);
 /* Whole RangeProofNi documents (range_proof_ni.rs:36-44): {"ek":{"n":..},"range":..,"ciphertext":..,"encrypted_pairs":{..},"proof":[..],
  * "error_factor":N} -> every field of the batch.  encrypted_pairs / proof as above.  ek, range and ciphertext are UN-annotated
- * in the reference (EncryptionKey of kzen-paillier, bare curv BigInt): their text form is fixed by crates outside the tree, so
- * `bigint_encoding` names it (a sample written by a Rust build decides, tools/reference_vectors "serde" section).  error_factor
- * must equal p->error_factor.  p->n_stride = n_bits/32: one key per proof; 0: one shared key, a document under another key is
- * malformed (RangeProofNi::verify asserts equality, :86).  Writes p->n, p->range and p->ciphertext too (inputs of the other entry
- * points, hence const in the struct).  HOST pointers only (flags must be 0). */
+ * in the reference: ek is kzen-paillier's EncryptionKey, range / ciphertext are bare curv BigInts; their text forms are fixed by crates
+ * outside the tree and need not agree with each other, so `bigint_forms` names BOTH: ZKP_BIGINT_FORMS(key_form, bare_form) (a sample
+ * written by a Rust build decides, tools/reference_vectors "serde" section).  A string that is not an integer of the named form is
+ * ZKP_DOC_INVALID — an all-digit decimal read as hex would silently be another number, which is why the two forms are separate.
+ * error_factor other than p->error_factor: ZKP_DOC_HOST_PATH.
+ * p->n_stride = n_bits/32: one key per proof, p->n receives the documents' keys (verify_self, range_proof_ni.rs:109-128).
+ * p->n_stride = 0: p->n is the VERIFIER's key, an input that is never written; a document under another key is ZKP_DOC_INVALID
+ * (RangeProofNi::verify asserts equality, :86), so no received document can change the key the others are verified under.
+ * Writes p->range and p->ciphertext (inputs of the other entry points, hence const in the struct).  HOST pointers only (flags 0). */
 #define ZKP_BIGINT_DEC 0u     /* "1234": decimal string (serialize::bigint, serialize.rs:8-33) */
 #define ZKP_BIGINT_HEX 1u     /* "04d2": hex string of the big-endian magnitude */
 #define ZKP_BIGINT_BYTES 2u   /* [4,210]: array of big-endian byte values */
-int32_t zkp_json_range_proof_ni_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len, uint32_t bigint_encoding,
+#define ZKP_BIGINT_FORMS(key_form, bare_form) (((key_form) << 4) | (bare_form))
+int32_t zkp_json_range_proof_ni_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len, uint32_t bigint_forms,
                                       const zkp_range_ni_proofs* p, uint8_t* out_status, uint32_t flags);
 /* {"sigma_vec":["..", x11]} -> sigma [B][11][n_bits/32] */
 int32_t zkp_json_correct_key_proof_batch(zkp_ctx* ctx, const char* text, const uint64_t* doc_off, const uint64_t* doc_len, uint32_t n_bits,

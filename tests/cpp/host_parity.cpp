@@ -4,8 +4,13 @@
 //   ck_challenge <n> <K> <s_0..s_K-1> <r_0..r_K-1>     -> sn_0.. e z_0.. s_digest           (correct_key.rs:64-102)
 //   ck_prove <p> <q> <e> <K> <sn_0..> <z_0..>          -> "ok <s_digest>" | "err <code 1..4>" (correct_key.rs:104-162)
 //   ck_ni_proof <p> <q>                                 -> sigma_0 .. sigma_10                 (correct_key_ni.rs:42-71)
+//   range_ni_verify_docs <file>                         -> one word per document: ok | err | panic | unsupported | serde
+//        (file: one serde_json RangeProofNi per line, every integer a decimal string, '-' allowed: serde_json::range_proof_ni_from_str,
+//         then RangeProofNi::verify_batch per run of documents under one key — canonical proofs on the fixed-width GPU path, the
+//         others through verify_general)
 // Needs a gfx950 GPU.
 #include <cstdio>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -54,6 +59,28 @@ int main() {
         BigInt p = next(), q = next();
         NiCorrectKeyProof pr = NiCorrectKeyProof::proof(DecryptionKey{p, q});
         for (size_t i = 0; i < pr.sigma_vec.size(); i++) std::printf("%s%s", hex(pr.sigma_vec[i]).c_str(), i + 1 < pr.sigma_vec.size() ? " " : "\n");
+      } else if (cmd == "range_ni_verify_docs") {
+        std::string path; in >> path;
+        std::ifstream f(path);
+        std::vector<RangeProofNi> proofs; std::vector<int> parsed;
+        std::string doc;
+        while (std::getline(f, doc)) {
+          if (doc.empty()) continue;
+          try { proofs.push_back(serde_json::range_proof_ni_from_str(doc)); parsed.push_back(1); }
+          catch (const std::runtime_error&) { proofs.emplace_back(); parsed.push_back(0); }
+        }
+        std::vector<std::string> words(proofs.size(), "serde");
+        for (size_t lo = 0; lo < proofs.size();) {
+          if (!parsed[lo]) { lo++; continue; }
+          size_t hi = lo;
+          std::vector<const RangeProofNi*> run;
+          while (hi < proofs.size() && parsed[hi] && proofs[hi].ek == proofs[lo].ek) run.push_back(&proofs[hi++]);
+          auto res = RangeProofNi::verify_batch(proofs[lo].ek, run);
+          for (size_t k = 0; k < res.size(); k++)
+            words[lo + k] = res[k].is_unsupported() ? "unsupported" : res[k].would_panic() ? "panic" : res[k].is_ok() ? "ok" : "err";
+          lo = hi;
+        }
+        for (size_t i = 0; i < words.size(); i++) std::printf("%s%s", words[i].c_str(), i + 1 < words.size() ? " " : "\n");
       } else {
         std::printf("unknown command\n");
       }

@@ -201,9 +201,36 @@ def next_rows():
     return out
 
 
+def signed_cases():
+    """RangeProofNi documents with negative / over-wide fields: verdicts from oracle/py_model.range_ni_verify_signed,
+    asserted equal to the C/GMP restatement over mpz (oracle_range_ni_verify_decimal) before they are written.  The documents are
+    rebuilt from seeds by tests/signed_cases.py (its SHA-256 is pinned here); signed Enc known answers are stored in full."""
+    import signed_cases as S
+    n = H.test_key(S.N_BITS)[2]
+    d = pm.Drbg(b"golden-signed-enc")
+    pairs = [(-1, 1), (-1, d.below(n)), (-d.bits(256), d.below(n)), (d.bits(256), -d.below(n)), (-d.bits(256), -d.below(n)), (-n, d.below(n)),
+             (-(n << 40) - 5, (n << 9) + 3), (7, 0), (-7, 0), (-3, n), (0, -1)]
+    enc = []
+    for m, r in pairs:
+        c = pm.enc_signed(n, m, r)
+        assert c == oracle.enc_decimal(n, m, r)
+        enc.append(dict(m=str(m), r=str(r), c=str(c)))
+    cases = []
+    for name in S.MUTATIONS:
+        proof, picked = S.build(name, oracle)
+        verdict = S.model_verdict(proof)
+        vo, e = oracle.range_ni_verify_decimal(proof)
+        assert vo == verdict, (name, vo, verdict)
+        cases.append(dict(name=name, seed="signed-" + name, n_bits=S.N_BITS, picked=picked, verdict=verdict, challenge=e.hex(), sha256_of_document=S.sha_doc(proof)))
+    return dict(note="verdicts of RangeProofNi::verify_self as the reference's BigInt operators give them [upstream semantics recalled, parity unpinned]: "
+                     "`%` truncated, mod_pow in [0, m), to_bytes = magnitude", n=str(n), enc_signed=enc, cases=cases)
+
+
 def main():
-    files = dict(modexp_kat=modexp_kats(), enc_kat=enc_kats(), digest_kat=digest_kats(), range_ni_transcripts=range_transcripts(),
-                 correct_key_ni=correct_key(), dlog=dlog(), next_rows=next_rows())
+    only = sys.argv[1:]
+    makers = dict(modexp_kat=modexp_kats, enc_kat=enc_kats, digest_kat=digest_kats, range_ni_transcripts=range_transcripts,
+                  correct_key_ni=correct_key, dlog=dlog, next_rows=next_rows, signed_cases=signed_cases)
+    files = {k: f() for k, f in makers.items() if not only or k in only}
     for name, obj in files.items():
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(obj, f, indent=1)

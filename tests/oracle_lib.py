@@ -41,6 +41,33 @@ class Oracle:
         self.lib.oracle_sha256(data, C.c_uint64(len(data)), out)
         return bytes(out)
 
+    def range_ni_verify_decimal(self, proof):
+        """RangeProofNi::verify_self on signed integers of any size (oracle_range_ni_verify_decimal: mpz over decimal strings).
+        proof: dict(n, range, ciphertext, error_factor, c1, c2, responses) of python ints -> ("ok" | "err" | "panic", challenge bytes)"""
+        def arr(vals):
+            a = (C.c_char_p * max(1, len(vals)))()
+            for i, v in enumerate(vals):
+                a[i] = str(v).encode()
+            return a
+        R = proof["responses"]
+        kind = (C.c_uint8 * max(1, len(R)))(*[0 if r[0] == "open" else 1 for r in R])
+        j = (C.c_uint8 * max(1, len(R)))(*[0 if r[0] == "open" else r[1] for r in R])
+        f1 = arr([r[1] if r[0] == "open" else r[2] for r in R]); f2 = arr([r[2] if r[0] == "open" else r[3] for r in R])
+        f3 = arr([r[3] if r[0] == "open" else 0 for r in R]); f4 = arr([r[4] if r[0] == "open" else 0 for r in R])
+        e = (C.c_uint8 * 32)(); el = C.c_uint8(0)
+        self.lib.oracle_range_ni_verify_decimal.restype = C.c_int32
+        v = self.lib.oracle_range_ni_verify_decimal(str(proof["n"]).encode(), str(proof["range"]).encode(), str(proof["ciphertext"]).encode(),
+                                                    C.c_uint32(proof["error_factor"]), arr(proof["c1"]), C.c_uint32(len(proof["c1"])),
+                                                    arr(proof["c2"]), C.c_uint32(len(proof["c2"])), kind, j, f1, f2, f3, f4, C.c_uint32(len(R)), e, C.byref(el))
+        assert v in (0, 1, 2), v
+        return {0: "err", 1: "ok", 2: "panic"}[v], bytes(e)[:el.value]
+
+    def enc_decimal(self, n, m, r):
+        out = C.create_string_buffer(4 * len(str(n)) + 8)
+        self.lib.oracle_enc_decimal.restype = C.c_int32
+        assert self.lib.oracle_enc_decimal(str(n).encode(), str(m).encode(), str(r).encode(), out, C.c_uint64(len(out))) == 0
+        return int(out.value)
+
     def modexp(self, mod_bits, exp_bits, base, exp, exp_stride, mod, mod_stride):
         count = base.shape[0]
         out = np.zeros_like(base)

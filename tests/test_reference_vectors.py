@@ -69,15 +69,17 @@ def simulated_doc():
     ni = pow(pow(g, -1, n), s, n)
     x, y = pm.dlog_prove(n, g, ni, s, d.bits(512))
     doc["dlog"] = [{"N": dec(n), "g": dec(g), "ni": dec(ni), "secret": dec(s), "x": dec(x), "y": dec(y), "verify": "ok"}]
-    # the "serde" section of round 3: the text forms of the UN-annotated types, with the value next to each sample.  The simulated
-    # document writes them as hex strings of the big-endian magnitude — one of the three forms the reader knows; a real file decides.
+    # the "serde" section: the text forms of the UN-annotated types, with the value next to each sample.  The simulated document is
+    # MIXED, the way the two crates are recalled to write them [upstream, unverified]: a bare curv BigInt as a hex string of the
+    # big-endian magnitude, kzen-paillier's EncryptionKey through its decimal-string adapter.  The consumer derives the two forms
+    # independently (bigint_samples / encryption_key); a real file decides.
     hx = lambda v: v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big").hex()
     doc["serde"] = {"bigint_samples": [{"x": dec(v), "json": hx(v)} for v in (0, 255, 256, n)],
-                    "encryption_key": {"n": dec(n), "json": {"n": hx(n)}},
+                    "encryption_key": {"n": dec(n), "json": {"n": dec(n)}},
                     "dlog_statement": {"N": dec(n), "g": dec(g), "ni": dec(ni), "json": {"N": hx(n), "g": hx(g), "ni": hx(ni)}},
                     "dlog_proof": {"x": dec(x), "y": dec(y), "json": {"x": hx(x), "y": hx(y)}}}
     for c in doc["range_ni"]:
-        c["raw"] = {"ek": {"n": hx(n)}, "range": hx(D(c["range"])), "ciphertext": hx(D(c["ciphertext"])), "encrypted_pairs": c["encrypted_pairs"],
+        c["raw"] = {"ek": {"n": dec(n)}, "range": hx(D(c["range"])), "ciphertext": hx(D(c["ciphertext"])), "encrypted_pairs": c["encrypted_pairs"],
                     "proof": c["proof"], "error_factor": c["error_factor"]}
     return doc
 
@@ -85,16 +87,31 @@ def simulated_doc():
 KNOWN_SECTIONS = {"generator", "to_bytes", "compute_digest", "enc", "range_ni", "correct_key_ni", "dlog", "serde"}
 
 
+def _forms(v):
+    b = v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big")
+    return {zkp.BIGINT_DEC: str(v), zkp.BIGINT_HEX: b.hex(), zkp.BIGINT_BYTES: list(b)}
+
+
+def _fits(j, v):
+    """the encodings under which the JSON value j reads as the integer v"""
+    return {e for e, f in _forms(v).items() if (f == j or (isinstance(j, str) and isinstance(f, str) and f.lstrip("0") == j.lower().lstrip("0") and e != zkp.BIGINT_DEC))}
+
+
 def bigint_encoding_of(doc):
-    """which text form the un-annotated BigInt takes in THIS file: decided by the samples whose values are known"""
-    def forms(v):
-        b = v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big")
-        return {zkp.BIGINT_DEC: str(v), zkp.BIGINT_HEX: b.hex(), zkp.BIGINT_BYTES: list(b)}
-    cands = set(forms(0))
+    """which text form the un-annotated bare BigInt takes in THIS file: decided by the samples whose values are known"""
+    cands = set(_forms(0))
     for smp in doc["serde"]["bigint_samples"]:
-        j = smp["json"]
-        cands &= {e for e, f in forms(D(smp["x"])).items() if (f == j or (isinstance(j, str) and isinstance(f, str) and f.lstrip("0") == j.lower().lstrip("0") and e != zkp.BIGINT_DEC))}
+        cands &= _fits(smp["json"], D(smp["x"]))
     assert len(cands) == 1, f"the BigInt samples fit {sorted(cands)} of the known encodings (0 dec, 1 hex, 2 bytes): teach the reader the new form"
+    return cands.pop()
+
+
+def key_encoding_of(doc):
+    """the form of EncryptionKey.n, from the encryption_key sample ALONE: kzen-paillier serialises its key through its own adapter,
+    which need not be curv's bare-BigInt form (the advisor's round-3 finding: one parameter for both cannot read a mixed document)"""
+    ek = doc["serde"]["encryption_key"]
+    cands = _fits(ek["json"]["n"], D(ek["n"]))
+    assert len(cands) == 1, f"EncryptionKey.n fits {sorted(cands)} of the known encodings"
     return cands.pop()
 
 
@@ -112,15 +129,15 @@ def check_serde_section(doc):
     assert not unknown, f"sections {sorted(unknown)} of the reference file are not consumed by any check"
     if "serde" not in doc:
         return None
-    enc = bigint_encoding_of(doc)
+    enc, key_enc = bigint_encoding_of(doc), key_encoding_of(doc)
     sd = doc["serde"]
     assert set(sd) <= {"bigint_samples", "encryption_key", "dlog_statement", "dlog_proof"}, "unread part of the serde section"
     ek = sd["encryption_key"]
-    assert decode_bigint(ek["json"]["n"], enc) == D(ek["n"])
+    assert decode_bigint(ek["json"]["n"], key_enc) == D(ek["n"])
     for part, fields in (("dlog_statement", ("N", "g", "ni")), ("dlog_proof", ("x", "y"))):
         for f in fields:
             assert decode_bigint(sd[part]["json"][f], enc) == D(sd[part][f]), (part, f)
-    return enc
+    return key_enc, enc
 
 
 def width_for(n):
@@ -158,11 +175,12 @@ def batch_from_case(c):
 
 def check_doc_cpu(doc, oracle):
     """every section against the oracle (C/GMP) and the python model"""
-    enc = check_serde_section(doc)
+    forms = check_serde_section(doc)
     for c in doc["range_ni"]:
-        if "raw" in c and enc is not None:                 # the whole-document form agrees with the fields printed beside it
+        if "raw" in c and forms is not None:               # the whole-document form agrees with the fields printed beside it
             raw = c["raw"]
-            assert decode_bigint(raw["ek"]["n"], enc) == D(c["n"]) and decode_bigint(raw["range"], enc) == D(c["range"])
+            key_enc, enc = forms
+            assert decode_bigint(raw["ek"]["n"], key_enc) == D(c["n"]) and decode_bigint(raw["range"], enc) == D(c["range"])
             assert decode_bigint(raw["ciphertext"], enc) == D(c["ciphertext"])
             assert raw["encrypted_pairs"] == c["encrypted_pairs"] and raw["proof"] == c["proof"] and raw["error_factor"] == c["error_factor"]
     for t in doc["to_bytes"]:
@@ -209,15 +227,15 @@ def check_doc_cpu(doc, oracle):
 
 def check_doc_gpu(doc, ctx):
     """the same sections through the C ABI on the GPU, incl. the serde wire format of the transcripts"""
-    enc = check_serde_section(doc)
-    if enc is not None:
+    forms = check_serde_section(doc)
+    if forms is not None:
         # the WHOLE RangeProofNi documents, as the crate wrote them, through zkp_json_range_proof_ni_batch, then verified
         raws = [c for c in doc["range_ni"] if "raw" in c]
         if raws:
             nb = width_for(D(raws[0]["n"]))
             pw = zkp.RangeBatch(nb, len(raws), int(raws[0]["error_factor"]), shared_key=False)
             st = np.full(len(raws), 9, np.uint8)
-            ctx.json_range_proof_ni([json.dumps(c["raw"], separators=(",", ":")).encode() for c in raws], enc, pw.struct(), st)
+            ctx.json_range_proof_ni([json.dumps(c["raw"], separators=(",", ":")).encode() for c in raws], zkp.bigint_forms(*forms), pw.struct(), st)
             assert not st.any()
             v = np.full(len(raws), 9, np.uint8)
             ctx.range_ni_verify(pw.struct(), v, device=False)

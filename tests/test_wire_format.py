@@ -234,29 +234,34 @@ def _enc_bigint(v, enc):
     return b.hex() if enc == zkp.BIGINT_HEX else list(b)
 
 
-def range_ni_document(case, pr, enc, ef, pretty=False, extra=False):
-    """serde_json text of a whole RangeProofNi (range_proof_ni.rs:36-44): ek / range / ciphertext in the encoding under test,
-    encrypted_pairs / proof in the crate's decimal-string format (serialize.rs)"""
+def range_ni_document(case, pr, enc, ef, pretty=False, extra=False, key_enc=None):
+    """serde_json text of a whole RangeProofNi (range_proof_ni.rs:36-44): range / ciphertext in the encoding under test, ek.n in
+    `key_enc` (kzen-paillier's EncryptionKey and curv's bare BigInt need not agree), encrypted_pairs / proof in the crate's
+    decimal-string format (serialize.rs)"""
+    key_enc = enc if key_enc is None else key_enc
     resp = []
     for r in pr["responses"]:
         if r[0] == "open":
             resp.append({"Open": {"w1": str(r[1]), "r1": str(r[2]), "w2": str(r[3]), "r2": str(r[4])}})
         else:
             resp.append({"Mask": {"j": r[1], "masked_x": str(r[2]), "masked_r": str(r[3])}})
-    ek = {"n": _enc_bigint(case["n"], enc)}
+    ek = {"n": _enc_bigint(case["n"], key_enc)}
     if extra:
-        ek["nn"] = _enc_bigint(case["n"] ** 2, enc)           # a fuller EncryptionKey: unknown fields are skipped
+        ek["nn"] = _enc_bigint(case["n"] ** 2, key_enc)           # a fuller EncryptionKey: unknown fields are skipped
     doc = {"ek": ek, "range": _enc_bigint(case["range"], enc), "ciphertext": _enc_bigint(pr["ciphertext"], enc),
            "encrypted_pairs": {"c1": [str(v) for v in pr["c1"]], "c2": [str(v) for v in pr["c2"]]}, "proof": resp, "error_factor": ef}
     return json.dumps(doc, indent=2 if pretty else None, separators=None if pretty else (",", ":")).encode()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("enc", [zkp.BIGINT_DEC, zkp.BIGINT_HEX, zkp.BIGINT_BYTES], ids=["dec", "hex", "bytes"])
-def test_gpu_whole_range_proof_ni_documents(ctx, oracle, enc):
-    """whole RangeProofNi documents -> the SoA batch -> verify: the three candidate encodings of the un-annotated fields, per-proof
-    and shared keys, and the documents serde would refuse"""
+@pytest.mark.parametrize("key_enc,enc", [(zkp.BIGINT_DEC, zkp.BIGINT_DEC), (zkp.BIGINT_HEX, zkp.BIGINT_HEX), (zkp.BIGINT_BYTES, zkp.BIGINT_BYTES),
+                                         (zkp.BIGINT_DEC, zkp.BIGINT_HEX), (zkp.BIGINT_HEX, zkp.BIGINT_BYTES)], ids=["dec", "hex", "bytes", "key-dec+bare-hex", "key-hex+bare-bytes"])
+def test_gpu_whole_range_proof_ni_documents(ctx, oracle, key_enc, enc):
+    """whole RangeProofNi documents -> the SoA batch -> verify: the candidate encodings of the un-annotated fields — the key's and the
+    bare BigInts' named SEPARATELY (a document may mix them) —, per-proof and shared keys, the documents serde would refuse, and the
+    valid ones this layout cannot carry (ZKP_DOC_HOST_PATH)"""
     n_bits, ef, kw = 1024, 128, 32
+    forms = zkp.bigint_forms(key_enc, enc)
     keys = [H.test_key(1024, tag=t)[2] for t in range(2)]
     docs, cases = [], []
     for b in range(3):
@@ -265,32 +270,45 @@ def test_gpu_whole_range_proof_ni_documents(ctx, oracle, enc):
         pr = pm.range_ni_prove(c["n"], c["range"], ct, c["x"], c["r"], c["w1"], c["w2"], c["r1"], c["r2"])
         pr["ciphertext"] = ct
         cases.append((c, pr))
-        docs.append(range_ni_document(c, pr, enc, ef, pretty=(b == 1), extra=(b == 0)))
+        docs.append(range_ni_document(c, pr, enc, ef, pretty=(b == 1), extra=(b == 0), key_enc=key_enc))
     good = docs[0]
-    bad = [good.replace(b'"error_factor":128', b'"error_factor":40'), good.replace(b'"range"', b'"rnge"'), good.replace(b'"ek"', b'"ek":{"n":"1"},"ek"', 1),
-           good[:-1], good.replace(b'"ciphertext":', b'"ciphertext":null,"x":', 1)]
-    all_docs = docs + bad
+    invalid = [good.replace(b'"range"', b'"rnge"'), good.replace(b'"ek"', b'"ek":{"n":"1"},"ek"', 1),
+               good[:-1], good.replace(b'"ciphertext":', b'"ciphertext":null,"x":', 1)]
+    # valid values of the reference's type that the fixed layout cannot carry: another error_factor, a negative response field
+    neg = good.replace(b'"masked_r":"', b'"masked_r":"-', 1)
+    host = [good.replace(b'"error_factor":128', b'"error_factor":40'), neg]
+    all_docs = docs + invalid + host
     B = len(all_docs)
     pg = zkp.RangeBatch(n_bits, B, ef, shared_key=False)
     st = np.full(B, 9, np.uint8)
-    ctx.json_range_proof_ni(all_docs, enc, pg.struct(), st)
-    assert list(st) == [0, 0, 0] + [zkp.VERDICT_MALFORMED] * len(bad)
+    ctx.json_range_proof_ni(all_docs, forms, pg.struct(), st)
+    assert list(st) == [0, 0, 0] + [zkp.DOC_INVALID] * len(invalid) + [zkp.DOC_HOST_PATH] * len(host)
     for b, (c, pr) in enumerate(cases):
         assert L.limbs_to_int(pg.n[b]) == c["n"] and L.limbs_to_int(pg.range[b]) == c["range"] and L.limbs_to_int(pg.ciphertext[b]) == pr["ciphertext"]
         assert [L.limbs_to_int(x) for x in pg.c1[b]] == pr["c1"] and [L.limbs_to_int(x) for x in pg.c2[b]] == pr["c2"]
         assert H.responses_from_batch(pg, b) == pr["responses"]
-    assert not pg.range[3:].any() and not pg.c1[3:].any()
+    assert not pg.range[3:].any() and not pg.c1[3:3 + len(invalid)].any() and not pg.n[3:3 + len(invalid)].any()
     v = np.full(3, 9, np.uint8)
     ctx.range_ni_verify(pg.slice(0, 3).struct(), v, device=False)
     assert list(v) == [zkp.VERDICT_ACCEPT, zkp.VERDICT_ACCEPT, zkp.VERDICT_REJECT]
-    # one shared key: the document under the other key is what RangeProofNi::verify's assert_eq!(ek) panics on
-    ps = zkp.RangeBatch(n_bits, 3, ef, shared_key=True)
-    st = np.full(3, 9, np.uint8)
-    ctx.json_range_proof_ni(docs, enc, ps.struct(), st)
-    assert list(st) == [0, zkp.VERDICT_MALFORMED, 0] and L.limbs_to_int(ps.n[0]) == keys[0]
-    # a value wider than the field, in every encoding
+    # one shared key = the VERIFIER's key (an input): the document under the other key is what RangeProofNi::verify's assert_eq!(ek)
+    # panics on, and it cannot become the key of the batch even when it comes first
+    for order in ([0, 1, 2], [1, 0, 2]):
+        ps = zkp.RangeBatch(n_bits, 3, ef, shared_key=True)
+        ps.n[0] = L.int_to_limbs(keys[0], kw)
+        st = np.full(3, 9, np.uint8)
+        ctx.json_range_proof_ni([docs[i] for i in order], forms, ps.struct(), st)
+        assert list(st) == [zkp.DOC_INVALID if i == 1 else 0 for i in order] and L.limbs_to_int(ps.n[0]) == keys[0]
+    # a value wider than the field, in every encoding: a valid BigInt -> host path
     wide = dict(cases[0][0]); wide["range"] = 1 << 1030
     st = np.full(1, 9, np.uint8)
     pwide = zkp.RangeBatch(n_bits, 1, ef, shared_key=False)          # (kept alive: struct() only borrows the arrays)
-    ctx.json_range_proof_ni([range_ni_document(wide, cases[0][1], enc, ef)], enc, pwide.struct(), st)
-    assert list(st) == [zkp.VERDICT_MALFORMED] and not pwide.range.any()
+    ctx.json_range_proof_ni([range_ni_document(wide, cases[0][1], enc, ef, key_enc=key_enc)], forms, pwide.struct(), st)
+    assert list(st) == [zkp.DOC_HOST_PATH] and not pwide.range.any()
+    # the form matters: decimal digits read as hex are another number, so a document in the OTHER form must not parse silently into
+    # a wrong key — with separate forms the mismatch is either an error or a different (rejected) statement, never the right key
+    if key_enc != enc and zkp.BIGINT_BYTES not in (key_enc, enc):
+        st = np.full(1, 9, np.uint8)
+        pswap = zkp.RangeBatch(n_bits, 1, ef, shared_key=False)
+        ctx.json_range_proof_ni([docs[0]], zkp.bigint_forms(enc, key_enc), pswap.struct(), st)
+        assert st[0] != 0 or L.limbs_to_int(pswap.n[0]) != cases[0][0]["n"]

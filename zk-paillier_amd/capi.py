@@ -150,6 +150,12 @@ class DecItem(C.Structure):
 
 DEC_OK, DEC_INVALID, DEC_NEGATIVE, DEC_OVERFLOW = 0, 1, 2, 3
 BIGINT_DEC, BIGINT_HEX, BIGINT_BYTES = 0, 1, 2
+DOC_OK, DOC_INVALID, DOC_HOST_PATH = 0, 2, 3
+
+
+def bigint_forms(key_form: int, bare_form: int) -> int:
+    """ZKP_BIGINT_FORMS: the text form of ek.n and of the bare BigInts (range, ciphertext), named separately"""
+    return (key_form << 4) | bare_form
 
 
 class ZkpError(RuntimeError):
@@ -425,11 +431,12 @@ class Context:
         self.check(self.lib.zkp_json_range_proof_batch(self.h, C.cast(buf, C.c_void_p), ptr(off), ptr(ln), C.byref(proofs), ptr(out_status),
                                                        ZKP_F_DEVICE_PTRS if device else 0))
 
-    def json_range_proof_ni(self, docs, bigint_encoding: int, proofs, out_status):
-        """whole RangeProofNi documents -> every field of the (host) batch; bigint_encoding: BIGINT_DEC / BIGINT_HEX / BIGINT_BYTES
-        for the un-annotated ek.n, range, ciphertext"""
+    def json_range_proof_ni(self, docs, forms: int, proofs, out_status):
+        """whole RangeProofNi documents -> every field of the (host) batch; forms = bigint_forms(key_form, bare_form): BIGINT_DEC /
+        BIGINT_HEX / BIGINT_BYTES for the un-annotated ek.n and, separately, for range / ciphertext.  With a shared key proofs.n is
+        the verifier's key (an input)."""
         buf, off, ln = self._json_docs(docs)
-        self.check(self.lib.zkp_json_range_proof_ni_batch(self.h, C.cast(buf, C.c_void_p), ptr(off), ptr(ln), bigint_encoding, C.byref(proofs), ptr(out_status), 0))
+        self.check(self.lib.zkp_json_range_proof_ni_batch(self.h, C.cast(buf, C.c_void_p), ptr(off), ptr(ln), forms, C.byref(proofs), ptr(out_status), 0))
 
     def json_correct_key_proof(self, docs, n_bits, out_sigma, out_status):
         buf, off, ln = self._json_docs(docs)

@@ -41,14 +41,19 @@ struct IncorrectProof {};   // src/zkproofs/errors.rs:5-13
 // Result<(), IncorrectProof>.  A batch call returns one Result per proof; a proof on which the reference would have
 // PANICKED (index out of bounds, assert) carries that panic and throws it when it is looked at, so that one crafted proof
 // cannot take the verdicts of the others with it.
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
 class Result {
-  enum State { Ok, Err, Panicked } st_;
+  enum State { Ok, Err, Panicked, Unsupp } st_;
   std::string what_;
-  void look() const { if (st_ == Panicked) throw Panic(what_); }
+  void look() const { if (st_ == Panicked) throw Panic(what_); if (st_ == Unsupp) throw Unsupported(what_); }
  public:
   explicit Result(bool ok) : st_(ok ? Ok : Err) {}
   static Result panicked(const std::string& what) { Result r(false); r.st_ = Panicked; r.what_ = what; return r; }
+  // the ONLY outcome that is not the reference's: a statement this fixed-width engine cannot carry at all (a key that is not a
+  // positive odd integer of at most 4096 bits).  Every other input — any size, either sign — gets the reference's verdict or panic.
+  static Result unsupported(const std::string& what) { Result r(false); r.st_ = Unsupp; r.what_ = what; return r; }
   bool would_panic() const { return st_ == Panicked; }
+  bool is_unsupported() const { return st_ == Unsupp; }
   bool is_ok() const { look(); return st_ == Ok; }
   bool is_err() const { look(); return st_ == Err; }
   void expect(const char* msg) const { look(); if (st_ != Ok) throw Panic(std::string(msg) + ": IncorrectProof"); }
@@ -92,14 +97,34 @@ struct Keypair {
 };
 
 struct Paillier {
-  // [upstream EncryptWithChosenRandomness] c = (1 + m n) r^n mod n^2
-  static BigInt encrypt_with_chosen_randomness(const EncryptionKey& ek, const BigInt& m, const BigInt& r) {
+  // [upstream kzen-paillier EncryptWithChosenRandomness] on ANY integers m, r (a received proof may hold negative or over-wide
+  // fields), exactly as the reference's operators give it:
+  //     rn = mod_pow(r, n, nn) in [0, nn);   gm = (m n + 1) % nn  (truncated: negative for m < 0);   c = gm rn % nn
+  // With E = Enc(m mod n, r mod n) — floored residues, the canonical operands the kernels take — that is  c = E  for m >= 0 and
+  // c = E - nn (or 0 when E = 0) for m < 0: (m n + 1) % nn = -(nn - G) with G = 1 + (m mod n) n, hence c = -((nn - G) rn mod nn).
+  // ONE zkp_paillier_enc_batch for the whole list.
+  static std::vector<BigInt> encrypt_with_chosen_randomness_batch(const EncryptionKey& ek, const std::vector<std::pair<const BigInt*, const BigInt*>>& mr) {
     Engine& e = Engine::instance();
     const uint32_t nb = width_for(ek.n), kw = nb / 32;
-    std::vector<uint32_t> n(kw), mm(kw), rr(kw), c(2 * kw);
-    ek.n.to_limbs(n.data(), kw); m.to_limbs(mm.data(), kw); r.to_limbs(rr.data(), kw);
-    e.check(zkp_paillier_enc_batch(e.ctx(), nb, 1, n.data(), 0, mm.data(), rr.data(), c.data(), 0), "zkp_paillier_enc_batch");
-    return BigInt::from_limbs(c.data(), 2 * kw);
+    const size_t cnt = mr.size();
+    std::vector<uint32_t> n(kw), mm(cnt * kw), rr(cnt * kw), c(cnt * 2 * kw);
+    ek.n.to_limbs(n.data(), kw);
+    for (size_t i = 0; i < cnt; i++) {
+      const BigInt &m = *mr[i].first, &r = *mr[i].second;
+      (m.fits_limbs(kw) && m < ek.n ? m : m.modulus(ek.n)).to_limbs(&mm[i * kw], kw);
+      (r.fits_limbs(kw) && r < ek.n ? r : r.modulus(ek.n)).to_limbs(&rr[i * kw], kw);
+    }
+    if (cnt) e.check(zkp_paillier_enc_batch(e.ctx(), nb, cnt, n.data(), 0, mm.data(), rr.data(), c.data(), 0), "zkp_paillier_enc_batch");
+    std::vector<BigInt> out;
+    out.reserve(cnt);
+    for (size_t i = 0; i < cnt; i++) {
+      BigInt E = BigInt::from_limbs(&c[i * 2 * kw], 2 * kw);
+      out.push_back(mr[i].first->is_negative() && !E.is_zero() ? E - ek.nn : E);
+    }
+    return out;
+  }
+  static BigInt encrypt_with_chosen_randomness(const EncryptionKey& ek, const BigInt& m, const BigInt& r) {
+    return encrypt_with_chosen_randomness_batch(ek, {{&m, &r}})[0];
   }
 };
 
@@ -109,7 +134,7 @@ inline BigInt mod_pow(const BigInt& base, const BigInt& exp, const BigInt& modul
   const uint32_t mb = b <= 2048 ? 2048 : b <= 4096 ? 4096 : 8192, L = mb / 32;
   if (exp.bit_length() > mb) throw std::length_error("exponent wider than the modulus width");
   std::vector<uint32_t> bb(L), ee(L), mm(L), out(L);
-  (base % modulus).to_limbs(bb.data(), L); exp.to_limbs(ee.data(), L); modulus.to_limbs(mm.data(), L);
+  base.modulus(modulus).to_limbs(bb.data(), L); exp.to_limbs(ee.data(), L); modulus.to_limbs(mm.data(), L);   // mpz_powm: a negative base gives the residue in [0, m)
   e.check(zkp_modexp_batch(e.ctx(), mb, mb, 1, bb.data(), ee.data(), L, mm.data(), L, out.data(), 0), "zkp_modexp_batch");
   return BigInt::from_limbs(out.data(), L);
 }
@@ -122,7 +147,7 @@ inline std::vector<BigInt> mod_pow_batch(const std::vector<BigInt>& bases, const
   const bool shared = exps.size() == 1;
   if (!shared && exps.size() != cnt) throw std::invalid_argument("mod_pow_batch: exps must have 1 or bases.size() entries");
   std::vector<uint32_t> bb(cnt * L), ee(exps.size() * L), mm(L), out(cnt * L);
-  for (size_t i = 0; i < cnt; i++) (bases[i] % modulus).to_limbs(&bb[i * L], L);
+  for (size_t i = 0; i < cnt; i++) bases[i].modulus(modulus).to_limbs(&bb[i * L], L);
   for (size_t i = 0; i < exps.size(); i++) exps[i].to_limbs(&ee[i * L], L);
   modulus.to_limbs(mm.data(), L);
   if (cnt) e.check(zkp_modexp_batch(e.ctx(), mb, mb, cnt, bb.data(), ee.data(), shared ? 0 : L, mm.data(), 0, out.data(), 0), "zkp_modexp_batch");
@@ -200,14 +225,13 @@ class RangeProofNi {
     const size_t B = st.size(), EF = SECURITY_PARAMETER, rows = B * EF;
     std::vector<uint32_t> n(kw), range(B * kw), ct(B * 2 * kw), x(B * kw), r(B * kw), w1(rows * kw), w2(rows * kw), r1(rows * kw), r2(rows * kw);
     ek.n.to_limbs(n.data(), kw);
-    std::random_device rd;
     for (size_t b = 0; b < B; b++) {
       st[b].range.to_limbs(&range[b * kw], kw); st[b].ciphertext.to_limbs(&ct[b * 2 * kw], 2 * kw);
       st[b].secret_x.to_limbs(&x[b * kw], kw); st[b].secret_r.to_limbs(&r[b * kw], kw);
       const BigInt third = st[b].range.div_floor(BigInt(3)), two_thirds = BigInt(2) * third;   // range_proof.rs:133-134
       for (size_t i = 0; i < EF; i++) {
         BigInt a = BigInt::sample_range(third, two_thirds), c = a - third;                      // :136-141
-        if (rd() & 1) std::swap(a, c);                                                           // :144-149
+        if (BigInt::coin()) std::swap(a, c);                                                     // :144-149
         a.to_limbs(&w1[(b * EF + i) * kw], kw); c.to_limbs(&w2[(b * EF + i) * kw], kw);
         BigInt::sample_below(ek.n).to_limbs(&r1[(b * EF + i) * kw], kw);                         // :151-159
         BigInt::sample_below(ek.n).to_limbs(&r2[(b * EF + i) * kw], kw);
@@ -247,100 +271,127 @@ class RangeProofNi {
     return prove_batch(ek, {Statement{range, ciphertext, secret_x, secret_r}})[0];
   }
 
-  // verify_self for many proofs sharing one key (range_proof_ni.rs:109-128).  Every field of a proof is prover-chosen and of
-  // arbitrary size in the reference (GMP); the fixed-width ABI carries kw / 2kw limbs.  Each proof is screened on the host so
-  // that an over-wide field yields the verdict the reference would reach for THAT proof, never an exception for the batch:
-  //   * r1, r2, masked_r enter only as r^n mod n^2 = (r mod n)^n mod n^2, and c_j[i], ciphertext on Mask rows only as a product
-  //     reduced mod n^2 (range_proof.rs:324-328): reduced on the host, same row result.  The Fiat-Shamir challenge, however, is
-  //     hashed over the RAW c1 / c2 (compute_digest over encrypted_pairs, range_proof_ni.rs:110-113, utils.rs:9-22): a proof with
-  //     an over-wide c_j on a Mask row gets its challenge from the host (the raw values) and goes through
-  //     zkp_range_verifier_output_batch with that challenge, in a second small call;
-  //   * an over-wide w1 / w2 fails the strict range test of an Open row (:300-305), an over-wide masked_x the bound of a Mask
-  //     row (:338), an over-wide c_j[i] of an Open row can never equal a ciphertext (:293-298): Err(IncorrectProof);
-  //   * a range wider than the key cannot be represented at all: that proof carries a panic-like "unsupported" result.
+  // verify_self for many proofs sharing one key (range_proof_ni.rs:109-128).  Every field of a received proof is prover-chosen: any
+  // size, either sign (curv::BigInt over GMP; the decimal serde takes a leading '-').  The fixed-width ABI carries kw / 2kw limbs of
+  // non-negative values.  So each proof is classified on the host:
+  //   * CANONICAL (every field non-negative and within its width, exactly error_factor rows stored): flattened into the SoA batch,
+  //     ONE zkp_range_ni_verify_batch for all of them;
+  //   * anything else goes through verify_general below: the reference's row logic verbatim on signed host integers, its modular
+  //     exponentiations — the Enc of every row that needs one — still batched on the GPU.  Such a proof gets exactly the verdict,
+  //     or the panic, the reference reaches for it (tests/golden/signed_cases.json);
+  //   * the one thing that has no answer here is a KEY the engine cannot carry (not a positive odd integer of <= 4096 bits):
+  //     Result::unsupported.
   static std::vector<Result> verify_batch(const EncryptionKey& ek, const std::vector<const RangeProofNi*>& proofs) {
-    Engine& e = Engine::instance();
-    const uint32_t nb = width_for(ek.n), kw = nb / 32;
     const size_t B = proofs.size();
     if (B == 0) return {};
-    const size_t EF = proofs[0]->error_factor, rows = B * EF;
-    std::vector<uint32_t> n(kw), range(B * kw), ct(B * 2 * kw), c1(rows * 2 * kw), c2(rows * 2 * kw), rw1(rows * kw), rr1(rows * kw), rw2(rows * kw), rr2(rows * kw);
-    std::vector<uint8_t> kind(rows), jj(rows), verdict(B);
-    enum Pre : uint8_t { Run = 0, Reject, PanicIdx, Unsupported, HostChallenge };
-    std::vector<uint8_t> pre(B, Run);
-    ek.n.to_limbs(n.data(), kw);
-    const size_t nbits_n = 32 * (size_t)kw, nbits_c = 64 * (size_t)kw;
-    auto fits = [](const BigInt& v, size_t bits) { return v.bit_length() <= bits; };
-    for (size_t b = 0; b < B; b++) {
-      const RangeProofNi& p = *proofs[b];
-      if (p.error_factor != EF) throw std::invalid_argument("verify_batch: mixed error factors");
-      // responses[i], c1[i], c2[i] for i < error_factor: out-of-bounds index is a panic in the reference (range_proof.rs:274,293,296)
-      if (p.proof.responses.size() < EF || p.encrypted_pairs.c1.size() < EF || p.encrypted_pairs.c2.size() < EF) { pre[b] = PanicIdx; continue; }
-      if (!fits(p.range, nbits_n)) { pre[b] = Unsupported; continue; }
-      p.range.to_limbs(&range[b * kw], kw);
-      (fits(p.ciphertext, nbits_c) ? p.ciphertext : p.ciphertext % ek.nn).to_limbs(&ct[b * 2 * kw], 2 * kw);
+    if (ek.n.is_negative() || !ek.n.is_odd() || ek.n.bit_length() > 4096 || ek.n.bit_length() < 2)
+      return std::vector<Result>(B, Result::unsupported("RangeProofNi::verify: the key is not a positive odd integer of at most 4096 bits"));
+    Engine& e = Engine::instance();
+    const uint32_t nb = width_for(ek.n), kw = nb / 32;
+    const size_t EF = proofs[0]->error_factor;
+    std::vector<size_t> fast, general;
+    auto canonical = [&](const RangeProofNi& p) {
+      if (p.error_factor != EF || p.proof.responses.size() != EF || p.encrypted_pairs.c1.size() != EF || p.encrypted_pairs.c2.size() != EF) return false;
+      if (!p.range.fits_limbs(kw) || !p.ciphertext.fits_limbs(2 * kw)) return false;
       for (size_t i = 0; i < EF; i++) {
-        const size_t t = b * EF + i;
         const Response& rs = p.proof.responses[i];
-        const BigInt &C1 = p.encrypted_pairs.c1[i], &C2 = p.encrypted_pairs.c2[i];
-        if (rs.kind == Response::Open) {
-          kind[t] = ZKP_RESP_OPEN;
-          if (!fits(rs.w1, nbits_n) || !fits(rs.w2, nbits_n) || !fits(C1, nbits_c) || !fits(C2, nbits_c)) { pre[b] = Reject; continue; }
-          C1.to_limbs(&c1[t * 2 * kw], 2 * kw); C2.to_limbs(&c2[t * 2 * kw], 2 * kw);
-          rs.w1.to_limbs(&rw1[t * kw], kw); rs.w2.to_limbs(&rw2[t * kw], kw);
-          (fits(rs.r1, nbits_n) ? rs.r1 : rs.r1 % ek.n).to_limbs(&rr1[t * kw], kw);
-          (fits(rs.r2, nbits_n) ? rs.r2 : rs.r2 % ek.n).to_limbs(&rr2[t * kw], kw);
-        } else {
-          kind[t] = ZKP_RESP_MASK; jj[t] = rs.j;
-          if (!fits(rs.masked_x, nbits_n)) { pre[b] = Reject; continue; }
-          if ((!fits(C1, nbits_c) || !fits(C2, nbits_c)) && pre[b] == Run) pre[b] = HostChallenge;   // e must be hashed over the raw values
-          (fits(C1, nbits_c) ? C1 : C1 % ek.nn).to_limbs(&c1[t * 2 * kw], 2 * kw);
-          (fits(C2, nbits_c) ? C2 : C2 % ek.nn).to_limbs(&c2[t * 2 * kw], 2 * kw);
-          rs.masked_x.to_limbs(&rw1[t * kw], kw);
-          (fits(rs.masked_r, nbits_n) ? rs.masked_r : rs.masked_r % ek.n).to_limbs(&rr1[t * kw], kw);
+        if (!p.encrypted_pairs.c1[i].fits_limbs(2 * kw) || !p.encrypted_pairs.c2[i].fits_limbs(2 * kw)) return false;
+        if (rs.kind == Response::Open ? !(rs.w1.fits_limbs(kw) && rs.r1.fits_limbs(kw) && rs.w2.fits_limbs(kw) && rs.r2.fits_limbs(kw))
+                                      : !(rs.masked_x.fits_limbs(kw) && rs.masked_r.fits_limbs(kw))) return false;
+      }
+      return true;
+    };
+    for (size_t b = 0; b < B; b++) (canonical(*proofs[b]) ? fast : general).push_back(b);
+    std::vector<Result> out(B, Result(false));
+    if (!fast.empty()) {
+      const size_t F = fast.size(), rows = F * EF;
+      std::vector<uint32_t> n(kw), range(F * kw), ct(F * 2 * kw), c1(rows * 2 * kw), c2(rows * 2 * kw), rw1(rows * kw), rr1(rows * kw), rw2(rows * kw, 0), rr2(rows * kw, 0);
+      std::vector<uint8_t> kind(rows), jj(rows, 0), verdict(F);
+      ek.n.to_limbs(n.data(), kw);
+      for (size_t f = 0; f < F; f++) {
+        const RangeProofNi& p = *proofs[fast[f]];
+        p.range.to_limbs(&range[f * kw], kw); p.ciphertext.to_limbs(&ct[f * 2 * kw], 2 * kw);
+        for (size_t i = 0; i < EF; i++) {
+          const size_t t = f * EF + i;
+          const Response& rs = p.proof.responses[i];
+          p.encrypted_pairs.c1[i].to_limbs(&c1[t * 2 * kw], 2 * kw); p.encrypted_pairs.c2[i].to_limbs(&c2[t * 2 * kw], 2 * kw);
+          if (rs.kind == Response::Open) {
+            kind[t] = ZKP_RESP_OPEN;
+            rs.w1.to_limbs(&rw1[t * kw], kw); rs.r1.to_limbs(&rr1[t * kw], kw); rs.w2.to_limbs(&rw2[t * kw], kw); rs.r2.to_limbs(&rr2[t * kw], kw);
+          } else {
+            kind[t] = ZKP_RESP_MASK; jj[t] = rs.j;
+            rs.masked_x.to_limbs(&rw1[t * kw], kw); rs.masked_r.to_limbs(&rr1[t * kw], kw);
+          }
         }
       }
+      zkp_range_ni_proofs p{nb, (uint32_t)EF, F, 0, n.data(), range.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
+                            rw1.data(), rr1.data(), rw2.data(), rr2.data()};
+      e.check(zkp_range_ni_verify_batch(e.ctx(), &p, verdict.data(), 0), "zkp_range_ni_verify_batch");
+      for (size_t f = 0; f < F; f++)
+        out[fast[f]] = verdict[f] == ZKP_VERDICT_MALFORMED ? Result::panicked("RangeProofNi::verify: malformed proof (the reference would panic)") : Result(verdict[f] == ZKP_VERDICT_ACCEPT);
     }
-    // (rows of screened-out proofs stay zero: the launch still runs over the whole batch, their verdicts are ignored)
-    zkp_range_ni_proofs p{nb, (uint32_t)EF, B, 0, n.data(), range.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
-                          rw1.data(), rr1.data(), rw2.data(), rr2.data()};
-    e.check(zkp_range_ni_verify_batch(e.ctx(), &p, verdict.data(), 0), "zkp_range_ni_verify_batch");
-    // proofs whose transcript holds values the ABI cannot carry: e = to_bytes(from_bytes(SHA256(n || c1 || c2))) over the raw
-    // BigInts (range_proof_ni.rs:89-92,110-113), then verifier_output with that challenge on their (reduced) rows
-    std::vector<size_t> hc;
-    for (size_t b = 0; b < B; b++) if (pre[b] == HostChallenge) hc.push_back(b);
-    if (!hc.empty()) {
-      const size_t H = hc.size(), hrows = H * EF;
-      std::vector<uint32_t> range2(H * kw), ct2(H * 2 * kw), c12(hrows * 2 * kw), c22(hrows * 2 * kw), w12(hrows * kw), r12(hrows * kw), w22(hrows * kw), r22(hrows * kw);
-      std::vector<uint8_t> kind2(hrows), jj2(hrows), v2(H), ebytes(H * 32, 0), elen(H);
-      for (size_t h = 0; h < H; h++) {
-        const size_t b = hc[h];
-        const RangeProofNi& q = *proofs[b];
-        std::memcpy(&range2[h * kw], &range[b * kw], 4 * kw); std::memcpy(&ct2[h * 2 * kw], &ct[b * 2 * kw], 8 * kw);
-        std::memcpy(&c12[h * EF * 2 * kw], &c1[b * EF * 2 * kw], EF * 8 * kw); std::memcpy(&c22[h * EF * 2 * kw], &c2[b * EF * 2 * kw], EF * 8 * kw);
-        std::memcpy(&w12[h * EF * kw], &rw1[b * EF * kw], EF * 4 * kw); std::memcpy(&r12[h * EF * kw], &rr1[b * EF * kw], EF * 4 * kw);
-        std::memcpy(&w22[h * EF * kw], &rw2[b * EF * kw], EF * 4 * kw); std::memcpy(&r22[h * EF * kw], &rr2[b * EF * kw], EF * 4 * kw);
-        std::memcpy(&kind2[h * EF], &kind[b * EF], EF); std::memcpy(&jj2[h * EF], &jj[b * EF], EF);
-        detail::Sha256 sh;
-        sh.update(ek.n);
-        for (size_t i = 0; i < EF; i++) sh.update(q.encrypted_pairs.c1[i]);
-        for (size_t i = 0; i < EF; i++) sh.update(q.encrypted_pairs.c2[i]);
-        const std::vector<uint8_t> eb = sh.finish().to_bytes();       // leading zero bytes of the digest are dropped
-        std::memcpy(&ebytes[h * 32], eb.data(), std::min<size_t>(eb.size(), 32));
-        elen[h] = (uint8_t)std::min<size_t>(eb.size(), 32);
+    if (!general.empty()) {
+      std::vector<const RangeProofNi*> g;
+      for (size_t b : general) g.push_back(proofs[b]);
+      std::vector<Result> r = verify_general(ek, g);
+      for (size_t k = 0; k < general.size(); k++) out[general[k]] = r[k];
+    }
+    return out;
+  }
+
+  // range_proof_ni.rs:109-128 -> range_proof.rs:254-355 on signed integers of any size (see verify_batch).  Operators as the
+  // reference's BigInt has them: `%` truncated (:325,327), div_floor floored (:264), comparisons signed (:300-305,338), equality
+  // exact (:293-298,335), to_bytes = magnitude in compute_digest (utils.rs:15-18, over EVERY stored c1 / c2).  Panics of the
+  // reference — bits_of_e[i], responses[i], c1[i] / c2[i] past the end (:272-274,293,296,325,327) — are found per row, in the arm
+  // that indexes, and win over any `false`.  All Enc of all these proofs: one batch on the GPU.
+  static std::vector<Result> verify_general(const EncryptionKey& ek, const std::vector<const RangeProofNi*>& proofs) {
+    struct Row { uint8_t what = 0; size_t enc0 = 0; BigInt expect0, expect1; bool flag = true; };   // what: 0 false, 1 open, 2 mask
+    struct Plan { std::vector<Row> rows; bool panic = false; };
+    std::vector<Plan> plans(proofs.size());
+    std::vector<std::pair<const BigInt*, const BigInt*>> encs;
+    for (size_t b = 0; b < proofs.size(); b++) {
+      const RangeProofNi& p = *proofs[b];
+      Plan& pl = plans[b];
+      detail::Sha256 sh;
+      sh.update(ek.n);
+      for (const BigInt& v : p.encrypted_pairs.c1) sh.update(v);
+      for (const BigInt& v : p.encrypted_pairs.c2) sh.update(v);
+      const std::vector<uint8_t> ebytes = sh.finish().to_bytes();      // leading zero bytes of the digest are dropped
+      const BigInt third = p.range.div_floor(BigInt(3)), two_thirds = BigInt(2) * third;      // :264-265
+      for (size_t i = 0; i < p.error_factor && !pl.panic; i++) {
+        if (i >= 8 * ebytes.size() || i >= p.proof.responses.size()) { pl.panic = true; break; }
+        const bool ei = (ebytes[i / 8] >> (7 - i % 8)) & 1;
+        const Response& rs = p.proof.responses[i];
+        Row row;
+        if (!ei && rs.kind == Response::Open) {                                              // :277-313
+          if (i >= p.encrypted_pairs.c1.size() || i >= p.encrypted_pairs.c2.size()) { pl.panic = true; break; }
+          row.what = 1; row.enc0 = encs.size();
+          encs.push_back({&rs.w1, &rs.r1}); encs.push_back({&rs.w2, &rs.r2});
+          row.expect0 = p.encrypted_pairs.c1[i]; row.expect1 = p.encrypted_pairs.c2[i];
+          row.flag = (rs.w2 < third && rs.w1 > third && rs.w1 < two_thirds) || (rs.w1 < third && rs.w2 > third && rs.w2 < two_thirds);   // :300-305
+        } else if (ei && rs.kind == Response::Mask) {                                         // :315-343
+          const std::vector<BigInt>& cj = rs.j == 1 ? p.encrypted_pairs.c1 : p.encrypted_pairs.c2;   // any j != 1 selects c2, :324-328
+          if (i >= cj.size()) { pl.panic = true; break; }
+          row.what = 2; row.enc0 = encs.size();
+          encs.push_back({&rs.masked_x, &rs.masked_r});
+          row.expect0 = (cj[i] * p.ciphertext) % ek.nn;                                       // truncated, sign of the product
+          row.flag = !(rs.masked_x < third || rs.masked_x > two_thirds);                      // :338
+        }
+        pl.rows.push_back(std::move(row));
       }
-      zkp_range_ni_proofs p2{nb, (uint32_t)EF, H, 0, n.data(), range2.data(), ct2.data(), c12.data(), c22.data(), kind2.data(), jj2.data(),
-                             w12.data(), r12.data(), w22.data(), r22.data()};
-      e.check(zkp_range_verifier_output_batch(e.ctx(), &p2, ebytes.data(), elen.data(), v2.data(), 0), "zkp_range_verifier_output_batch");
-      for (size_t h = 0; h < H; h++) { verdict[hc[h]] = v2[h]; pre[hc[h]] = Run; }
     }
+    const std::vector<BigInt> E = Paillier::encrypt_with_chosen_randomness_batch(ek, encs);
     std::vector<Result> out;
-    for (size_t b = 0; b < B; b++) {
-      if (pre[b] == PanicIdx) out.push_back(Result::panicked("index out of bounds: the len is less than error_factor"));
-      else if (pre[b] == Unsupported) out.push_back(Result::panicked("RangeProofNi::verify: range wider than the key: not representable in the fixed-width ABI"));
-      else if (pre[b] == Reject) out.emplace_back(false);
-      else if (verdict[b] == ZKP_VERDICT_MALFORMED) out.push_back(Result::panicked("RangeProofNi::verify: malformed proof (the reference would panic)"));
-      else out.emplace_back(verdict[b] == ZKP_VERDICT_ACCEPT);
+    for (const Plan& pl : plans) {
+      if (pl.panic) { out.push_back(Result::panicked("index out of bounds: the len is less than error_factor")); continue; }
+      bool all = true;
+      for (const Row& r : pl.rows) {
+        bool res = r.what != 0 && r.flag;
+        if (r.what == 1) res = res && E[r.enc0] == r.expect0 && E[r.enc0 + 1] == r.expect1;
+        if (r.what == 2) res = res && E[r.enc0] == r.expect0;
+        all = all && res;
+      }
+      out.emplace_back(all);
     }
     return out;
   }
@@ -375,8 +426,7 @@ struct RangeProof {
   static VerifierCommit verifier_commit(const EncryptionKey& ek) {
     ChallengeBits e;
     e.bytes.resize(STATISTICAL_ERROR_FACTOR / 8);
-    std::random_device rd;
-    for (auto& b : e.bytes) b = (uint8_t)rd();
+    for (auto& b : e.bytes) b = (uint8_t)detail::ChaChaRng::local().next();
     BigInt r = BigInt::sample_below(ek.n);
     return {Commitment{get_paillier_commitment(ek, compute_digest(e.bytes), r)}, ChallengeRandomness{r}, e};
   }
@@ -392,10 +442,9 @@ struct RangeProof {
     const size_t EF = error_factor;
     DataRandomnessPairs d;
     const BigInt third = range.div_floor(BigInt(3)), two_thirds = BigInt(2) * third;   // :133-134
-    std::random_device rd;
     for (size_t i = 0; i < EF; i++) {
       BigInt a = BigInt::sample_range(third, two_thirds), c = a - third;                // :136-141
-      if (rd() & 1) std::swap(a, c);                                                     // :144-149
+      if (BigInt::coin()) std::swap(a, c);                                               // :144-149
       d.w1.push_back(a); d.w2.push_back(c);
       d.r1.push_back(BigInt::sample_below(ek.n)); d.r2.push_back(BigInt::sample_below(ek.n));   // :151-159
     }
@@ -945,6 +994,167 @@ inline NiCorrectKeyProof correct_key_from_str(const EncryptionKey& ek, const std
   NiCorrectKeyProof p;
   for (size_t i = 0; i < NiCorrectKeyProof::M2; i++) p.sigma_vec.push_back(BigInt::from_limbs(&sig[i * kw], kw));
   return p;
+}
+
+// ---- serde_json::from_str::<RangeProofNi> on the HOST, for the documents the GPU reader hands back (status ZKP_DOC_HOST_PATH: a
+// well-formed document holding a number the fixed-width ABI cannot carry — negative or over-wide — or another row count).  Numbers
+// become signed BigInts of any size, so RangeProofNi::verify_batch gives such a proof the reference's verdict (verify_general).
+// encrypted_pairs / proof: decimal strings (serialize.rs:1-78, mpz_set_str: a leading '-' is a sign).  ek.n and the bare BigInts
+// range / ciphertext are un-annotated in the reference (range_proof_ni.rs:38-40): their text forms are the caller's to name,
+// separately (kzen-paillier's EncryptionKey and curv's BigInt need not agree), as for zkp_json_range_proof_ni_batch.
+enum class BigintText { Dec = ZKP_BIGINT_DEC, Hex = ZKP_BIGINT_HEX, Bytes = ZKP_BIGINT_BYTES };
+namespace detail_json {
+struct Cur {
+  const std::string& t; size_t p = 0;
+  [[noreturn]] void fail(const char* what) const { throw std::runtime_error(std::string("serde_json: ") + what + " at byte " + std::to_string(p)); }
+  void ws() { while (p < t.size() && (t[p] == ' ' || t[p] == '\n' || t[p] == '\r' || t[p] == '\t')) p++; }
+  bool eat(char c) { ws(); if (p < t.size() && t[p] == c) { p++; return true; } return false; }
+  void expect(char c) { if (!eat(c)) fail("unexpected token"); }
+  std::string str() {
+    expect('"');
+    std::string out;
+    while (p < t.size() && t[p] != '"') {
+      if (t[p] == '\\') {
+        if (++p >= t.size()) fail("bad escape");
+        const char c = t[p++];
+        if (c == 'u') {
+          if (p + 4 > t.size()) fail("bad \\u escape");
+          const unsigned v = (unsigned)std::stoul(t.substr(p, 4), nullptr, 16); p += 4;
+          if (v > 0x7f) fail("non-ASCII escape in a number or field name");
+          out.push_back((char)v);
+        } else out.push_back(c == 'n' ? '\n' : c == 't' ? '\t' : c == 'r' ? '\r' : c == 'b' ? '\b' : c == 'f' ? '\f' : c);
+      } else out.push_back(t[p++]);
+    }
+    if (p >= t.size()) fail("unterminated string");
+    p++;
+    return out;
+  }
+  uint64_t uint() {
+    ws();
+    if (p >= t.size() || t[p] < '0' || t[p] > '9') fail("expected an unsigned integer");
+    uint64_t v = 0;
+    while (p < t.size() && t[p] >= '0' && t[p] <= '9') { if (v > (~0ull - 9) / 10) fail("integer overflow"); v = v * 10 + (uint64_t)(t[p++] - '0'); }
+    if (p < t.size() && (t[p] == '.' || t[p] == 'e' || t[p] == 'E')) fail("expected an integer");
+    return v;
+  }
+  void skip() {
+    ws();
+    if (p >= t.size()) fail("unexpected end");
+    if (t[p] == '"') { (void)str(); return; }
+    if (t[p] == '{' || t[p] == '[') {
+      const char close = t[p] == '{' ? '}' : ']';
+      p++;
+      if (eat(close)) return;
+      do { if (close == '}') { (void)str(); expect(':'); } skip(); } while (eat(','));
+      expect(close); return;
+    }
+    while (p < t.size() && t[p] != ',' && t[p] != '}' && t[p] != ']' && t[p] != ' ' && t[p] != '\n') p++;
+  }
+  template <class F> void object(F&& field) {      // field(name) consumes the value and returns true, or returns false (unknown: skipped)
+    expect('{');
+    if (eat('}')) return;
+    do { const std::string nm = str(); expect(':'); if (!field(nm)) skip(); } while (eat(','));
+    expect('}');
+  }
+  BigInt dec() { const std::string s = str(); try { return BigInt::from_str_radix10(s); } catch (const std::invalid_argument&) { fail("not a decimal integer"); } }
+  BigInt bigint(BigintText form) {
+    if (form == BigintText::Dec) return dec();
+    if (form == BigintText::Bytes) {
+      std::vector<uint8_t> b;
+      expect('[');
+      if (!eat(']')) { do { const uint64_t v = uint(); if (v > 255) fail("byte out of range"); b.push_back((uint8_t)v); } while (eat(',')); expect(']'); }
+      return BigInt::from_bytes(b);
+    }
+    std::string h = str();
+    const bool minus = !h.empty() && h[0] == '-';
+    if (minus) h.erase(0, 1);
+    if (h.empty()) fail("empty hex integer");
+    BigInt r;
+    r.l.assign((h.size() + 7) / 8, 0);
+    for (size_t i = 0; i < h.size(); i++) {
+      const char c = h[h.size() - 1 - i];
+      const int v = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
+      if (v < 0) fail("not a hex integer");
+      r.l[i / 8] |= (uint32_t)v << (4 * (i % 8));
+    }
+    r.trim();
+    r.neg = minus && !r.is_zero();
+    return r;
+  }
+};
+}  // namespace detail_json
+
+inline RangeProofNi range_proof_ni_from_str(const std::string& doc, BigintText key_form = BigintText::Dec, BigintText bigint_form = BigintText::Dec) {
+  detail_json::Cur j{doc};
+  RangeProofNi out;
+  unsigned seen = 0;
+  auto once = [&](unsigned bit) { if (seen & bit) j.fail("duplicate field"); seen |= bit; };
+  auto vec = [&](std::vector<BigInt>& v) { j.expect('['); if (!j.eat(']')) { do v.push_back(j.dec()); while (j.eat(',')); j.expect(']'); } };
+  j.object([&](const std::string& nm) {
+    if (nm == "ek") {
+      once(1);
+      bool has_n = false;
+      j.object([&](const std::string& f) { if (f != "n") return false; if (has_n) j.fail("duplicate field"); has_n = true; out.ek.n = j.bigint(key_form); return true; });
+      if (!has_n) j.fail("missing field `n`");
+      out.ek.nn = out.ek.n * out.ek.n;       // MinimalEncryptionKey -> EncryptionKey { n, nn = n * n } [upstream kzen-paillier]
+    } else if (nm == "range") { once(2); out.range = j.bigint(bigint_form); }
+    else if (nm == "ciphertext") { once(4); out.ciphertext = j.bigint(bigint_form); }
+    else if (nm == "encrypted_pairs") {
+      once(8);
+      unsigned s2 = 0;
+      j.object([&](const std::string& f) {
+        if (f == "c1") { if (s2 & 1) j.fail("duplicate field"); s2 |= 1; vec(out.encrypted_pairs.c1); return true; }
+        if (f == "c2") { if (s2 & 2) j.fail("duplicate field"); s2 |= 2; vec(out.encrypted_pairs.c2); return true; }
+        return false;
+      });
+      if (s2 != 3) j.fail("missing field of EncryptedPairs");
+    } else if (nm == "proof") {
+      once(16);
+      j.expect('[');
+      if (!j.eat(']')) {
+        do {
+          Response rs;
+          int variants = 0;
+          j.object([&](const std::string& var) {
+            if (++variants > 1) j.fail("expected a single-variant enum map");
+            unsigned s3 = 0;
+            if (var == "Open") {
+              rs.kind = Response::Open;
+              j.object([&](const std::string& f) {
+                BigInt* dst = f == "w1" ? &rs.w1 : f == "r1" ? &rs.r1 : f == "w2" ? &rs.w2 : f == "r2" ? &rs.r2 : nullptr;
+                if (!dst) return false;
+                const unsigned bit = f == "w1" ? 1 : f == "r1" ? 2 : f == "w2" ? 4 : 8;
+                if (s3 & bit) j.fail("duplicate field");
+                s3 |= bit;
+                *dst = j.dec();
+                return true;
+              });
+              if (s3 != 15) j.fail("missing field of Response::Open");
+            } else if (var == "Mask") {
+              rs.kind = Response::Mask;
+              j.object([&](const std::string& f) {
+                if (f == "j") { if (s3 & 1) j.fail("duplicate field"); s3 |= 1; const uint64_t v = j.uint(); if (v > 255) j.fail("j is a u8"); rs.j = (uint8_t)v; return true; }
+                if (f == "masked_x") { if (s3 & 2) j.fail("duplicate field"); s3 |= 2; rs.masked_x = j.dec(); return true; }
+                if (f == "masked_r") { if (s3 & 4) j.fail("duplicate field"); s3 |= 4; rs.masked_r = j.dec(); return true; }
+                return false;
+              });
+              if (s3 != 7) j.fail("missing field of Response::Mask");
+            } else j.fail("unknown variant of Response");
+            return true;
+          });
+          if (variants != 1) j.fail("expected a single-variant enum map");
+          out.proof.responses.push_back(std::move(rs));
+        } while (j.eat(','));
+        j.expect(']');
+      }
+    } else if (nm == "error_factor") { once(32); out.error_factor = (size_t)j.uint(); }
+    else return false;
+    return true;
+  });
+  if (seen != 63u) j.fail("missing field of RangeProofNi");
+  j.ws();
+  if (j.p != doc.size()) j.fail("trailing characters");
+  return out;
 }
 }  // namespace serde_json
 
