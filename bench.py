@@ -243,6 +243,36 @@ class ClockSampler:
         return out
 
 
+def gpu_identity(device_index, rank=0):
+    """which physical GPU a rank's numbers come from (the boxes of the pool differ by up to 6 %: without this a regression of that
+    size cannot be told from a slower board): PCI bus id, the board's unique id and VBIOS from sysfs where readable"""
+    out = {"rank": rank, "device_index": int(device_index)}
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+            bus = buf.value.decode().lower()
+            out["pci_bus"] = bus
+            for key, fn in (("unique_id", "unique_id"), ("vbios", "vbios_version"), ("power_cap_w", None)):
+                try:
+                    if fn:
+                        out[key] = open(f"/sys/bus/pci/devices/{bus}/{fn}").read().strip()
+                    else:
+                        caps = glob.glob(f"/sys/bus/pci/devices/{bus}/hwmon/hwmon*/power1_cap")
+                        if caps:
+                            out[key] = int(open(caps[0]).read()) / 1e6
+                except (OSError, ValueError):
+                    pass
+    except Exception:
+        pass
+    try:
+        out["hostname"] = os.uname().nodename
+    except Exception:
+        pass
+    return out
+
+
 class GpuEngine:
     """the product path: the C ABI on device-resident buffers (raises if the HIP library / a gfx950 GPU is missing)"""
 
@@ -270,26 +300,36 @@ def block_counts(total, world):
     return [shard.shard_range(total, world, r)[1] - shard.shard_range(total, world, r)[0] for r in range(world)]
 
 
-def make_steps(engine, pb, wt, verdict, world, counts=None):
+def make_steps(engine, pb, wt, verdict, world, counts=None, gather="all"):
     """the two timed step functions.  `engine` supplies prove / verify on this rank's block of proofs; the gather of the output
     slabs goes through zk-paillier_amd/shard.py (RCCL on GPUs; tests/test_distributed_gloo.py drives these same functions over gloo).
-    counts: proofs per rank when the blocks are unequal (a total that N does not divide), else None."""
+    counts: proofs per rank when the blocks are unequal (a total that N does not divide), else None.
+    gather: "all" (north_star: the c1 / c2 slabs of a prove step are reassembled on every rank, 2 x 128 KiB per proof at n = 2048)
+    or "verdicts" (a prove step exchanges nothing: each rank keeps its own proofs; verify steps always gather their verdict bytes).
+    The receive buffers are allocated HERE, once, not inside the timed steps; out["recv_bytes"] = bytes this rank receives per step."""
     shard = importlib.import_module("zk-paillier_amd.shard")
     out = {}
     if counts is not None and len(set(counts)) == 1:
         counts = None
+    assert gather in ("all", "verdicts")
+    bufs = {"verdict": shard.GatherBuffers(verdict, world, counts)}
+    if gather == "all":
+        bufs["c1"] = shard.GatherBuffers(pb.c1, world, counts)
+        bufs["c2"] = shard.GatherBuffers(pb.c2, world, counts)
+    out["recv_bytes"] = {"prove": sum(bufs[k].nbytes for k in ("c1", "c2") if k in bufs), "verify": bufs["verdict"].nbytes}
 
     def prove_step():
         engine.prove(pb, wt)
         engine.before_collective()
-        out["c1"] = shard.all_gather_slabs(pb.c1, world, counts)
-        out["c2"] = shard.all_gather_slabs(pb.c2, world, counts)
+        if gather == "all":
+            out["c1"] = shard.all_gather_slabs(pb.c1, world, counts, bufs["c1"])
+            out["c2"] = shard.all_gather_slabs(pb.c2, world, counts, bufs["c2"])
         engine.after_collective()
 
     def verify_step():
         engine.verify(pb, verdict)
         engine.before_collective()
-        out["verdict"] = shard.all_gather_slabs(verdict, world, counts)
+        out["verdict"] = shard.all_gather_slabs(verdict, world, counts, bufs["verdict"])
         engine.after_collective()
 
     return prove_step, verify_step, out
@@ -320,9 +360,13 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU (weak scaling) / in all (strong scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch proofs per rank; strong: --batch proofs in all, cut into N blocks of proof indices")
+    ap.add_argument("--gather", choices=["all", "verdicts"], default="all",
+                    help="what a PROVE step exchanges: all = the c1 / c2 slabs are all-gathered onto every rank (north_star; 2 x 128 KiB per proof "
+                         "at n = 2048: 4.3 GB received per rank per step at 8 x 4096 proofs); verdicts = nothing (each rank keeps its proofs)")
     ap.add_argument("--n-bits", type=int, default=2048)
     ap.add_argument("--cpu-sample", type=int, default=64, help="proofs verified by the all-cores CPU baseline (0 = skip the CPU legs and the oracle samples)")
     ap.add_argument("--no-prove-leg", action="store_true")
+    ap.add_argument("--no-host-api-leg", action="store_true", help="skip the C++ host-API leg (tests/cpp/host_bench.cpp; rank 0 at N = 1 only)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the legs for the other BASELINE.json configurations")
     ap.add_argument("--other-reps", type=int, default=3, help="repetitions of each other_configs leg (min and median reported)")
     ap.add_argument("--big-batch", type=int, default=4096, help="proofs IN ALL of the n=4096 leg (configs[4]); 0 = skip")
@@ -470,15 +514,18 @@ def main():
     ctx.paillier_enc(n_bits, B, pb.n, 0, wt.x, wt.r, pb.ciphertext)
     sync()
     verdict = torch.zeros(B, dtype=torch.uint8, device=dev)
-    prove_step, verify_step, gathered = make_steps(engine, pb, wt, verdict, world, counts)
+    prove_step, verify_step, gathered = make_steps(engine, pb, wt, verdict, world, counts, args.gather)
+    recv_bytes = gathered.pop("recv_bytes")
 
     # ---- prove leg (also produces the proofs the verify leg consumes)
     prove = None
     if args.no_prove_leg:
         engine.prove(pb, wt); sync()
     else:
-        dt, kms, launches, modexps = timed(prove_step, args.steps, args.warmup)
-        prove = {"value": B_total * args.steps / dt, "unit": "proofs/s", "ms_per_step": 1e3 * dt / args.steps,
+        with ClockSampler(local_rank) as clk_p:
+            dt, kms, launches, modexps = timed(prove_step, args.steps, args.warmup)
+        prove = {"value": B_total * args.steps / dt, "unit": "proofs/s", "ms_per_step": 1e3 * dt / args.steps, "clock": clk_p.summary(),
+                 "gather": args.gather, "gather_recv_bytes_per_rank_per_step": recv_bytes["prove"],
                  "enc_kernel_ms_per_launch": kms / max(launches, 1), "launches": launches,
                  "achieved_limb_mac_per_s": modexps * enc_limb_macs(n_bits) / (kms * 1e-3) if kms else None,
                  "frac": modexps * enc_limb_macs(n_bits) / (kms * 1e-3) / PEAK_LIMB_MAC_PER_S if kms else None}
@@ -498,6 +545,7 @@ def main():
     ok = ok and bool(torch.equal(gathered["verdict"][my_lo:my_lo + B], expect)) and gathered["verdict"].shape[0] == B_total
     if "c1" in gathered:
         ok = ok and bool(torch.equal(gathered["c1"][my_lo:my_lo + B], pb.c1))
+    ok = ok and (("c1" in gathered) == (args.gather == "all" and not args.no_prove_leg))
     value = B_total * args.steps / dt
     roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc<{144 // lpl}, true> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer; sliding-window ladder, squarings at 3/4 of a product)", clk.summary(), executed_lane_mads_per_enc(n, n_bits, True))
     ms_per_step = 1e3 * dt / args.steps
@@ -512,13 +560,24 @@ def main():
         if not args.no_pcie_leg:
             pcie, same = pcie_leg(ctx, pb, expect, np, B)
             ok = ok and same
+    host_api = None
+    if rank == 0 and world == 1 and not args.no_host_api_leg:
+        host_api, same = host_api_leg(B)
+        ok = ok and same
     if not args.no_other_configs:
         env = dict(args=args, ctx=ctx, engine=engine, synth=synth, shard=shard, torch=torch, dist=dist, dev=dev, sync=sync, barrier=barrier,
-                   timed_reps=timed_reps, enc_roofline=enc_roofline, lpl=lpl, np=np, world=world, rank=rank, pb=pb, wt=wt)
+                   timed_reps=timed_reps, enc_roofline=enc_roofline, lpl=lpl, np=np, world=world, rank=rank, pb=pb, wt=wt, local_rank=local_rank)
         other, same = other_configs(env)
         ok = ok and same
     okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
     dist.all_reduce(okt, op=dist.ReduceOp.MIN)          # a failed self-check on ANY rank fails the line
+    # which board every rank ran on, with the clock and power it held during the timed verify steps
+    mine = dict(gpu_identity(local_rank, rank), verify_clock=clk.summary(), verify_kernel_ms_per_launch=kms / max(launches, 1))
+    gpus = [None] * world
+    if world > 1:
+        dist.all_gather_object(gpus, mine)
+    else:
+        gpus = [mine]
     ok = bool(okt.item())
 
     if rank == 0:
@@ -530,9 +589,11 @@ def main():
                "verdicts_ok": ok,
                "config": {"workload": f"BASELINE.json configs[1]: batch={args.batch} RangeProofNi verify {per}, n={n_bits} (reference fixture key), "
                                       f"128 rows/proof, 1/64 of the proofs tampered; prove leg = configs[2]",
-                          "parallelism": f"proof-index sharding x{world}, one RCCL all-gather per step of verdicts (verify) and c1/c2 slabs (prove) via zk-paillier_amd/shard.py",
+                          "parallelism": f"proof-index sharding x{world}, one RCCL all-gather per step of verdicts (verify)" + (" and c1/c2 slabs (prove)" if args.gather == "all" else "; --gather verdicts: a prove step exchanges nothing") + " via zk-paillier_amd/shard.py (receive buffers allocated once, outside the timed steps)",
+                          "gather": args.gather, "gather_recv_bytes_per_rank_per_step": recv_bytes,
                           "proofs_per_rank": B, "proofs_total": B_total},
-               "prove": prove, "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "other_configs": other}
+               "gpus": gpus,
+               "prove": prove, "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "host_api": host_api, "other_configs": other}
         # RCCL writes a version banner through C stdio when the communicator is created; push it out first so that the
         # JSON line is the LAST line on stdout
         import ctypes
@@ -583,6 +644,8 @@ def cpu_baseline(args, pb, wt, verdict, np):
         lat[label] = {"threads": th, "prove_ms": 1e3 * (t1 - t0), "verify_ms": 1e3 * (t2 - t1), "prove_plus_verify_ms": 1e3 * (t2 - t0), "accepted": bool(v1[0] == 1)}
     one = lat["1_thread"]
     cpu = {"value": S / t_v, "unit": "verifies/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+           "cores_note": f"{threads} threads = what this process may use (affinity / cgroup quota) of the box's {os.cpu_count()} hardware threads: "
+                         f"'all cores' below means these {threads}, a fraction of the socket; per-core rates scale linearly (independent mpz_powm calls)",
            "sample": f"oracle (C + GMP 6.2.1 mpz_powm, OpenMP over (proof,row)) verifying proofs 0..{S-1} of the same batch in {t_v:.2f}s; verdicts equal to GPU: {same}",
            "prove": {"value": P / t_p, "unit": "proofs/s", "cores": threads,
                      "sample": f"the same oracle proving proofs 0..{P-1} from the same witnesses in {t_p:.2f}s; c1 equal to GPU: {same_p}"},
@@ -590,6 +653,28 @@ def cpu_baseline(args, pb, wt, verdict, np):
                              "sample": "one proof of the batch proved and verified on one thread (BASELINE configs[0], benches/all.rs:55-71)"},
            "configs[0] one RangeProofNi, n=2048, CPU reference path": lat}
     return cpu, same and same_p
+
+
+def host_api_leg(B):
+    """the reference-shaped HOST API end to end (the round-3 verdict's "host API cost is unmeasured"): tests/cpp/host_bench.cpp drives
+    RangeProofNi::prove_batch / verify_batch of zk-paillier_amd/host/zkproofs.hpp at B proofs — sampling 4 x 128 values per proof,
+    BigInt <-> limb flattening, the GPU call on pageable host buffers, rebuilding the proof objects — in its own process (its own
+    ctx on this rank's GPU, after this process has gone idle).  Not part of `value`."""
+    src = os.path.join(ROOT, "tests", "cpp", "host_bench.cpp")
+    exe = os.path.join(ROOT, "build", "host_bench")
+    pkg = os.path.join(ROOT, "zk-paillier_amd")
+    try:
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        deps = [src, os.path.join(pkg, "host", "zkproofs.hpp"), os.path.join(pkg, "host", "bigint.hpp")]
+        if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", exe, "-L" + pkg, "-lzkp_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+        out = subprocess.run([exe, str(B)], capture_output=True, text=True, timeout=900)
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:                         # no compiler on the box, a build error: the leg is reported as missing, the line survives
+        return {"error": f"{type(e).__name__}: {e}"}, True
+    rec["what"] = ("host/zkproofs.hpp RangeProofNi::{prove,verify}_batch, n=2048, fixture key: wall time of the whole call; host_share = 1 - gpu_call_ms / ms "
+                   "(gpu_call_ms = zkp_range_ni_{prove,verify}_batch with pageable host buffers, i.e. staging + PCIe + kernels)")
+    return rec, bool(rec.get("all_accepted")) and out.returncode == 0
 
 
 def pcie_leg(ctx, pb, expect, np, B):
@@ -708,14 +793,17 @@ def other_configs(env):
         sync()
         ctx.paillier_enc(nb, Bx, pbx.n, 0 if isinstance(nkey, int) else nb // 32, wtx.x, wtx.r, pbx.ciphertext); sync()
         vx = torch.full((Bx,), 9, dtype=torch.uint8, device=dev)
-        p_step, v_step, outx = make_steps(engine, pbx, wtx, vx, world, block_counts(total, world))
-        rp = timed_reps(p_step, reps)
-        gathered_ok = outx["c1"].shape[0] == total
+        p_step, v_step, outx = make_steps(engine, pbx, wtx, vx, world, block_counts(total, world), args.gather)
+        recv_x = outx.pop("recv_bytes")
+        with ClockSampler(env["local_rank"]) as clkx:
+            rp = timed_reps(p_step, reps)
+        gathered_ok = outx["c1"].shape[0] == total if args.gather == "all" else "c1" not in outx
         outx.clear()
         bad = torch.arange(0, Bx, 64, device=dev)
         pbx.resp_r1[bad, 0, 0] ^= 1
         exp = torch.ones(Bx, dtype=torch.uint8, device=dev); exp[bad] = 0
-        rv = timed_reps(v_step, reps)
+        with ClockSampler(env["local_rank"]) as clkv:
+            rv = timed_reps(v_step, reps)
         good = bool(torch.equal(vx, exp)) and gathered_ok and outx["verdict"].shape[0] == total
         kp, mp = min(r[1] for r in rp), rp[0][3]
         iv = min(range(len(rv)), key=lambda i: rv[i][1])
@@ -724,8 +812,10 @@ def other_configs(env):
                "verifies_per_s": sv["verifies_per_s"], "verifies_per_s_median": sv["verifies_per_s_median"],
                "prove_ms": sp["ms_min"], "prove_ms_all": sp["ms_all"], "verify_ms": sv["ms_min"], "verify_ms_all": sv["ms_all"], "reps": sp["reps"],
                "verdicts_ok": good, "prove_frac": mp * enc_limb_macs(nb) / (kp * 1e-3) / PEAK_LIMB_MAC_PER_S if kp else None,
-               "roofline": enc_roofline(rv[iv][1], rv[iv][2], rv[iv][3], nb, kernel),
-               "parallelism": f"proof-index blocks x{world} + all-gather of c1/c2 (prove) and verdict bytes (verify)"}
+               "roofline": enc_roofline(rv[iv][1], rv[iv][2], rv[iv][3], nb, kernel, clkv.summary()),
+               "gpu": gpu_identity(env["local_rank"], rank), "clock_prove": clkx.summary(),
+               "gather": args.gather, "gather_recv_bytes_per_rank": recv_x,
+               "parallelism": f"proof-index blocks x{world} + all-gather of " + ("c1/c2 (prove) and " if args.gather == "all" else "") + "verdict bytes (verify)"}
         if oracle is not None and sample > 0:
             S = min(sample, Bx)
             host = pbx.slice(0, S).to(None)            # contains tampered proof 0

@@ -36,6 +36,8 @@ pub const ZKP_DOC_HOST_PATH: u8 = 3;
 pub const ZKP_BIGINT_DEC: u32 = 0;
 pub const ZKP_BIGINT_HEX: u32 = 1;
 pub const ZKP_BIGINT_BYTES: u32 = 2;
+pub const ZKP_GATHER_HOST: u32 = 0;
+pub const ZKP_GATHER_RCCL: u32 = 1;
 /// `ZKP_BIGINT_FORMS(key_form, bare_form)`: the text forms of `ek.n` and of the bare BigInts of a RangeProofNi document
 pub const fn ZKP_BIGINT_FORMS(key_form: u32, bare_form: u32) -> u32 {
     (key_form << 4) | bare_form
@@ -144,6 +146,8 @@ extern "C" {
     pub fn zkp_multi_ctx(m: *mut zkp_multi, i: u32) -> *mut zkp_ctx;
     pub fn zkp_multi_last_error_string(m: *mut zkp_multi) -> *const c_char;
     pub fn zkp_multi_last_timing(m: *mut zkp_multi, i: u32, out_ms: *mut f64, out_lo: *mut u64, out_hi: *mut u64) -> i32;
+    pub fn zkp_multi_set_gather(m: *mut zkp_multi, mode: u32) -> i32;
+    pub fn zkp_multi_gathered(m: *mut zkp_multi, device_index: u32, which: u32, out_device_ptr: *mut *mut c_void, out_block_stride_bytes: *mut u64, out_bytes: *mut u64) -> i32;
     pub fn zkp_multi_range_ni_prove_batch(m: *mut zkp_multi, p: *const zkp_range_ni_proofs, w: *const zkp_range_ni_witness, out_e: *mut u8, out_e_len: *mut u8, out_status: *mut u8) -> i32;
     pub fn zkp_multi_range_ni_verify_batch(m: *mut zkp_multi, p: *const zkp_range_ni_proofs, out_verdict: *mut u8) -> i32;
     pub fn zkp_multi_correct_key_ni_verify_batch(m: *mut zkp_multi, n_bits: u32, batch: u64, n: *const u32, sigma: *const u32, salt: *const u8, salt_len: u32, out_verdict: *mut u8) -> i32;

@@ -5,6 +5,8 @@
  *   gcc -O2 -I../include multi_gpu_verify.c -L../zk-paillier_amd -lzkp_hip -Wl,-rpath,$PWD/../zk-paillier_amd -o multi_gpu_verify
  *   ./multi_gpu_verify 0 1 2 3        # device ids, one context each (an id may repeat: "0 0" = two contexts on GPU 0)
  *   ZKP_DEVICES=0,1,2,3,4,5,6,7 ZKP_BATCH=4096 ./multi_gpu_verify      # the same from the environment: a one-command check on an 8-GPU node
+ *   ZKP_GATHER=rccl ZKP_DEVICES=0,1,2,3,4,5,6,7 ./multi_gpu_verify     # outputs reassembled by RCCL all-gathers inside the library (distinct
+ *                                                                      # GPUs): the whole c1 / c2 / verdicts end up device-resident on EVERY GPU
  *
  * Prints the block and the wall time of every device context for the prove and the verify call (zkp_multi_last_timing), then runs
  * the SAME batch through ONE context (device of the first id) and compares ciphertexts, responses and verdicts byte for byte:
@@ -70,6 +72,8 @@ int main(int argc, char** argv) {
   const uint64_t B = getenv("ZKP_BATCH") && atoll(getenv("ZKP_BATCH")) > 8 ? (uint64_t)atoll(getenv("ZKP_BATCH")) : 64;
   zkp_multi* m = NULL;
   if (zkp_multi_create(devs, nd, &m) != ZKP_OK) { fprintf(stderr, "zkp_multi_create failed: no gfx950 GPU (there is no CPU fallback)\n"); return 2; }
+  const int rccl = getenv("ZKP_GATHER") && strcmp(getenv("ZKP_GATHER"), "rccl") == 0;
+  if (rccl && zkp_multi_set_gather(m, ZKP_GATHER_RCCL) != ZKP_OK) { fprintf(stderr, "zkp_multi_set_gather(RCCL) failed: %s\n", zkp_multi_last_error_string(m)); return 3; }
 
   const size_t rows = B * EF;
   uint32_t* n = calloc(KW, 4);
@@ -102,6 +106,14 @@ int main(int argc, char** argv) {
   rr1[(5 * EF + 0) * KW] ^= 1;                                                      /* tamper proof 5 */
   CHECK(zkp_multi_range_ni_verify_batch(m, &p, verdict));                          /* RangeProofNi::verify_self x B */
   print_timing(m, devs, "verify");
+  if (rccl) {       /* the gathered verdicts are device-resident on every GPU: block i at i * stride */
+    for (uint32_t i = 0; i < zkp_multi_size(m); i++) {
+      void* dp = NULL; uint64_t stride = 0, bytes = 0;
+      CHECK(zkp_multi_gathered(m, i, 0, &dp, &stride, &bytes));
+      printf("  gather=rccl context %u (device %d): verdicts of all %llu proofs at %p, %llu bytes, block stride %llu\n", i, devs[i], (unsigned long long)B, dp,
+             (unsigned long long)bytes, (unsigned long long)stride);
+    }
+  }
   unsigned accepted = 0, bad_status = 0;
   for (uint64_t b = 0; b < B; b++) { accepted += verdict[b] == ZKP_VERDICT_ACCEPT; bad_status += status[b] != 0; }
   printf("contexts=%u proofs=%llu accepted=%u rejected=%llu prove_status_errors=%u verdict[5]=%u\n", zkp_multi_size(m), (unsigned long long)B, accepted,

@@ -380,11 +380,11 @@ int32_t zkp_json_correct_key_proof_batch(zkp_ctx* ctx, const char* text, const u
 /* ------------------------------------------------------------------ several GPUs behind one caller
  * The reference spreads a proof's rows over a rayon pool (src/zkproofs/range_proof.rs:161-187,270-348); here a batch
  * is cut into contiguous blocks of PROOF indices, one block per device context, one host thread per context
- * (the only threads this library starts).  Host pointers only: every block reads its slice of the caller's arrays and
- * writes its slab of the caller's output arrays, so the per-GPU D2H copy is the reassembly step and no collective is
- * needed inside one process.  (One process per GPU with device-resident results on every GPU — the RCCL all-gather
- * of north_star — is zk-paillier_amd/shard.py + bench.py.)  device_ids may repeat: two contexts on one GPU are two
- * independent streams.  Results are identical to one call of the single-context entry point on the whole batch. */
+ * (the only threads this library starts).  The caller hands over HOST pointers: every block reads its slice of the caller's
+ * arrays and its output slab lands in the caller's output arrays — by per-GPU D2H, or, with ZKP_GATHER_RCCL, after an RCCL
+ * all-gather that also leaves the whole result device-resident on every GPU (below).  (One PROCESS per GPU — torch.distributed
+ * ranks — is zk-paillier_amd/shard.py + bench.py.)  device_ids may repeat in ZKP_GATHER_HOST mode: two contexts on one GPU are
+ * two independent streams.  Results are identical to one call of the single-context entry point on the whole batch. */
 typedef struct zkp_multi zkp_multi;
 int32_t zkp_multi_create(const int32_t* device_ids, uint32_t n_devices, zkp_multi** out);
 int32_t zkp_multi_destroy(zkp_multi* m);
@@ -394,6 +394,23 @@ const char* zkp_multi_last_error_string(zkp_multi* m);
 /* the most recent batch call, per device context i: the block [lo, hi) of items it was given and the wall time of its share
  * (staging, launches and the D2H of its output slab), in milliseconds */
 int32_t zkp_multi_last_timing(zkp_multi* m, uint32_t i, double* out_ms, uint64_t* out_lo, uint64_t* out_hi);
+/* Where the outputs of the batch calls below are reassembled.
+ *   ZKP_GATHER_HOST (default): every context copies its output slab into the caller's host arrays (one D2H per GPU, no collective).
+ *   ZKP_GATHER_RCCL: every context works on device-resident copies of its block and writes its slab into its segment of a buffer
+ *     holding the WHOLE batch; one grouped ncclAllGather per output (RCCL over xGMI, on the contexts' streams) then leaves the whole
+ *     gathered output in the memory of EVERY GPU, and the caller's host arrays are filled from one GPU's copy — same bytes as
+ *     ZKP_GATHER_HOST.  Gathered: the verdict bytes of the verify calls; status bytes, c1 and c2 of a prove call.  The first switch
+ *     to ZKP_GATHER_RCCL creates one communicator per context (ncclCommInitAll): ZKP_EDEVICE with RCCL's text
+ *     (zkp_multi_last_error_string) if that fails, e.g. for a device listed twice.
+ * zkp_multi_gathered: the device-resident result of the most recent ZKP_GATHER_RCCL call on device context `device_index`:
+ *   which = 0 verdict / status bytes, 1 c1, 2 c2.  Blocks of unequal size are padded to the largest: block i (the items
+ *   zkp_multi_last_timing reports for context i) starts at i * *out_block_stride_bytes; *out_bytes = n_contexts * stride.  The pointer
+ *   stays valid until the next batch call or zkp_multi_destroy; work that consumes it is ordered on zkp_ctx_stream(zkp_multi_ctx(m, i)). */
+#define ZKP_GATHER_HOST 0u
+#define ZKP_GATHER_RCCL 1u
+int32_t zkp_multi_set_gather(zkp_multi* m, uint32_t mode);
+int32_t zkp_multi_gathered(zkp_multi* m, uint32_t device_index, uint32_t which, void** out_device_ptr, uint64_t* out_block_stride_bytes,
+                           uint64_t* out_bytes);
 int32_t zkp_multi_range_ni_prove_batch(zkp_multi* m, const zkp_range_ni_proofs* p, const zkp_range_ni_witness* w,
                                        uint8_t* out_e, uint8_t* out_e_len, uint8_t* out_status);
 int32_t zkp_multi_range_ni_verify_batch(zkp_multi* m, const zkp_range_ni_proofs* p, uint8_t* out_verdict);

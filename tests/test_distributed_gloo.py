@@ -132,9 +132,20 @@ def _bench_worker(rank, world, port, n_bits, B, ret):
     oracle = oracle_lib.Oracle()
     pb, wt = _rank_batch(rank, n_bits, B, oracle)
     verdict = torch.zeros(B, dtype=torch.uint8)
+    # --gather verdicts: a prove step exchanges nothing, the verify step still gathers its verdict bytes; receive buffers are
+    # allocated by make_steps, once (their sizes are what bench.py prints per rank)
+    p2, v2, out2 = bench.make_steps(_OracleEngine(oracle), pb, wt, verdict, world, None, "verdicts")
+    p2(); v2()
+    verdicts_mode = ("c1" not in out2, out2["verdict"].tolist(), out2["recv_bytes"])
     prove_step, verify_step, out = bench.make_steps(_OracleEngine(oracle), pb, wt, verdict, world)
+    recv = out["recv_bytes"]
+    assert recv == {"prove": 2 * world * B * 128 * (2 * n_bits // 32) * 4, "verify": world * B} and verdicts_mode[2] == {"prove": 0, "verify": world * B}
     prove_step()
+    first_buffer = out["c1"].data_ptr()
     verify_step()
+    prove_step()                                    # a second step reuses the receive buffers
+    assert out["c1"].data_ptr() == first_buffer
+    assert verdicts_mode[0] and verdicts_mode[1] == out["verdict"].tolist()
     if rank == 0:
         # single-process reference: both ranks' batches proved and verified here
         exp_v, exp_c1 = [], []

@@ -26,7 +26,7 @@ def build_exe():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     deps = [SRC, os.path.join(PKG, "host", "zkproofs.hpp"), os.path.join(PKG, "host", "bigint.hpp"), H.zkp.LIB_PATH]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", SRC, "-o", EXE, "-L" + PKG, "-lzkp_hip",
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", SRC, "-o", EXE, "-L" + PKG, "-lzkp_hip",
                                "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
     return EXE
 

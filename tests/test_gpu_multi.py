@@ -104,6 +104,75 @@ def test_c_example_takes_devices_and_batch_from_the_environment():
     assert "contexts=2 proofs=24 accepted=23 rejected=1" in out.stdout and "proofs [12, 24)" in out.stdout
 
 
+def test_rccl_gather_inside_the_library_equals_the_host_gather(oracle):
+    """ZKP_GATHER_RCCL at n_devices = 1 — the only communicator a 1-GPU box can have: the degenerate all-gather still goes through
+    real RCCL (ncclCommInitAll, grouped ncclAllGather on the ctx stream), and every byte the caller gets must equal the D2H path's;
+    the gathered result is device-resident (read back here through torch)"""
+    import torch
+    n_bits, B, kw, EF = 1024, 5, 32, 128
+    n = H.test_key(1024)[2]
+    cases = H.build_range_case(b"multi-rccl", [n], n_bits, B)
+    cases[2] = H.build_range_case(b"multi-rccl-bad", [n], n_bits, 1, honest=False)[0]
+    pb_h, wt = H.fill_batch(cases, n_bits, True, oracle)
+    pb_r = pb_h.to(None)
+    m = zkp.MultiContext([0])
+    out = {}
+    for mode, pb in ((zkp.GATHER_HOST, pb_h), (zkp.GATHER_RCCL, pb_r)):
+        m.set_gather(mode)
+        e = np.zeros((B, 32), np.uint8); elen = np.zeros(B, np.uint8); st = np.full(B, 9, np.uint8)
+        m.range_ni_prove(pb.struct(), wt.struct(), e, elen, st)
+        if mode == zkp.GATHER_RCCL:
+            for which, host in ((1, pb.c1), (2, pb.c2)):          # c1 / c2 of the whole batch sit in device memory
+                dp, stride, total = m.gathered(0, which)
+                assert stride == B * EF * 2 * kw * 4 and total == stride
+                dev = torch.empty(total, dtype=torch.uint8, device="cuda:0")
+                assert torch.cuda.current_stream().synchronize() is None
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                assert hip.hipMemcpy(ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(dp), ctypes.c_size_t(total), 3) == 0        # hipMemcpyDeviceToDevice
+                assert np.array_equal(dev.cpu().numpy().view(np.uint32).reshape(host.shape), host)
+        pb.resp_r1[1, 3, 0] ^= 2
+        v = np.full(B, 9, np.uint8)
+        m.range_ni_verify(pb.struct(), v)
+        out[mode] = (e.copy(), elen.copy(), st.copy(), v.copy())
+    for f in ("c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2"):
+        assert np.array_equal(getattr(pb_h, f), getattr(pb_r, f)), f
+    for a, b in zip(out[zkp.GATHER_HOST], out[zkp.GATHER_RCCL]):
+        assert np.array_equal(a, b)
+    assert list(out[zkp.GATHER_RCCL][3]) == [1, 0, 0, 1, 1] and not out[zkp.GATHER_RCCL][2].any()
+    # NiCorrectKeyProof verdicts through the same gather
+    keys = [H.test_key(1024, tag=t) for t in range(5)]
+    n_arr = L.ints_to_limbs([k[2] for k in keys], 32)
+    sig = np.stack([L.ints_to_limbs(pm.correct_key_proof(k[0], k[1], b"KZen"), 32) for k in keys])
+    sig[1, 0, 0] ^= 1
+    v = np.full(5, 9, np.uint8)
+    m.correct_key_ni_verify(1024, 5, n_arr, sig, b"KZen", v)
+    assert list(v) == [1, 0, 1, 1, 1]
+    m.close()
+
+
+def test_rccl_gather_needs_distinct_devices():
+    """a device listed twice has no RCCL communicator: ZKP_EDEVICE with a text, and the context set keeps working on the host gather"""
+    m = zkp.MultiContext([0, 0])
+    with pytest.raises(zkp.ZkpError, match="listed twice"):
+        m.set_gather(zkp.GATHER_RCCL)
+    m.close()
+
+
+def test_c_example_with_the_rccl_gather():
+    import os
+    import subprocess
+    env = dict(os.environ, ZKP_GATHER="rccl", ZKP_DEVICES="0", ZKP_BATCH="24")
+    out = subprocess.run([_build_c_example()], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "contexts=1 proofs=24 accepted=23 rejected=1" in out.stdout and "gather=rccl context 0" in out.stdout and "single-context cross-check: identical" in out.stdout
+
+
+def test_library_links_rccl():
+    import subprocess
+    assert "librccl" in subprocess.check_output(["ldd", zkp.LIB_PATH], text=True)
+
+
 def test_multi_last_timing_reports_blocks(oracle):
     keys = [H.test_key(1024, tag=t) for t in range(5)]
     n_arr = L.ints_to_limbs([k[2] for k in keys], 32)

@@ -111,6 +111,8 @@ EXPORTS = {
     "zkp_ctx_set_geometry": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_ctx_last_geometry": (C.c_int32, [C.c_void_p]),
     "zkp_ctx_latency_limbs_per_lane": (C.c_int32, [C.c_void_p]),
+    "zkp_multi_set_gather": (C.c_int32, [C.c_void_p, C.c_uint32]),
+    "zkp_multi_gathered": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "zkp_multi_range_ni_prove_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.POINTER(RangeNiWitness), C.c_void_p, C.c_void_p, C.c_void_p]),
     "zkp_multi_range_ni_verify_batch": (C.c_int32, [C.c_void_p, C.POINTER(RangeNiProofs), C.c_void_p]),
     "zkp_multi_correct_key_ni_verify_batch": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -151,6 +153,7 @@ class DecItem(C.Structure):
 DEC_OK, DEC_INVALID, DEC_NEGATIVE, DEC_OVERFLOW = 0, 1, 2, 3
 BIGINT_DEC, BIGINT_HEX, BIGINT_BYTES = 0, 1, 2
 DOC_OK, DOC_INVALID, DOC_HOST_PATH = 0, 2, 3
+GATHER_HOST, GATHER_RCCL = 0, 1
 
 
 def bigint_forms(key_form: int, bare_form: int) -> int:
@@ -210,6 +213,17 @@ class MultiContext:
             self.check(self.lib.zkp_multi_last_timing(self.h, i, C.byref(ms), C.byref(lo), C.byref(hi)))
             out.append((ms.value, lo.value, hi.value))
         return out
+
+    def set_gather(self, mode: int):
+        """GATHER_HOST (per-GPU D2H) or GATHER_RCCL (one grouped ncclAllGather per output inside the library: the whole result
+        device-resident on every GPU, host arrays filled from one copy)"""
+        self.check(self.lib.zkp_multi_set_gather(self.h, mode))
+
+    def gathered(self, device_index: int, which: int):
+        """(device pointer, block stride in bytes, total bytes) of gathered output `which` (0 verdict/status, 1 c1, 2 c2)"""
+        p, stride, total = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self.check(self.lib.zkp_multi_gathered(self.h, device_index, which, C.byref(p), C.byref(stride), C.byref(total)))
+        return p.value, stride.value, total.value
 
     def range_ni_prove(self, proofs, wit, out_e=None, out_e_len=None, out_status=None):
         self.check(self.lib.zkp_multi_range_ni_prove_batch(self.h, C.byref(proofs), C.byref(wit), ptr(out_e), ptr(out_e_len), ptr(out_status)))

@@ -23,10 +23,15 @@
 // Every modular exponentiation runs on the GPU; this layer only samples, hashes small transcripts
 // (NiCorrectKeyProof::proof's MGF), converts BigInt <-> limbs and flattens proofs into batches.
 #pragma once
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -73,6 +78,40 @@ class Engine {
     if (st != ZKP_OK) throw std::runtime_error(std::string(what) + " failed (status " + std::to_string(st) + "): " + zkp_last_error_string(ctx_));
   }
   static Engine& instance() { static Engine e(0); return e; }
+};
+
+// ------------------------------------------------------------------ host-side parallelism and timing of the batch calls
+// The reference spreads a proof's rows over a rayon pool (range_proof.rs:136-187); here the per-proof HOST work of a batch call —
+// sampling 4 x 128 values, BigInt <-> limb conversion, rebuilding the proof objects — runs on a few threads (ZKP_HOST_THREADS,
+// default min(16, hardware threads)) around the one GPU call.  last_host_timing(): where the time of the most recent
+// RangeProofNi::{prove,verify}_batch went (bench.py's host_api leg prints it next to the GPU step).
+struct HostTiming { double sample_flatten_ms = 0, gpu_ms = 0, rebuild_ms = 0, general_ms = 0; size_t proofs = 0, general_proofs = 0; unsigned threads = 1; };
+inline HostTiming& last_host_timing() { static HostTiming t; return t; }
+inline unsigned host_threads() {
+  static const unsigned n = [] {
+    const char* e = std::getenv("ZKP_HOST_THREADS");
+    unsigned v = e ? (unsigned)std::atoi(e) : std::min(16u, std::thread::hardware_concurrency());
+    return std::max(1u, std::min(v, 64u));
+  }();
+  return n;
+}
+template <class F> inline void parallel_for(size_t count, F body) {
+  const size_t T = std::min<size_t>(host_threads(), count);
+  if (T <= 1) { for (size_t i = 0; i < count; i++) body(i); return; }
+  std::exception_ptr first;
+  std::mutex mu;
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < T; t++)
+    th.emplace_back([&, t] {
+      try { for (size_t i = count * t / T; i < count * (t + 1) / T; i++) body(i); }
+      catch (...) { std::lock_guard<std::mutex> g(mu); if (!first) first = std::current_exception(); }
+    });
+  for (auto& x : th) x.join();
+  if (first) std::rethrow_exception(first);
+}
+struct StopWatch {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double lap() { const auto t1 = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; return ms; }
 };
 
 // kernel width (bits) for an n of the given size
@@ -225,7 +264,10 @@ class RangeProofNi {
     const size_t B = st.size(), EF = SECURITY_PARAMETER, rows = B * EF;
     std::vector<uint32_t> n(kw), range(B * kw), ct(B * 2 * kw), x(B * kw), r(B * kw), w1(rows * kw), w2(rows * kw), r1(rows * kw), r2(rows * kw);
     ek.n.to_limbs(n.data(), kw);
-    for (size_t b = 0; b < B; b++) {
+    HostTiming& tm = last_host_timing();
+    tm = HostTiming(); tm.proofs = B; tm.threads = host_threads();
+    StopWatch sw;
+    parallel_for(B, [&](size_t b) {
       st[b].range.to_limbs(&range[b * kw], kw); st[b].ciphertext.to_limbs(&ct[b * 2 * kw], 2 * kw);
       st[b].secret_x.to_limbs(&x[b * kw], kw); st[b].secret_r.to_limbs(&r[b * kw], kw);
       const BigInt third = st[b].range.div_floor(BigInt(3)), two_thirds = BigInt(2) * third;   // range_proof.rs:133-134
@@ -236,15 +278,18 @@ class RangeProofNi {
         BigInt::sample_below(ek.n).to_limbs(&r1[(b * EF + i) * kw], kw);                         // :151-159
         BigInt::sample_below(ek.n).to_limbs(&r2[(b * EF + i) * kw], kw);
       }
-    }
+    });
+    tm.sample_flatten_ms = sw.lap();
     std::vector<uint32_t> c1(rows * 2 * kw), c2(rows * 2 * kw), rw1(rows * kw), rr1(rows * kw), rw2(rows * kw), rr2(rows * kw);
     std::vector<uint8_t> kind(rows), jj(rows), status(B);
     zkp_range_ni_proofs p{nb, (uint32_t)EF, B, 0, n.data(), range.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
                           rw1.data(), rr1.data(), rw2.data(), rr2.data()};
     zkp_range_ni_witness w{x.data(), r.data(), w1.data(), w2.data(), r1.data(), r2.data()};
+    sw.lap();
     e.check(zkp_range_ni_prove_batch(e.ctx(), &p, &w, nullptr, nullptr, status.data(), 0), "zkp_range_ni_prove_batch");
+    tm.gpu_ms = sw.lap();
     std::vector<RangeProofNi> out(B);
-    for (size_t b = 0; b < B; b++) {
+    parallel_for(B, [&](size_t b) {
       if (status[b] != 0) throw Panic("RangeProofNi::prove: malformed (the reference would panic)");
       RangeProofNi& o = out[b];
       o.ek = ek; o.range = st[b].range; o.ciphertext = st[b].ciphertext; o.error_factor = EF;
@@ -263,7 +308,8 @@ class RangeProofNi {
         }
         o.proof.responses.push_back(std::move(rs));
       }
-    }
+    });
+    tm.rebuild_ms = sw.lap();
     return out;
   }
 
@@ -301,14 +347,20 @@ class RangeProofNi {
       }
       return true;
     };
-    for (size_t b = 0; b < B; b++) (canonical(*proofs[b]) ? fast : general).push_back(b);
+    HostTiming& tm = last_host_timing();
+    tm = HostTiming(); tm.proofs = B; tm.threads = host_threads();
+    StopWatch sw;
+    std::vector<char> canon(B);
+    parallel_for(B, [&](size_t b) { canon[b] = canonical(*proofs[b]); });
+    for (size_t b = 0; b < B; b++) (canon[b] ? fast : general).push_back(b);
+    tm.general_proofs = general.size();
     std::vector<Result> out(B, Result(false));
     if (!fast.empty()) {
       const size_t F = fast.size(), rows = F * EF;
       std::vector<uint32_t> n(kw), range(F * kw), ct(F * 2 * kw), c1(rows * 2 * kw), c2(rows * 2 * kw), rw1(rows * kw), rr1(rows * kw), rw2(rows * kw, 0), rr2(rows * kw, 0);
       std::vector<uint8_t> kind(rows), jj(rows, 0), verdict(F);
       ek.n.to_limbs(n.data(), kw);
-      for (size_t f = 0; f < F; f++) {
+      parallel_for(F, [&](size_t f) {
         const RangeProofNi& p = *proofs[fast[f]];
         p.range.to_limbs(&range[f * kw], kw); p.ciphertext.to_limbs(&ct[f * 2 * kw], 2 * kw);
         for (size_t i = 0; i < EF; i++) {
@@ -323,18 +375,22 @@ class RangeProofNi {
             rs.masked_x.to_limbs(&rw1[t * kw], kw); rs.masked_r.to_limbs(&rr1[t * kw], kw);
           }
         }
-      }
+      });
+      tm.sample_flatten_ms = sw.lap();
       zkp_range_ni_proofs p{nb, (uint32_t)EF, F, 0, n.data(), range.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
                             rw1.data(), rr1.data(), rw2.data(), rr2.data()};
       e.check(zkp_range_ni_verify_batch(e.ctx(), &p, verdict.data(), 0), "zkp_range_ni_verify_batch");
+      tm.gpu_ms = sw.lap();
       for (size_t f = 0; f < F; f++)
         out[fast[f]] = verdict[f] == ZKP_VERDICT_MALFORMED ? Result::panicked("RangeProofNi::verify: malformed proof (the reference would panic)") : Result(verdict[f] == ZKP_VERDICT_ACCEPT);
     }
     if (!general.empty()) {
       std::vector<const RangeProofNi*> g;
       for (size_t b : general) g.push_back(proofs[b]);
+      sw.lap();
       std::vector<Result> r = verify_general(ek, g);
       for (size_t k = 0; k < general.size(); k++) out[general[k]] = r[k];
+      tm.general_ms = sw.lap();
     }
     return out;
   }

@@ -11,9 +11,25 @@ def shard_range(total: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_slabs(local, world: int, counts=None):
+class GatherBuffers:
+    """receive (and, for unequal blocks, padding) buffers of ONE recurring all-gather, allocated once outside the timed loop:
+    at N = 8 the prove-side gather of a 4096-proof rank block receives 8 x 537 MB = 4.3 GB per output per rank, which a serving
+    loop must not allocate per step.  nbytes = what this rank receives per gather."""
+
+    def __init__(self, like, world: int, counts=None):
+        import torch
+        self.world, self.counts = world, (None if counts is None or len(set(counts)) == 1 else list(counts))
+        rows = like.shape[0] if self.counts is None else max(self.counts)
+        tail = tuple(like.shape[1:])
+        self.pad = None if self.counts is None else torch.zeros((rows,) + tail, dtype=like.dtype, device=like.device)
+        self.out = torch.empty((world * rows,) + tail, dtype=like.dtype, device=like.device)
+        self.nbytes = self.out.numel() * self.out.element_size()
+
+
+def all_gather_slabs(local, world: int, counts=None, buffers=None):
     """all-gather equally sized slabs along dim 0 -> tensor [world * local.shape[0], ...].
-    With `counts` (rows per rank, unequal) slabs are padded to max(counts) and trimmed after the gather."""
+    With `counts` (rows per rank, unequal) slabs are padded to max(counts) and trimmed after the gather.
+    buffers: a GatherBuffers made for this shape (then nothing is allocated here, except the trimmed copy of unequal blocks)."""
     import torch
     import torch.distributed as dist
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
@@ -22,14 +38,16 @@ def all_gather_slabs(local, world: int, counts=None):
         # device-resident slabs under the gloo backend (several ranks sharing one GPU in a functional check of the N > 1 path:
         # RCCL refuses that): the exchange goes through host memory
         return all_gather_slabs(local.cpu(), world, counts).to(local.device)
+    if counts is not None and len(set(counts)) == 1:
+        counts = None
     if counts is None:
-        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        out = buffers.out if buffers is not None else torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
         return out
     m = max(counts)
-    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad = buffers.pad if buffers is not None else torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    out = torch.empty((world * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    out = buffers.out if buffers is not None else torch.empty((world * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, pad)
     return torch.cat([out[r * m: r * m + counts[r]] for r in range(world)], dim=0)
 
