@@ -37,3 +37,17 @@ def test_reference_unit_tests_ported_to_cpp_pass():
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("PASS") == 32 and "FAIL" not in out.stdout
+
+
+def test_host_bigint_against_gmp():
+    """host/bigint.hpp — signed since round 4 (a received proof may hold negative integers): + - * truncated %, floored modulus,
+    div_floor, gcd, mod_inv, decimal text, to_bytes against GMP on random mixed-sign operands (tests/cpp/test_bigint.cpp)"""
+    src = os.path.join(ROOT, "tests", "cpp", "test_bigint.cpp")
+    exe = os.path.join(ROOT, "build", "test_bigint")
+    gmp = next((p for p in ("/usr/lib/x86_64-linux-gnu/libgmp.so.10", "/opt/conda/lib/libgmp.so") if os.path.exists(p)), None)
+    if gmp is None or not os.path.exists("/opt/conda/include/gmp.h"):
+        pytest.skip("no GMP header / library on this machine")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I/opt/conda/include", src, gmp, "-o", exe])
+    out = subprocess.run([exe, "8000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "bigint ok" in out.stdout, out.stdout + out.stderr

@@ -36,6 +36,9 @@ for line in p.stdout:
         rec.update({"clock_ghz_mean": round(ghz, 4), "clock_samples": len(win), "power_w_mean": round(sum(s[2] for s in win) / len(win), 1),
                     "cycles_per_wave_instr_per_simd_at_sampled_clock": round(ghz * 1e9 * 256 * 4 * 64 / rec["lane_mad_per_s"], 3),
                     "lane_mad_per_s_over_16_lanes_per_clk_per_simd": round(rec["lane_mad_per_s"] / (16 * 1024 * ghz * 1e9), 4)})
+        if "cycles_per_substep_per_wave_at_2.4GHz" in rec:
+            rec["cycles_per_substep_per_wave_at_sampled_clock"] = round(rec["cycles_per_substep_per_wave_at_2.4GHz"] * ghz / 2.4, 1)
+            rec["substeps_per_s_per_simd"] = round(ghz * 1e9 / rec["cycles_per_substep_per_wave_at_sampled_clock"], 1)
         if "valu_instr_per_mad" in rec:
             rec["cycles_per_valu_instr_per_simd_at_sampled_clock"] = round(rec["cycles_per_wave_instr_per_simd_at_sampled_clock"] / rec["valu_instr_per_mad"], 3)
     print(json.dumps(rec), flush=True)

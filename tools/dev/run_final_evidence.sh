@@ -1,12 +1,25 @@
 #!/bin/bash
 # everything the round's evidence is made of, on one box: bash tools/dev/run_final_evidence.sh [tag]
 TAG=${1:-final}
+ROUND=${ROUND:-r04}
 R=$PWD
-timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/r03_pytest_gpu_$TAG.txt
-tail -3 gpurun_out/r03_pytest_gpu_$TAG.txt
-python bench.py > gpurun_out/bench_r03_$TAG.json 2> gpurun_out/bench_r03_$TAG.err; echo bench rc=$?
-(cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r03_$TAG -- python $R/bench.py --cpu-sample 0 --no-pcie-leg --other-reps 1 > $R/gpurun_out/prof_r03_$TAG.log 2>&1; echo rocprof rc=$?)
-find gpurun_out/prof_r03_$TAG -name "*kernel_stats.csv" -exec cp {} gpurun_out/r03_kernel_stats_bench_$TAG.csv \;
-find gpurun_out/prof_r03_$TAG -name "*kernel_trace.csv" -delete
-bash profiles/r03_collect_all.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/${ROUND}_pytest_gpu_$TAG.txt
+tail -3 gpurun_out/${ROUND}_pytest_gpu_$TAG.txt
+python bench.py > gpurun_out/bench_${ROUND}_$TAG.json 2> gpurun_out/bench_${ROUND}_$TAG.err; echo bench rc=$?
+(cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${ROUND}_$TAG -- python $R/bench.py --cpu-sample 0 --no-pcie-leg --other-reps 1 > $R/gpurun_out/prof_${ROUND}_$TAG.log 2>&1; echo rocprof rc=$?)
+find gpurun_out/prof_${ROUND}_$TAG -name "*kernel_stats.csv" -exec cp {} gpurun_out/${ROUND}_kernel_stats_bench_$TAG.csv \;
+# the per-dispatch durations of the headline kernel (the stats file averages verify, prove and warm-up launches of one kernel name together)
+python - <<PY
+import csv, glob, json
+rows = []
+for f in glob.glob("gpurun_out/prof_${ROUND}_$TAG/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_enc<4, true" in r.get("Kernel_Name", ""):
+            rows.append(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 3))
+json.dump({"kernel": "k_enc<4, true, false>", "launch_ms_in_dispatch_order": rows,
+           "note": "rocprofv3 --kernel-trace of the default bench run: the ~1.86 s launches are the timed verify steps (roofline.kernel_ms_per_launch), the ~2.5 s ones the merged c1 + c2 launch of a prove step, the short ones warm-ups / small legs"},
+          open("gpurun_out/${ROUND}_kernel_trace_k_enc4_true_launches_$TAG.json", "w"), indent=1)
+PY
+find gpurun_out/prof_${ROUND}_$TAG -name "*kernel_trace.csv" -delete
+ROUND=$ROUND bash profiles/collect_all.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
 tail -6 gpurun_out/pmc_$TAG.log

@@ -281,7 +281,7 @@ class BigInt {
     std::copy(l.begin(), l.end(), out);
     std::fill(out + l.size(), out + n, 0u);
   }
-  static BigInt from_limbs(const uint32_t* p, size_t n) { BigInt r; r.l.assign(p, p + n); r.trim(); return r; }
+  static BigInt from_limbs(const uint32_t* p, size_t n) { while (n && p[n - 1] == 0) n--; BigInt r; r.l.assign(p, p + n); return r; }
   std::string to_hex() const {
     if (is_zero()) return "0";
     static const char* d = "0123456789abcdef";
