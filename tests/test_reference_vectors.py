@@ -78,13 +78,72 @@ def simulated_doc():
                     "encryption_key": {"n": dec(n), "json": {"n": dec(n)}},
                     "dlog_statement": {"N": dec(n), "g": dec(g), "ni": dec(ni), "json": {"N": hx(n), "g": hx(g), "ni": hx(ni)}},
                     "dlog_proof": {"x": dec(x), "y": dec(y), "json": {"x": hx(x), "y": hx(y)}}}
+    doc["signed"] = simulated_signed_section(n, d, hx)
     for c in doc["range_ni"]:
         c["raw"] = {"ek": {"n": dec(n)}, "range": hx(D(c["range"])), "ciphertext": hx(D(c["ciphertext"])), "encrypted_pairs": c["encrypted_pairs"],
                     "proof": c["proof"], "error_factor": c["error_factor"]}
     return doc
 
 
-KNOWN_SECTIONS = {"generator", "to_bytes", "compute_digest", "enc", "range_ni", "correct_key_ni", "dlog", "serde"}
+SIGNED_MUTATIONS = ["none", "neg_r1_open", "neg_masked_r", "wide_masked_r", "neg_masked_x", "neg_w2_only", "neg_w1_and_w2", "short_responses"]
+
+
+def simulated_signed_section(n, d, hx):
+    """the "signed" section of tools/reference_vectors/src/main.rs from the python model (pins nothing): truncated remainders, mod_pow on
+    negative bases, Enc on negative operands, and verify_self of documents with one edited decimal field (tests/signed_cases.py)"""
+    import oracle_lib
+    import signed_cases as S
+    a, m = d.bits(300), d.bits(200) + 1
+    rem = [{"a": dec(x), "m": dec(y), "rem": dec(pm.tdiv_r(x, y))} for x, y in ((a, m), (-a, m), (a, -m), (-a, -m), (-m, m))]
+    base = d.below(n)
+    mod_pow = [{"base": dec(b), "exp": dec(n), "modulus": dec(n * n), "out": dec(pow(b, n, n * n))} for b in (-base, -(base + n * n), base + n * n)]
+    r, x = d.below(n), d.bits(256)
+    enc = [{"m": dec(mm), "r": dec(rr), "c": dec(pm.enc_signed(n, mm, rr))} for mm, rr in ((-1, 1), (-x, r), (x, -r), (-x, -r), (-n, r), (7, 0), (-7, 0))]
+    oracle = oracle_lib.Oracle()
+    cases = []
+    for name in SIGNED_MUTATIONS:
+        proof, _ = S.build(name, oracle)
+        assert proof["n"] == n
+        raw = json.loads(S.document(proof))
+        raw["range"] = hx(proof["range"]); raw["ciphertext"] = hx(proof["ciphertext"])       # the bare BigInts in the file's own (here: hex) form
+        cases.append({"name": name, "raw": raw, "verify_self": S.model_verdict(proof)})
+    return {"rem": rem, "mod_pow": mod_pow, "enc": enc, "range_ni": cases}
+
+
+def proof_of_raw(raw, key_enc, enc):
+    """a whole-document RangeProofNi (as serde wrote it) -> the python-int proof dict of tests/signed_cases.py"""
+    resp = []
+    for r in raw["proof"]:
+        if "Open" in r:
+            o = r["Open"]; resp.append(("open", int(o["w1"]), int(o["r1"]), int(o["w2"]), int(o["r2"])))
+        else:
+            mk = r["Mask"]; resp.append(("mask", int(mk["j"]), int(mk["masked_x"]), int(mk["masked_r"])))
+    return dict(n=decode_bigint(raw["ek"]["n"], key_enc), range=decode_bigint(raw["range"], enc), ciphertext=decode_bigint(raw["ciphertext"], enc),
+                error_factor=int(raw["error_factor"]), c1=[int(v) for v in raw["encrypted_pairs"]["c1"]], c2=[int(v) for v in raw["encrypted_pairs"]["c2"]], responses=resp)
+
+
+def check_signed_section(doc, oracle, forms):
+    """SURVEY N4 / N5 pinned by the reference itself: `%`, mod_pow, Enc on negative operands; verify_self on edited documents"""
+    sg = doc.get("signed")
+    if sg is None:
+        return
+    assert set(sg) <= {"rem", "mod_pow", "enc", "range_ni"}, "unread part of the signed section"
+    for t in sg["rem"]:
+        assert pm.tdiv_r(int(t["a"]), int(t["m"])) == int(t["rem"]), "Rust `%` on BigInt is not the truncated remainder the oracles assume"
+    for t in sg["mod_pow"]:
+        assert pow(int(t["base"]), int(t["exp"]), int(t["modulus"])) == int(t["out"]), "mod_pow on a negative base"
+    n = D(doc["enc"]["n"])
+    for t in sg["enc"]:
+        m, r, c = int(t["m"]), int(t["r"]), int(t["c"])
+        assert pm.enc_signed(n, m, r) == c == oracle.enc_decimal(n, m, r), (m < 0, r < 0)
+    assert forms is not None, "the signed documents need the serde section to say how the un-annotated fields are written"
+    for c in sg["range_ni"]:
+        proof = proof_of_raw(c["raw"], *forms)
+        want = {"ok": "ok", "err": "err", "panic": "panic"}[c["verify_self"]]
+        assert oracle.range_ni_verify_decimal(proof)[0] == want, c["name"]
+
+
+KNOWN_SECTIONS = {"generator", "to_bytes", "compute_digest", "enc", "range_ni", "correct_key_ni", "dlog", "serde", "signed"}
 
 
 def _forms(v):
@@ -176,6 +235,7 @@ def batch_from_case(c):
 def check_doc_cpu(doc, oracle):
     """every section against the oracle (C/GMP) and the python model"""
     forms = check_serde_section(doc)
+    check_signed_section(doc, oracle, forms)
     for c in doc["range_ni"]:
         if "raw" in c and forms is not None:               # the whole-document form agrees with the fields printed beside it
             raw = c["raw"]
@@ -244,6 +304,20 @@ def check_doc_gpu(doc, ctx):
                 ref, _ = batch_from_case(c)
                 for f in ("range", "ciphertext", "c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2"):
                     assert np.array_equal(getattr(pw, f)[b], getattr(ref, f)[0]), f
+    if forms is not None and "signed" in doc:
+        # the edited documents through the product's host layer (serde_json::range_proof_ni_from_str -> RangeProofNi::verify_batch)
+        import subprocess
+        import tempfile
+        import signed_cases as S
+        from test_gpu_host_parity import build_exe
+        cases = doc["signed"]["range_ni"]
+        with tempfile.NamedTemporaryFile("wb", suffix=".jsonl", delete=False) as f:
+            f.write(b"\n".join(S.document(proof_of_raw(c["raw"], *forms)) for c in cases) + b"\n")
+        try:
+            out = subprocess.run([build_exe()], input=f"range_ni_verify_docs {f.name}\n", capture_output=True, text=True, timeout=900)
+        finally:
+            os.unlink(f.name)
+        assert out.returncode == 0 and out.stdout.split() == [c["verify_self"] for c in cases], (out.stdout, out.stderr)
     n = D(doc["enc"]["n"]); nb = width_for(n); kw = nb // 32
     items = doc["enc"]["items"]
     out = np.zeros((len(items), 2 * kw), np.uint32)

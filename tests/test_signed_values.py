@@ -138,3 +138,62 @@ def test_gpu_document_reader_routes_signed_documents_to_the_host_path(ctx, built
         assert v[i] == verdict[GOLDEN["cases"][i]["verdict"]], names[i]
     host_idx = [i for i, w in enumerate(want) if w == zkp.DOC_HOST_PATH]
     assert not pg.c1[host_idx].any() and not pg.resp_w1[host_idx].any()
+
+
+def random_mutation(rng, proof):
+    """one random edit of a received proof: a field of a random row (or the statement) negated, shifted by a multiple of n, made
+    over-wide, or bumped by one; c1 / c2 edits change the challenge, so most of them reject — what matters is that the product's
+    answer is the oracle's, whatever it is"""
+    n, nn = proof["n"], proof["n"] ** 2
+    ops = [lambda v, m: -v, lambda v, m: v - m, lambda v, m: v + (m << rng.randrange(1, 1200)), lambda v, m: v + 1, lambda v, m: v - 2 * m, lambda v, m: 0]
+    what = rng.choice(["resp", "resp", "resp", "c1", "c2", "ciphertext", "range"])
+    op = rng.choice(ops)
+    if what == "resp":
+        i = rng.randrange(len(proof["responses"]))
+        r = list(proof["responses"][i])
+        k = rng.randrange(1, 5) if r[0] == "open" else rng.randrange(2, 4)
+        r[k] = op(r[k], n)
+        proof["responses"][i] = tuple(r)
+    elif what in ("c1", "c2"):
+        i = rng.randrange(len(proof[what]))
+        proof[what][i] = op(proof[what][i], nn)
+    elif what == "ciphertext":
+        proof["ciphertext"] = op(proof["ciphertext"], nn)
+    else:
+        proof["range"] = op(proof["range"], n)
+
+
+@pytest.mark.gpu
+def test_gpu_host_layer_on_randomly_edited_proofs(oracle):
+    """fuzz: 48 documents with 1-3 random signed / over-wide edits each (seed printed) through the host layer on the GPU against the
+    C/GMP restatement over mpz; every answer must be a verdict of the reference's kind"""
+    import random
+    seed = int(os.environ.get("ZKP_SOAK_SEED", "0")) or random.SystemRandom().randrange(1 << 30)
+    print("signed fuzz seed", seed)
+    rng = random.Random(seed)
+    bases = [S.honest_proof(b"signed-fuzz-%d" % k, oracle)[0] for k in range(4)]
+    proofs = []
+    for k in range(48):
+        b = bases[k % 4]
+        p = dict(b, c1=list(b["c1"]), c2=list(b["c2"]), responses=list(b["responses"]))
+        for _ in range(rng.randrange(1, 4)):
+            if k < 12:              # harmless by construction: a randomness field moved by a multiple of n (r^n mod n^2 depends on r mod n only)
+                i = rng.randrange(len(p["responses"]))
+                r = list(p["responses"][i])
+                f = rng.choice([2, 4]) if r[0] == "open" else 3
+                r[f] += p["n"] * rng.choice([-1, -3, 1 << rng.randrange(1, 1500)])
+                p["responses"][i] = tuple(r)
+            else:
+                random_mutation(rng, p)
+        proofs.append(p)
+    want = [oracle.range_ni_verify_decimal(p)[0] for p in proofs]
+    with tempfile.NamedTemporaryFile("wb", suffix=".jsonl", delete=False) as f:
+        f.write(b"\n".join(S.document(p) for p in proofs) + b"\n")
+    try:
+        out = subprocess.run([build_exe()], input=f"range_ni_verify_docs {f.name}\n", capture_output=True, text=True, timeout=900)
+    finally:
+        os.unlink(f.name)
+    assert out.returncode == 0, out.stderr
+    got = out.stdout.split()
+    assert got == want, [(i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w]
+    assert "ok" in want and "err" in want, "the fuzz should produce both verdicts (harmless edits of r / masked_r keep a proof valid)"

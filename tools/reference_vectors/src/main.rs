@@ -18,7 +18,12 @@
 //!   "correct_key_ni": [{"p","q","n","salt_hex","sigma_vec":[..],"verify":"ok"|"err"}],
 //!   "dlog": [{"N","g","ni","secret","x","y","verify":"ok"|"err"}],
 //!   "serde": {"bigint_samples":[{"x","json":<serde of a bare BigInt>}], "encryption_key":{"n","json":<serde of EncryptionKey>},
-//!             "dlog_statement":{"N","g","ni","json"}, "dlog_proof":{"x","y","json"}} }
+//!             "dlog_statement":{"N","g","ni","json"}, "dlog_proof":{"x","y","json"}},
+//!   "signed": {"rem":[{"a","m","rem"}], "mod_pow":[{"base","exp","modulus","out"}], "enc":[{"m","r","c"}],
+//!              "range_ni":[{"name","raw":<a RangeProofNi document with one mutated decimal field>,"verify_self":"ok"|"err"|"panic"}]} }
+//! The "signed" section pins what the reference does with NEGATIVE and over-wide integers, which a deserialised
+//! proof may hold: Rust's `%` on BigInt, mod_pow on a negative base, Enc on negative operands, and the verdicts of verify_self
+//! on documents whose decimal-string fields were edited after an honest prover made them.
 use std::env;
 use std::fs;
 
@@ -72,6 +77,90 @@ fn range_case(ek: &EncryptionKey, honest: bool) -> Value {
         "honest": honest, "encrypted_pairs": raw["encrypted_pairs"].clone(), "proof": raw["proof"].clone(),
         "error_factor": raw["error_factor"].clone(), "verify_self": verdict, "raw": raw,
     })
+}
+
+/// first row of `proof` of the given kind ("Open" / "Mask")
+fn first_row(doc: &Value, kind: &str) -> usize {
+    doc["proof"].as_array().unwrap().iter().position(|r| r.get(kind).is_some()).expect("no such row")
+}
+
+/// field `f` of row `i` (a decimal string, serialize.rs:8-31) -> `edit(value)`
+fn edit_field(doc: &mut Value, i: usize, kind: &str, f: &str, edit: &dyn Fn(&BigInt) -> BigInt) {
+    let cur = big(doc["proof"][i][kind][f].as_str().unwrap());
+    doc["proof"][i][kind][f] = Value::String(dec(&edit(&cur)));
+}
+
+/// verify_self of a document as the crate deserialises it; a panic of the reference (index out of bounds) is an outcome
+fn verdict_of(doc: &Value) -> &'static str {
+    let parsed: Result<RangeProofNi, _> = serde_json::from_value(doc.clone());
+    match parsed {
+        Err(_) => "serde",
+        Ok(p) => match std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| p.verify_self())) {
+            Ok(Ok(())) => "ok",
+            Ok(Err(_)) => "err",
+            Err(_) => "panic",
+        },
+    }
+}
+
+/// documents with one edited field each (no re-answering of the challenge: only fields that are not hashed are touched)
+fn signed_range_cases(ek: &EncryptionKey) -> Vec<Value> {
+    let range = BigInt::sample(256);
+    let secret_r = BigInt::sample_below(&ek.n);
+    let secret_x = BigInt::sample_below(&range.div_floor(&BigInt::from(3)));
+    let cipher_x = enc(ek, &secret_x, &secret_r);
+    let honest = serde_json::to_value(&RangeProofNi::prove(ek, &range, &cipher_x, &secret_x, &secret_r)).unwrap();
+    let n = ek.n.clone();
+    let wide = BigInt::from(2).pow(2100) * &n;
+    let mut out: Vec<Value> = Vec::new();
+    let mut push = |name: &str, doc: Value| {
+        let v = verdict_of(&doc);
+        out.push(json!({"name": name, "raw": doc, "verify_self": v}));
+    };
+    push("none", honest.clone());
+    {
+        let mut d = honest.clone();
+        let i = first_row(&d, "Open");
+        edit_field(&mut d, i, "Open", "r1", &|v| v - &n);
+        push("neg_r1_open", d);
+    }
+    {
+        let mut d = honest.clone();
+        let i = first_row(&d, "Mask");
+        edit_field(&mut d, i, "Mask", "masked_r", &|v| v - &n);
+        push("neg_masked_r", d);
+    }
+    {
+        let mut d = honest.clone();
+        let i = first_row(&d, "Mask");
+        edit_field(&mut d, i, "Mask", "masked_r", &|v| v + &wide);
+        push("wide_masked_r", d);
+    }
+    {
+        let mut d = honest.clone();
+        let i = first_row(&d, "Mask");
+        edit_field(&mut d, i, "Mask", "masked_x", &|v| v - &n);
+        push("neg_masked_x", d);
+    }
+    {
+        let mut d = honest.clone();
+        let i = first_row(&d, "Open");
+        edit_field(&mut d, i, "Open", "w2", &|v| v - &n);
+        push("neg_w2_only", d);
+    }
+    {
+        let mut d = honest.clone();
+        let i = first_row(&d, "Open");
+        edit_field(&mut d, i, "Open", "w1", &|v| v - &n);
+        edit_field(&mut d, i, "Open", "w2", &|v| v - &n);
+        push("neg_w1_and_w2", d);
+    }
+    {
+        let mut d = honest.clone();
+        d["proof"].as_array_mut().unwrap().truncate(100);
+        push("short_responses", d);
+    }
+    out
 }
 
 fn main() {
@@ -158,10 +247,39 @@ fn main() {
         })
     };
 
+    // negative / over-wide operands: the operators a deserialised proof reaches with them
+    let signed_section = {
+        let a = BigInt::sample(300);
+        let m = BigInt::sample(200) + BigInt::one();
+        let neg = |x: &BigInt| BigInt::zero() - x;
+        let rem: Vec<Value> = vec![(a.clone(), m.clone()), (neg(&a), m.clone()), (a.clone(), neg(&m)), (neg(&a), neg(&m)), (neg(&m), m.clone())]
+            .iter()
+            .map(|(x, y)| json!({"a": dec(x), "m": dec(y), "rem": dec(&(x.clone() % y))}))
+            .collect();
+        let base = BigInt::sample_below(&ek.n);
+        let mod_pow: Vec<Value> = vec![neg(&base), neg(&(&base + &ek.nn)), &base + &ek.nn]
+            .iter()
+            .map(|b| json!({"base": dec(b), "exp": dec(&ek.n), "modulus": dec(&ek.nn), "out": dec(&BigInt::mod_pow(b, &ek.n, &ek.nn))}))
+            .collect();
+        let r = BigInt::sample_below(&ek.n);
+        let x = BigInt::sample(256);
+        let pairs = vec![
+            (neg(&BigInt::one()), BigInt::one()),
+            (neg(&x), r.clone()),
+            (x.clone(), neg(&r)),
+            (neg(&x), neg(&r)),
+            (neg(&ek.n), r.clone()),
+            (BigInt::from(7), BigInt::zero()),
+            (neg(&BigInt::from(7)), BigInt::zero()),
+        ];
+        let enc_signed: Vec<Value> = pairs.iter().map(|(m, r)| json!({"m": dec(m), "r": dec(r), "c": dec(&enc(&ek, m, r))})).collect();
+        json!({"rem": rem, "mod_pow": mod_pow, "enc": enc_signed, "range_ni": signed_range_cases(&ek)})
+    };
+
     let doc = json!({
         "generator": "tools/reference_vectors (zk-paillier 0.4.4 + curv-kzen 0.10 / rust-gmp-kzen + kzen-paillier 0.4.3)",
         "to_bytes": to_bytes, "compute_digest": digests, "enc": {"n": dec(&ek.n), "items": enc_items},
-        "range_ni": range_ni, "correct_key_ni": ck, "dlog": dlog, "serde": serde_section,
+        "range_ni": range_ni, "correct_key_ni": ck, "dlog": dlog, "serde": serde_section, "signed": signed_section,
     });
     fs::write(&out_path, serde_json::to_string(&doc).unwrap()).unwrap();
     println!("wrote {}", out_path);

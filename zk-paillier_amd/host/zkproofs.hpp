@@ -266,59 +266,108 @@ class RangeProofNi {
 
   struct Statement { BigInt range, ciphertext, secret_x, secret_r; };
 
-  // range_proof_ni.rs:47-82 for many provers sharing one key; randomness sampled as range_proof.rs:133-159
+  // range_proof_ni.rs:47-82 for many provers sharing one key; randomness sampled as range_proof.rs:133-159.
+  // Large batches run as a PIPELINE of up to 4 chunks (>= 1024 proofs each): while the GPU proves chunk k (a blocking C-ABI call on
+  // host buffers), a helper thread samples + flattens chunk k+1 and rebuilds the proof objects of chunk k-1, so that of the host
+  // work only the first chunk's sampling and the last chunk's rebuild stay on the critical path (one extra launch tail of ~38 ms per
+  // extra chunk at n = 2048).  ZKP_HOST_PIPELINE=0 proves the batch in one call.
+  struct ProveChunk {
+    size_t lo, hi;
+    RawBuf<uint32_t> range, ct, x, r, w1, w2, r1, r2, c1, c2, rw1, rr1, rw2, rr2;
+    RawBuf<uint8_t> kind, jj;
+    std::vector<uint8_t> status;
+    ProveChunk(size_t lo_, size_t hi_, size_t kw, size_t EF)
+        : lo(lo_), hi(hi_), range((hi_ - lo_) * kw), ct((hi_ - lo_) * 2 * kw), x((hi_ - lo_) * kw), r((hi_ - lo_) * kw), w1((hi_ - lo_) * EF * kw), w2((hi_ - lo_) * EF * kw),
+          r1((hi_ - lo_) * EF * kw), r2((hi_ - lo_) * EF * kw), c1((hi_ - lo_) * EF * 2 * kw), c2((hi_ - lo_) * EF * 2 * kw), rw1((hi_ - lo_) * EF * kw), rr1((hi_ - lo_) * EF * kw),
+          rw2((hi_ - lo_) * EF * kw), rr2((hi_ - lo_) * EF * kw), kind((hi_ - lo_) * EF), jj((hi_ - lo_) * EF), status(hi_ - lo_) {}
+  };
   static std::vector<RangeProofNi> prove_batch(const EncryptionKey& ek, const std::vector<Statement>& st) {
     Engine& e = Engine::instance();
     const uint32_t nb = width_for(ek.n), kw = nb / 32;
-    const size_t B = st.size(), EF = SECURITY_PARAMETER, rows = B * EF;
-    RawBuf<uint32_t> n(kw), range(B * kw), ct(B * 2 * kw), x(B * kw), r(B * kw), w1(rows * kw), w2(rows * kw), r1(rows * kw), r2(rows * kw);
+    const size_t B = st.size(), EF = SECURITY_PARAMETER;
+    RawBuf<uint32_t> n(kw);
     ek.n.to_limbs(n.data(), kw);
     HostTiming& tm = last_host_timing();
     tm = HostTiming(); tm.proofs = B; tm.threads = host_threads();
-    StopWatch sw;
-    parallel_for(B, [&](size_t b) {
-      st[b].range.to_limbs(&range[b * kw], kw); st[b].ciphertext.to_limbs(&ct[b * 2 * kw], 2 * kw);
-      st[b].secret_x.to_limbs(&x[b * kw], kw); st[b].secret_r.to_limbs(&r[b * kw], kw);
-      const BigInt third = st[b].range.div_floor(BigInt(3)), two_thirds = BigInt(2) * third;   // range_proof.rs:133-134
-      for (size_t i = 0; i < EF; i++) {
-        BigInt a = BigInt::sample_range(third, two_thirds), c = a - third;                      // :136-141
-        if (BigInt::coin()) std::swap(a, c);                                                     // :144-149
-        a.to_limbs(&w1[(b * EF + i) * kw], kw); c.to_limbs(&w2[(b * EF + i) * kw], kw);
-        BigInt::sample_below(ek.n).to_limbs(&r1[(b * EF + i) * kw], kw);                         // :151-159
-        BigInt::sample_below(ek.n).to_limbs(&r2[(b * EF + i) * kw], kw);
-      }
-    });
-    tm.sample_flatten_ms = sw.lap();
-    RawBuf<uint32_t> c1(rows * 2 * kw), c2(rows * 2 * kw), rw1(rows * kw), rr1(rows * kw), rw2(rows * kw), rr2(rows * kw);   // written in full by the call
-    RawBuf<uint8_t> kind(rows), jj(rows);
-    std::vector<uint8_t> status(B);
-    zkp_range_ni_proofs p{nb, (uint32_t)EF, B, 0, n.data(), range.data(), ct.data(), c1.data(), c2.data(), kind.data(), jj.data(),
-                          rw1.data(), rr1.data(), rw2.data(), rr2.data()};
-    zkp_range_ni_witness w{x.data(), r.data(), w1.data(), w2.data(), r1.data(), r2.data()};
-    e.check(zkp_range_ni_prove_batch(e.ctx(), &p, &w, nullptr, nullptr, status.data(), 0), "zkp_range_ni_prove_batch");
-    tm.gpu_ms = sw.lap();
+    const char* pe = std::getenv("ZKP_HOST_PIPELINE");
+    const size_t chunks = (pe && pe[0] == '0') ? 1 : std::max<size_t>(1, std::min<size_t>(4, B / 1024));
     std::vector<RangeProofNi> out(B);
-    parallel_for(B, [&](size_t b) {
-      if (status[b] != 0) throw Panic("RangeProofNi::prove: malformed (the reference would panic)");
-      RangeProofNi& o = out[b];
-      o.ek = ek; o.range = st[b].range; o.ciphertext = st[b].ciphertext; o.error_factor = EF;
-      o.encrypted_pairs.c1.reserve(EF); o.encrypted_pairs.c2.reserve(EF); o.proof.responses.reserve(EF);
-      for (size_t i = 0; i < EF; i++) {
-        const size_t t = b * EF + i;
-        o.encrypted_pairs.c1.push_back(BigInt::from_limbs(&c1[t * 2 * kw], 2 * kw));
-        o.encrypted_pairs.c2.push_back(BigInt::from_limbs(&c2[t * 2 * kw], 2 * kw));
-        Response rs;
-        if (kind[t] == ZKP_RESP_OPEN) {
-          rs.kind = Response::Open;
-          rs.w1 = BigInt::from_limbs(&rw1[t * kw], kw); rs.r1 = BigInt::from_limbs(&rr1[t * kw], kw);
-          rs.w2 = BigInt::from_limbs(&rw2[t * kw], kw); rs.r2 = BigInt::from_limbs(&rr2[t * kw], kw);
-        } else {
-          rs.kind = Response::Mask; rs.j = jj[t];
-          rs.masked_x = BigInt::from_limbs(&rw1[t * kw], kw); rs.masked_r = BigInt::from_limbs(&rr1[t * kw], kw);
+
+    // stage A: sample (range_proof.rs:133-159) and flatten the statements of a chunk
+    auto sample_flatten = [&](ProveChunk& c, unsigned max_threads) {
+      parallel_for(c.hi - c.lo, [&](size_t k) {
+        const size_t b = c.lo + k;
+        st[b].range.to_limbs(&c.range[k * kw], kw); st[b].ciphertext.to_limbs(&c.ct[k * 2 * kw], 2 * kw);
+        st[b].secret_x.to_limbs(&c.x[k * kw], kw); st[b].secret_r.to_limbs(&c.r[k * kw], kw);
+        const BigInt third = st[b].range.div_floor(BigInt(3)), two_thirds = BigInt(2) * third;   // range_proof.rs:133-134
+        for (size_t i = 0; i < EF; i++) {
+          BigInt a = BigInt::sample_range(third, two_thirds), cc = a - third;                     // :136-141
+          if (BigInt::coin()) std::swap(a, cc);                                                    // :144-149
+          a.to_limbs(&c.w1[(k * EF + i) * kw], kw); cc.to_limbs(&c.w2[(k * EF + i) * kw], kw);
+          BigInt::sample_below(ek.n).to_limbs(&c.r1[(k * EF + i) * kw], kw);                      // :151-159
+          BigInt::sample_below(ek.n).to_limbs(&c.r2[(k * EF + i) * kw], kw);
         }
-        o.proof.responses.push_back(std::move(rs));
-      }
-    }, 2);   // 0.75 GB of fresh proof objects: bound by first-touch page faults, more threads only contend for the address space (measured: 16 threads 674 ms, one 377 ms)
+      }, max_threads);
+    };
+    // stage B: the chunk's 256 Enc per proof, challenges and responses on the GPU (blocking: host buffers)
+    auto gpu = [&](ProveChunk& c) {
+      zkp_range_ni_proofs p{nb, (uint32_t)EF, c.hi - c.lo, 0, n.data(), c.range.data(), c.ct.data(), c.c1.data(), c.c2.data(), c.kind.data(), c.jj.data(),
+                            c.rw1.data(), c.rr1.data(), c.rw2.data(), c.rr2.data()};
+      zkp_range_ni_witness w{c.x.data(), c.r.data(), c.w1.data(), c.w2.data(), c.r1.data(), c.r2.data()};
+      e.check(zkp_range_ni_prove_batch(e.ctx(), &p, &w, nullptr, nullptr, c.status.data(), 0), "zkp_range_ni_prove_batch");
+    };
+    // stage C: the proof objects of a chunk (0.19 MB each: bound by first-touch page faults, more than 2 threads only contend for
+    // the address space — measured at 4096 proofs: 16 threads 674 ms, one 377 ms)
+    auto rebuild = [&](ProveChunk& c) {
+      parallel_for(c.hi - c.lo, [&](size_t k) {
+        const size_t b = c.lo + k;
+        if (c.status[k] != 0) throw Panic("RangeProofNi::prove: malformed (the reference would panic)");
+        RangeProofNi& o = out[b];
+        o.ek = ek; o.range = st[b].range; o.ciphertext = st[b].ciphertext; o.error_factor = EF;
+        o.encrypted_pairs.c1.reserve(EF); o.encrypted_pairs.c2.reserve(EF); o.proof.responses.reserve(EF);
+        for (size_t i = 0; i < EF; i++) {
+          const size_t t = k * EF + i;
+          o.encrypted_pairs.c1.push_back(BigInt::from_limbs(&c.c1[t * 2 * kw], 2 * kw));
+          o.encrypted_pairs.c2.push_back(BigInt::from_limbs(&c.c2[t * 2 * kw], 2 * kw));
+          Response rs;
+          if (c.kind[t] == ZKP_RESP_OPEN) {
+            rs.kind = Response::Open;
+            rs.w1 = BigInt::from_limbs(&c.rw1[t * kw], kw); rs.r1 = BigInt::from_limbs(&c.rr1[t * kw], kw);
+            rs.w2 = BigInt::from_limbs(&c.rw2[t * kw], kw); rs.r2 = BigInt::from_limbs(&c.rr2[t * kw], kw);
+          } else {
+            rs.kind = Response::Mask; rs.j = c.jj[t];
+            rs.masked_x = BigInt::from_limbs(&c.rw1[t * kw], kw); rs.masked_r = BigInt::from_limbs(&c.rr1[t * kw], kw);
+          }
+          o.proof.responses.push_back(std::move(rs));
+        }
+      }, 2);
+    };
+
+    std::vector<std::unique_ptr<ProveChunk>> ch(chunks);
+    auto bounds = [&](size_t k) { return std::make_pair(B * k / chunks, B * (k + 1) / chunks); };
+    StopWatch sw;
+    ch[0].reset(new ProveChunk(bounds(0).first, bounds(0).second, kw, EF));
+    sample_flatten(*ch[0], ~0u);
+    tm.sample_flatten_ms = sw.lap();
+    for (size_t k = 0; k < chunks; k++) {
+      std::exception_ptr helper_error;
+      std::thread helper([&, k] {
+        try {
+          if (k + 1 < chunks) {                     // next chunk's inputs, on a few threads: the GPU call only waits
+            ch[k + 1].reset(new ProveChunk(bounds(k + 1).first, bounds(k + 1).second, kw, EF));
+            sample_flatten(*ch[k + 1], std::max(1u, host_threads() / 2));
+          }
+          if (k > 0) { rebuild(*ch[k - 1]); ch[k - 1].reset(); }
+        } catch (...) { helper_error = std::current_exception(); }
+      });
+      StopWatch g;
+      try { gpu(*ch[k]); } catch (...) { helper.join(); throw; }
+      tm.gpu_ms += g.lap();
+      helper.join();
+      if (helper_error) std::rethrow_exception(helper_error);
+    }
+    sw.lap();
+    rebuild(*ch[chunks - 1]);
     tm.rebuild_ms = sw.lap();
     return out;
   }
