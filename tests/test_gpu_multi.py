@@ -210,3 +210,21 @@ def test_bench_two_ranks_share_the_one_gpu(scaling):
     assert ck["n_gpus"] == 2 and ck["keys_per_rank"] == 513 and ck["all_rejected_as_expected"]          # 1025 keys: blocks of 513 + 512
     assert big["n_gpus"] == 2 and big["batch_per_rank"] == 5 and big["verdicts_ok"]                       # 9 proofs: blocks of 5 + 4
     assert all(v.get("verdicts_ok", True) and v.get("all_accepted", True) for v in legs.values())
+
+
+def test_receive_buffers_of_an_8_rank_prove_step_fit_the_gpu():
+    """the round-3 verdict: "at N = 8 weak scaling that is a 4.3 GB receive buffer per rank per step that nothing has ever allocated
+    on hardware".  shard.GatherBuffers for world = 8 at the headline rank block (4096 proofs, n = 2048): c1 + c2 = 2 x 4.29 GB next
+    to the rank's own 1.5 GB batch — allocated ONCE here, as bench.make_steps does outside its timed steps."""
+    import importlib
+    import torch
+    shard = importlib.import_module("zk-paillier_amd.shard")
+    like = torch.empty((4096, 128, 128), dtype=torch.int32, device="cuda:0")          # one rank's c1: 4096 x 128 rows x 4096 bits
+    bufs = [shard.GatherBuffers(like, 8) for _ in range(2)]
+    assert all(b.nbytes == 8 * 4096 * 128 * 128 * 4 == 4294967296 for b in bufs) and bufs[0].pad is None
+    unequal = shard.GatherBuffers(like[:4093], 8, counts=[4093] * 7 + [4090])
+    assert unequal.pad.shape[0] == 4093 and unequal.out.shape[0] == 8 * 4093
+    bufs[0].out[-1].fill_(7); torch.cuda.synchronize()
+    assert int(bufs[0].out[-1, -1, -1].item()) == 7
+    del bufs, unequal, like
+    torch.cuda.empty_cache()
