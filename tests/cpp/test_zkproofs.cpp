@@ -183,6 +183,23 @@ static void test_correct_zk_proof_with_salt_str() {   // :133-138
   ASSERT(proof.verify(ek, salt_str, 8).is_err());             // tampered root
 }
 
+static void test_correct_key_verify_batch_and_noncanonical_roots() {   // many keys in one launch; sigma + k n and sigma - n verify like sigma
+  auto [ek, dk] = test_keypair().keys();
+  NiCorrectKeyProof good = NiCorrectKeyProof::proof(dk), wide = good, neg = good, bad = good, few = good;
+  wide.sigma_vec[2] = wide.sigma_vec[2] + ek.n * BigInt::pow2(300);        // mod_pow(sigma, n, n) only sees sigma mod n (correct_key_ni.rs:92)
+  neg.sigma_vec[5] = neg.sigma_vec[5] - ek.n;                              // negative: mpz_powm reduces it into [0, n)
+  bad.sigma_vec[7] = bad.sigma_vec[7] + BigInt::one();
+  few.sigma_vec.resize(10);                                                // sigma_vec[10]: index panic
+  EncryptionKey even{ek.n + BigInt::one(), (ek.n + BigInt::one()) * (ek.n + BigInt::one())};      // gcd(primorial, n) >= 2: Err (correct_key_ni.rs:87-88,95)
+  EncryptionKey huge{BigInt::pow2(4200) + BigInt::one(), BigInt::one()};
+  auto res = NiCorrectKeyProof::verify_batch({{&ek, &good}, {&ek, &wide}, {&ek, &neg}, {&ek, &bad}, {&ek, &few}, {&even, &good}, {&huge, &good}});
+  ASSERT(res[0].is_ok() && res[1].is_ok() && res[2].is_ok());
+  ASSERT(res[3].is_err());
+  ASSERT(res[4].would_panic());
+  ASSERT(res[5].is_err());
+  ASSERT(res[6].is_unsupported());
+}
+
 // ---- wi_dlog_proof.rs tests
 static int legendre_symbol(const BigInt& a, const BigInt& p) {   // :94-107
   BigInt e = (p - BigInt::one()).div_floor(BigInt(2));
@@ -415,6 +432,7 @@ int main() {
   run("range_proof_ni::over-wide pair on a mask row follows the raw transcript", test_overwide_pair_on_a_mask_row_follows_the_raw_transcript);
   run("correct_key_ni::test_correct_zk_proof_no_salt_str", test_correct_zk_proof_no_salt_str);
   run("correct_key_ni::test_correct_zk_proof_with_salt_str", test_correct_zk_proof_with_salt_str);
+  run("correct_key_ni::verify_batch, non-canonical roots, panic and unsupported key", test_correct_key_verify_batch_and_noncanonical_roots);
   run("wi_dlog_proof::test_correct_dlog_proof", test_correct_dlog_proof);
   run("wi_dlog_proof::test_bad_dlog_proof", test_bad_dlog_proof, true);
   run("wi_dlog_proof::test_bad_dlog_proof_2", test_bad_dlog_proof_2, true);

@@ -693,17 +693,47 @@ class NiCorrectKeyProof {
     for (size_t i = 0; i < M2; i++) p.sigma_vec.push_back(BigInt::from_limbs(&out[i * kw], kw));
     return p;
   }
-  // correct_key_ni.rs:73-100
-  Result verify(const EncryptionKey& ek, const uint8_t* salt = SALT_STRING, size_t salt_len = 4) const {
+  // correct_key_ni.rs:73-100 for many (key, proof) pairs in ONE zkp_correct_key_ni_verify_batch (keys of one kernel width per call; the
+  // widths are grouped here).  sigma_i is prover-chosen: any size, either sign — the reference only uses it as mod_pow(sigma_i, n, n),
+  // which depends on sigma_i mod n (floored: mpz_powm), so a non-canonical root is reduced on the host and gets the reference's verdict;
+  // fewer than 11 roots is the reference's index panic (:92); an even key fails the primorial gcd test whatever the roots are (Err); a key
+  // the engine cannot carry (not positive, or wider than 4096 bits) is Result::unsupported.
+  static std::vector<Result> verify_batch(const std::vector<std::pair<const EncryptionKey*, const NiCorrectKeyProof*>>& items, const uint8_t* salt = SALT_STRING,
+                                          size_t salt_len = 4) {
     Engine& e = Engine::instance();
-    if (sigma_vec.size() < M2) throw Panic("index out of bounds: sigma_vec");   // self.sigma_vec[i], :92
-    const uint32_t nb = width_for(ek.n), kw = nb / 32;
-    std::vector<uint32_t> n(kw), sg(M2 * kw);
-    ek.n.to_limbs(n.data(), kw);
-    for (size_t i = 0; i < M2; i++) sigma_vec[i].to_limbs(&sg[i * kw], kw);
-    uint8_t v = 9;
-    e.check(zkp_correct_key_ni_verify_batch(e.ctx(), nb, 1, n.data(), sg.data(), salt, (uint32_t)salt_len, &v, 0), "zkp_correct_key_ni_verify_batch");
-    return Result(v == ZKP_VERDICT_ACCEPT);
+    std::vector<Result> out(items.size(), Result(false));
+    for (uint32_t nb : {1024u, 2048u, 4096u}) {
+      const uint32_t kw = nb / 32;
+      std::vector<size_t> idx;
+      for (size_t k = 0; k < items.size(); k++) {
+        const BigInt& n = items[k].first->n;
+        if (!n.is_negative() && !n.is_zero() && !n.is_odd()) continue;   // an even key: gcd(primorial, n) >= 2, Err(IncorrectProof) whatever the roots are (:87-88,95); `out` holds that already
+        const bool supported = !n.is_negative() && n.is_odd() && n.bit_length() >= 2 && n.bit_length() <= 4096;
+        if (!supported) { if (nb == 1024) out[k] = Result::unsupported("NiCorrectKeyProof::verify: the key is not a positive integer of at most 4096 bits"); continue; }
+        if (width_for(n) != nb) continue;
+        if (items[k].second->sigma_vec.size() < M2) { out[k] = Result::panicked("index out of bounds: sigma_vec"); continue; }
+        idx.push_back(k);
+      }
+      if (idx.empty()) continue;
+      std::vector<uint32_t> n(idx.size() * kw), sg(idx.size() * M2 * kw);
+      std::vector<uint8_t> v(idx.size(), 9);
+      for (size_t q = 0; q < idx.size(); q++) {
+        const EncryptionKey& ek = *items[idx[q]].first;
+        ek.n.to_limbs(&n[q * kw], kw);
+        for (size_t i = 0; i < M2; i++) {
+          const BigInt& s = items[idx[q]].second->sigma_vec[i];
+          (s.fits_limbs(kw) ? s : s.modulus(ek.n)).to_limbs(&sg[(q * M2 + i) * kw], kw);
+        }
+      }
+      e.check(zkp_correct_key_ni_verify_batch(e.ctx(), nb, idx.size(), n.data(), sg.data(), salt, (uint32_t)salt_len, v.data(), 0), "zkp_correct_key_ni_verify_batch");
+      for (size_t q = 0; q < idx.size(); q++) out[idx[q]] = Result(v[q] == ZKP_VERDICT_ACCEPT);
+    }
+    return out;
+  }
+  Result verify(const EncryptionKey& ek, const uint8_t* salt = SALT_STRING, size_t salt_len = 4) const {
+    Result r = verify_batch({{&ek, this}}, salt, salt_len)[0];
+    (void)r.is_ok();                          // a single proof panics right here, as the reference does
+    return r;
   }
 };
 
