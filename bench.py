@@ -361,7 +361,7 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch proofs per rank; strong: --batch proofs in all, cut into N blocks of proof indices")
     ap.add_argument("--gather", choices=["all", "verdicts"], default="all",
-                    help="what a PROVE step exchanges: all = the c1 / c2 slabs are all-gathered onto every rank (north_star; 2 x 128 KiB per proof "
+                    help="what a PROVE step exchanges: all = the c1 / c2 slabs are all-gathered onto every rank (north_star; 2 x 64 KiB per proof "
                          "at n = 2048: 4.3 GB received per rank per step at 8 x 4096 proofs); verdicts = nothing (each rank keeps its proofs)")
     ap.add_argument("--n-bits", type=int, default=2048)
     ap.add_argument("--cpu-sample", type=int, default=64, help="proofs verified by the all-cores CPU baseline (0 = skip the CPU legs and the oracle samples)")

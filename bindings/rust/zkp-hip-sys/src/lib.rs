@@ -38,6 +38,7 @@ pub const ZKP_BIGINT_HEX: u32 = 1;
 pub const ZKP_BIGINT_BYTES: u32 = 2;
 pub const ZKP_GATHER_HOST: u32 = 0;
 pub const ZKP_GATHER_RCCL: u32 = 1;
+pub const ZKP_GATHER_COPY: u32 = 2;
 /// `ZKP_BIGINT_FORMS(key_form, bare_form)`: the text forms of `ek.n` and of the bare BigInts of a RangeProofNi document
 pub const fn ZKP_BIGINT_FORMS(key_form: u32, bare_form: u32) -> u32 {
     (key_form << 4) | bare_form

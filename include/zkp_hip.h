@@ -408,6 +408,8 @@ int32_t zkp_multi_last_timing(zkp_multi* m, uint32_t i, double* out_ms, uint64_t
  *   stays valid until the next batch call or zkp_multi_destroy; work that consumes it is ordered on zkp_ctx_stream(zkp_multi_ctx(m, i)). */
 #define ZKP_GATHER_HOST 0u
 #define ZKP_GATHER_RCCL 1u
+#define ZKP_GATHER_COPY 2u   /* the device-resident gather of ZKP_GATHER_RCCL by device-to-device copies instead of the collective: for device
+                                lists RCCL has no communicator for (a GPU listed several times); same layout, same zkp_multi_gathered */
 int32_t zkp_multi_set_gather(zkp_multi* m, uint32_t mode);
 int32_t zkp_multi_gathered(zkp_multi* m, uint32_t device_index, uint32_t which, void** out_device_ptr, uint64_t* out_block_stride_bytes,
                            uint64_t* out_bytes);

@@ -153,7 +153,7 @@ class DecItem(C.Structure):
 DEC_OK, DEC_INVALID, DEC_NEGATIVE, DEC_OVERFLOW = 0, 1, 2, 3
 BIGINT_DEC, BIGINT_HEX, BIGINT_BYTES = 0, 1, 2
 DOC_OK, DOC_INVALID, DOC_HOST_PATH = 0, 2, 3
-GATHER_HOST, GATHER_RCCL = 0, 1
+GATHER_HOST, GATHER_RCCL, GATHER_COPY = 0, 1, 2
 
 
 def bigint_forms(key_form: int, bare_form: int) -> int:
