@@ -304,7 +304,7 @@ def make_steps(engine, pb, wt, verdict, world, counts=None, gather="all"):
     """the two timed step functions.  `engine` supplies prove / verify on this rank's block of proofs; the gather of the output
     slabs goes through zk-paillier_amd/shard.py (RCCL on GPUs; tests/test_distributed_gloo.py drives these same functions over gloo).
     counts: proofs per rank when the blocks are unequal (a total that N does not divide), else None.
-    gather: "all" (north_star: the c1 / c2 slabs of a prove step are reassembled on every rank, 2 x 128 KiB per proof at n = 2048)
+    gather: "all" (north_star: the c1 / c2 slabs of a prove step are reassembled on every rank, 2 x 64 KiB per proof at n = 2048)
     or "verdicts" (a prove step exchanges nothing: each rank keeps its own proofs; verify steps always gather their verdict bytes).
     The receive buffers are allocated HERE, once, not inside the timed steps; out["recv_bytes"] = bytes this rank receives per step."""
     shard = importlib.import_module("zk-paillier_amd.shard")

@@ -13,7 +13,7 @@ def shard_range(total: int, world: int, rank: int):
 
 class GatherBuffers:
     """receive (and, for unequal blocks, padding) buffers of ONE recurring all-gather, allocated once outside the timed loop:
-    at N = 8 the prove-side gather of a 4096-proof rank block receives 8 x 537 MB = 4.3 GB per output per rank, which a serving
+    at N = 8 the prove-side gather of a 4096-proof rank block receives 8 x 268 MB = 2.1 GB per output (c1, c2: 4.3 GB together) per rank, which a serving
     loop must not allocate per step.  nbytes = what this rank receives per gather."""
 
     def __init__(self, like, world: int, counts=None):
