@@ -408,6 +408,47 @@ static void interactive_case(bool honest) {   // :431-525
   Result result = RangeProof::verifier_output(ek, vc.e, ep, z, range, cipher_x, SEF);
   ASSERT(result.is_ok() == honest);
 }
+// the interactive verifier on values the fixed-width call cannot carry: a randomness field moved by a multiple of n keeps the verdict
+// (r^n mod n^2 depends on r mod n), a negative masked_x / short vectors get the reference's Err / panic — through verify_general with the
+// verifier's own challenge bits
+static void test_interactive_verifier_on_noncanonical_values() {
+  BigInt range = BigInt::sample(RANGE_BITS);
+  auto [ek, dk] = test_keypair().keys();
+  auto vc = RangeProof::verifier_commit(ek);
+  auto [ep, data] = RangeProof::generate_encrypted_pairs(ek, range, SEF);
+  BigInt secret_r = BigInt::sample_below(ek.n), secret_x = BigInt::sample_below(range.div_floor(BigInt(3)));
+  BigInt cipher_x = Paillier::encrypt_with_chosen_randomness(ek, secret_x, secret_r);
+  const Proof z = RangeProof::generate_proof(ek, secret_x, secret_r, vc.e, range, data, SEF);
+  ASSERT(RangeProof::verifier_output(ek, vc.e, ep, z, range, cipher_x, SEF).is_ok());
+  {
+    Proof y = z;
+    for (auto& rs : y.responses) {
+      if (rs.kind == Response::Open) { rs.r1 = rs.r1 - ek.n; rs.r2 = rs.r2 + ek.n * BigInt::pow2(77); }
+      else rs.masked_r = rs.masked_r - ek.n * BigInt(3);
+    }
+    ASSERT(RangeProof::verifier_output(ek, vc.e, ep, y, range, cipher_x, SEF).is_ok());
+  }
+  {
+    Proof y = z;
+    size_t i = 0;
+    while (y.responses[i].kind != Response::Mask) i++;
+    y.responses[i].masked_x = y.responses[i].masked_x - ek.n;
+    ASSERT(RangeProof::verifier_output(ek, vc.e, ep, y, range, cipher_x, SEF).is_err());
+  }
+  {
+    Proof y = z;
+    y.responses.resize(SEF - 1);
+    bool threw = false;
+    try { (void)RangeProof::verifier_output(ek, vc.e, ep, y, range, cipher_x, SEF); } catch (const Panic&) { threw = true; }
+    ASSERT(threw);
+  }
+  {
+    // a negative ciphertext: every Mask row's product turns negative and can only equal a zero Enc -> Err as soon as there is a Mask row
+    bool any_mask = false;
+    for (auto& rs : z.responses) any_mask |= rs.kind == Response::Mask;
+    ASSERT(RangeProof::verifier_output(ek, vc.e, ep, z, range, cipher_x - ek.nn, SEF).is_ok() == !any_mask);
+  }
+}
 static void test_range_proof_correct_proof() { interactive_case(true); }
 static void test_range_proof_incorrect_proof() { interactive_case(false); }
 
@@ -423,6 +464,7 @@ int main() {
   run("range_proof::test_generate_proof", test_generate_proof);
   run("range_proof::test_range_proof_correct_proof", test_range_proof_correct_proof);
   run("range_proof::test_range_proof_incorrect_proof", test_range_proof_incorrect_proof);
+  run("range_proof::interactive verifier on negative / over-wide values and short vectors", test_interactive_verifier_on_noncanonical_values);
   run("range_proof_ni::test_prover", test_prover);
   run("range_proof_ni::test_verifier_for_correct_proof", test_verifier_for_correct_proof);
   run("range_proof_ni::test_verifier_for_incorrect_proof", test_verifier_for_incorrect_proof, true);

@@ -163,6 +163,23 @@ def random_mutation(rng, proof):
         proof["range"] = op(proof["range"], n)
 
 
+def test_the_two_oracles_agree_on_randomly_edited_proofs(oracle):
+    """differential check of the two restatements over signed integers (C + mpz against pure Python) on 6 documents with 1-3 random
+    signed / over-wide edits each: the pair the GPU fuzz below is judged against"""
+    import random
+    rng = random.Random(20240904)
+    base = S.honest_proof(b"signed-fuzz-cpu", oracle)[0]
+    seen = set()
+    for k in range(6):
+        p = dict(base, c1=list(base["c1"]), c2=list(base["c2"]), responses=list(base["responses"]))
+        for _ in range(rng.randrange(1, 4)):
+            random_mutation(rng, p)
+        v = oracle.range_ni_verify_decimal(p)[0]
+        assert v == S.model_verdict(p), k
+        seen.add(v)
+    assert seen <= {"ok", "err", "panic"}
+
+
 @pytest.mark.gpu
 def test_gpu_host_layer_on_randomly_edited_proofs(oracle):
     """fuzz: 48 documents with 1-3 random signed / over-wide edits each (seed printed) through the host layer on the GPU against the

@@ -461,7 +461,9 @@ class RangeProofNi {
   // exact (:293-298,335), to_bytes = magnitude in compute_digest (utils.rs:15-18, over EVERY stored c1 / c2).  Panics of the
   // reference — bits_of_e[i], responses[i], c1[i] / c2[i] past the end (:272-274,293,296,325,327) — are found per row, in the arm
   // that indexes, and win over any `false`.  All Enc of all these proofs: one batch on the GPU.
-  static std::vector<Result> verify_general(const EncryptionKey& ek, const std::vector<const RangeProofNi*>& proofs) {
+  // challenges: the verifier's own challenge bytes per proof (interactive RangeProof::verifier_output); null = Fiat-Shamir (above).
+  static std::vector<Result> verify_general(const EncryptionKey& ek, const std::vector<const RangeProofNi*>& proofs,
+                                            const std::vector<std::vector<uint8_t>>* challenges = nullptr) {
     struct Row { uint8_t what = 0; size_t enc0 = 0; BigInt expect0, expect1; bool flag = true; };   // what: 0 false, 1 open, 2 mask
     struct Plan { std::vector<Row> rows; bool panic = false; };
     std::vector<Plan> plans(proofs.size());
@@ -469,11 +471,15 @@ class RangeProofNi {
     for (size_t b = 0; b < proofs.size(); b++) {
       const RangeProofNi& p = *proofs[b];
       Plan& pl = plans[b];
-      detail::Sha256 sh;
-      sh.update(ek.n);
-      for (const BigInt& v : p.encrypted_pairs.c1) sh.update(v);
-      for (const BigInt& v : p.encrypted_pairs.c2) sh.update(v);
-      const std::vector<uint8_t> ebytes = sh.finish().to_bytes();      // leading zero bytes of the digest are dropped
+      std::vector<uint8_t> ebytes;
+      if (challenges) ebytes = (*challenges)[b];
+      else {
+        detail::Sha256 sh;
+        sh.update(ek.n);
+        for (const BigInt& v : p.encrypted_pairs.c1) sh.update(v);
+        for (const BigInt& v : p.encrypted_pairs.c2) sh.update(v);
+        ebytes = sh.finish().to_bytes();                               // leading zero bytes of the digest are dropped
+      }
       const BigInt third = p.range.div_floor(BigInt(3)), two_thirds = BigInt(2) * third;      // :264-265
       for (size_t i = 0; i < p.error_factor && !pl.panic; i++) {
         if (i >= 8 * ebytes.size() || i >= p.proof.responses.size()) { pl.panic = true; break; }
@@ -632,7 +638,23 @@ struct RangeProof {
     Engine& e = Engine::instance();
     const uint32_t nb = width_for(ek.n), kw = nb / 32;
     const size_t EF = error_factor;
-    if (proof.responses.size() < EF || ep.c1.size() < EF || ep.c2.size() < EF) throw Panic("index out of bounds");   // :274,293,296
+    // values the fixed-width call cannot carry (negative, over-wide), short vectors, a challenge of more than 32 bytes: the reference's
+    // row logic on signed host integers with the verifier's own challenge (RangeProofNi::verify_general), Enc still on the GPU
+    bool canonical = proof.responses.size() >= EF && ep.c1.size() >= EF && ep.c2.size() >= EF && ch.bytes.size() <= 32 && range.fits_limbs(kw) && cipher_x.fits_limbs(2 * kw);
+    for (size_t t = 0; canonical && t < EF; t++) {
+      const Response& rs = proof.responses[t];
+      canonical = ep.c1[t].fits_limbs(2 * kw) && ep.c2[t].fits_limbs(2 * kw) &&
+                  (rs.kind == Response::Open ? rs.w1.fits_limbs(kw) && rs.r1.fits_limbs(kw) && rs.w2.fits_limbs(kw) && rs.r2.fits_limbs(kw)
+                                             : rs.masked_x.fits_limbs(kw) && rs.masked_r.fits_limbs(kw));
+    }
+    if (!canonical) {
+      RangeProofNi tmp;
+      tmp.ek = ek; tmp.range = range; tmp.ciphertext = cipher_x; tmp.encrypted_pairs = ep; tmp.proof = proof; tmp.error_factor = EF;
+      const std::vector<std::vector<uint8_t>> chal{ch.bytes};
+      Result r = RangeProofNi::verify_general(ek, {&tmp}, &chal)[0];
+      (void)r.is_ok();                          // a panic of the reference is thrown here
+      return r;
+    }
     std::vector<uint32_t> n(kw), rg(kw), ct(2 * kw), c1(EF * 2 * kw), c2(EF * 2 * kw), rw1(EF * kw), rr1(EF * kw), rw2(EF * kw), rr2(EF * kw);
     std::vector<uint8_t> kind(EF), jj(EF);
     ek.n.to_limbs(n.data(), kw); range.to_limbs(rg.data(), kw); cipher_x.to_limbs(ct.data(), 2 * kw);
