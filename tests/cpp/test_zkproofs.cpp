@@ -190,6 +190,17 @@ static void test_correct_key_verify_batch_and_noncanonical_roots() {   // many k
   neg.sigma_vec[5] = neg.sigma_vec[5] - ek.n;                              // negative: mpz_powm reduces it into [0, n)
   bad.sigma_vec[7] = bad.sigma_vec[7] + BigInt::one();
   few.sigma_vec.resize(10);                                                // sigma_vec[10]: index panic
+  {  // the wire format of such a proof: the GPU reader answers "host path" for the negative root, the host parser takes over
+    const std::string doc = serde_json::to_string(good, ek);
+    const size_t q = doc.find('"', doc.find('[')) + 1;                   // first root: make it negative by writing sigma_0 - n
+    const size_t qe = doc.find('"', q);
+    const BigInt s0 = BigInt::from_str_radix10(doc.substr(q, qe - q));
+    const std::string neg_doc = doc.substr(0, q) + (s0 - ek.n).to_str_radix10() + doc.substr(qe);
+    ASSERT(neg_doc.find("\"-") != std::string::npos);
+    NiCorrectKeyProof back = serde_json::correct_key_from_str(ek, neg_doc);
+    ASSERT(back.sigma_vec.size() == 11 && back.sigma_vec[0].is_negative() && back.sigma_vec[1] == good.sigma_vec[1]);
+    ASSERT(back.verify(ek).is_ok());
+  }
   EncryptionKey even{ek.n + BigInt::one(), (ek.n + BigInt::one()) * (ek.n + BigInt::one())};      // gcd(primorial, n) >= 2: Err (correct_key_ni.rs:87-88,95)
   EncryptionKey huge{BigInt::pow2(4200) + BigInt::one(), BigInt::one()};
   auto res = NiCorrectKeyProof::verify_batch({{&ek, &good}, {&ek, &wide}, {&ek, &neg}, {&ek, &bad}, {&ek, &few}, {&even, &good}, {&huge, &good}});

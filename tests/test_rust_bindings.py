@@ -223,3 +223,30 @@ def test_patch_applies_to_the_reference_tree():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_rust_patch.py"), "--reference", REFERENCE], capture_output=True, text=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
         assert r.returncode == 0, r.stderr
         assert subprocess.run(["git", "diff", "--quiet", "--", PATCH], cwd=ROOT).returncode in (0, 1)
+
+
+def test_hip_module_names_exist_in_the_reference_crate():
+    """every item hip.rs imports from the crate, and every field it reads, exists under that name in the reference tree (checked
+    where the tree is present): a rename upstream would otherwise only show when somebody compiles the module"""
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference tree is not on this machine")
+    src = open(HIP).read()
+    z = os.path.join(REFERENCE, "src", "zkproofs")
+    wanted = {"correct_key_ni.rs": ["pub struct NiCorrectKeyProof", "pub sigma_vec: Vec<BigInt>", "pub fn verify(&self, ek: &EncryptionKey, salt_str: &[u8])"],
+              "errors.rs": ["pub struct IncorrectProof"],
+              "range_proof.rs": ["pub struct EncryptedPairs", "pub c1: Vec<BigInt>", "pub c2: Vec<BigInt>", "pub struct Proof(", "pub enum Response", "Open {", "Mask {", "masked_x: BigInt", "masked_r: BigInt", "j: u8"],
+              "range_proof_ni.rs": ["pub struct RangeProofNi", "ek: EncryptionKey", "range: BigInt", "ciphertext: BigInt", "encrypted_pairs: EncryptedPairs", "proof: Proof", "error_factor: usize",
+                                    "pub fn verify(&self, ek: &EncryptionKey, ciphertext: &BigInt)", "pub fn verify_self(&self)"],
+              "wi_dlog_proof.rs": ["pub struct CompositeDLogProof", "pub x: BigInt", "pub y: BigInt", "pub struct DLogStatement", "pub N: BigInt", "pub g: BigInt", "pub ni: BigInt",
+                                   "pub fn prove(statement: &DLogStatement, secret: &BigInt)", "pub fn verify(&self, statement: &DLogStatement)"]}
+    for f, needles in wanted.items():
+        text = open(os.path.join(z, f)).read()
+        for n in needles:
+            assert n in text, f"{f}: `{n}` not found in the reference — hip.rs relies on it"
+    for use in re.findall(r"^use super::(\w+)::", src, re.M):
+        assert os.path.exists(os.path.join(z, use + ".rs")), f"hip.rs imports super::{use}, no such module in the reference"
+    # the crates hip.rs names are the reference's own dependencies (+ the sys crate the patch adds)
+    cargo = open(os.path.join(REFERENCE, "Cargo.toml")).read()
+    for crate, dep in (("curv", "curv-kzen"), ("paillier", 'package = "kzen-paillier"'), ("rand", "rand =")):
+        assert re.search(rf"^use {crate}::", src, re.M) and dep in cargo
+    assert "use zkp_hip_sys as sys;" in src and "zkp-hip-sys" in open(PATCH).read()

@@ -1152,6 +1152,7 @@ inline std::vector<std::pair<EncryptedPairs, Proof>> range_from_str(const Encryp
   }
   return out;
 }
+inline NiCorrectKeyProof correct_key_from_str_host(const std::string& doc);
 inline NiCorrectKeyProof correct_key_from_str(const EncryptionKey& ek, const std::string& doc) {
   Engine& e = Engine::instance();
   const uint32_t nb = width_for(ek.n), kw = nb / 32;
@@ -1159,6 +1160,7 @@ inline NiCorrectKeyProof correct_key_from_str(const EncryptionKey& ek, const std
   uint64_t off = 0, len = doc.size();
   uint8_t st = 9;
   e.check(zkp_json_correct_key_proof_batch(e.ctx(), doc.data(), &off, &len, nb, 1, sig.data(), &st, 0), "zkp_json_correct_key_proof_batch");
+  if (st == ZKP_DOC_HOST_PATH) return correct_key_from_str_host(doc);     // a negative or over-wide root: a valid NiCorrectKeyProof, parsed here
   if (st) throw std::runtime_error("serde_json: not a NiCorrectKeyProof of this width");
   NiCorrectKeyProof p;
   for (size_t i = 0; i < NiCorrectKeyProof::M2; i++) p.sigma_vec.push_back(BigInt::from_limbs(&sig[i * kw], kw));
@@ -1252,6 +1254,25 @@ struct Cur {
   }
 };
 }  // namespace detail_json
+
+// {"sigma_vec":["..", ..]} (correct_key_ni.rs:35-39) with signed roots of any size and any count
+inline NiCorrectKeyProof correct_key_from_str_host(const std::string& doc) {
+  detail_json::Cur j{doc};
+  NiCorrectKeyProof out;
+  bool seen = false;
+  j.object([&](const std::string& nm) {
+    if (nm != "sigma_vec") return false;
+    if (seen) j.fail("duplicate field");
+    seen = true;
+    j.expect('[');
+    if (!j.eat(']')) { do out.sigma_vec.push_back(j.dec()); while (j.eat(',')); j.expect(']'); }
+    return true;
+  });
+  if (!seen) j.fail("missing field `sigma_vec`");
+  j.ws();
+  if (j.p != doc.size()) j.fail("trailing characters");
+  return out;
+}
 
 inline RangeProofNi range_proof_ni_from_str(const std::string& doc, BigintText key_form = BigintText::Dec, BigintText bigint_form = BigintText::Dec) {
   detail_json::Cur j{doc};
