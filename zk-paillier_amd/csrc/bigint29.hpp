@@ -73,6 +73,22 @@ template <int G> __device__ __forceinline__ uint32_t bcast0(uint32_t v) {
   else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x001C);
 }
 
+// ZKP_AND_DPP=1 (A/B switch, round 4): the 29-bit limb mask is applied AFTER the DPP move and from a VGPR the compiler cannot see through,
+// so that its DPP combiner folds each (move, and) pair of a sub-step into one v_and_b32_dpp: 2 of the ~8 bookkeeping instructions of a
+// sub-step.  Measured: see DESIGN.md section 8 (the kernels are at the board's power cap; fewer instructions buy a lower clock).
+#ifndef ZKP_AND_DPP
+#define ZKP_AND_DPP 0
+#endif
+__device__ __forceinline__ uint32_t limb_mask_operand() {
+#if ZKP_AND_DPP
+  uint32_t m;
+  asm("v_mov_b32 %0, 0x1fffffff" : "=v"(m));
+  return m;
+#else
+  return LMASK;
+#endif
+}
+
 // lane j receives the value of lane j+1 (one DPP move).  The top lane of a group receives the value of the NEXT group's
 // lane 0 (or 0 at the end of a DPP row): inside montmul that value is the low limb of lane 0's finished bottom column,
 // which the quotient digit has just made zero, so no select is needed to clear it (ZKP_SELECT_TOP=1 restores the select).
@@ -178,6 +194,7 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
   uint64_t c[W];
 #pragma unroll
   for (int k = 0; k < W; k++) c[k] = 0;
+  [[maybe_unused]] const uint32_t lm = limb_mask_operand();
   [[maybe_unused]] uint64_t sink;   // carry-out operand of the explicit v_mad_u64_u32 below (never set: the sums stay below 2^64)
 
 #pragma unroll 1
@@ -188,12 +205,20 @@ __device__ __forceinline__ void montmul(uint32_t (&R)[W], const uint32_t (&A)[W]
       const uint32_t b = ldsB[s * BLK + t];
 #pragma unroll
       for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)A[k] * b;
+#if ZKP_AND_DPP
+      const uint32_t q = bcast0<G>(ORUP ? (uint32_t)c[t] : (uint32_t)c[t] * n1) & lm;
+#else
       const uint32_t q = bcast0<G>((ORUP ? (uint32_t)c[t] : (uint32_t)c[t] * n1) & LMASK);
+#endif
 #pragma unroll
       for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q;
       const uint64_t v = c[t];
       c[(t + 1) % W] += v >> LB;
+#if ZKP_AND_DPP
+      c[t] = (uint64_t)(from_next<G>((uint32_t)v, gl) & lm);
+#else
       c[t] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+#endif
       if constexpr (SAFE && COL_NEEDS_CARE) {
         constexpr int H = W / 2;
         const uint32_t hi = (uint32_t)(c[(t + H) % W] >> 32);
@@ -237,6 +262,7 @@ __device__ __forceinline__ void montsqr(uint32_t (&X)[W], const uint32_t* ldsB /
   uint64_t c[W];
 #pragma unroll
   for (int k = 0; k < W; k++) c[k] = 0;
+  [[maybe_unused]] const uint32_t lm = limb_mask_operand();
 #pragma unroll 1
   for (int s = 0; s < G; s++) {
 #pragma unroll
@@ -250,12 +276,20 @@ __device__ __forceinline__ void montsqr(uint32_t (&X)[W], const uint32_t* ldsB /
         const bool take = (W & 1) ? (d >= 1 && d <= H) : ((d >= 1 && d < H) || (d == H && t < H));
         if (take) c[(t + k) % W] += (uint64_t)X[k] * b2;
       }
+#if ZKP_AND_DPP
+      const uint32_t q = bcast0<G>((uint32_t)c[t]) & lm;
+#else
       const uint32_t q = bcast0<G>((uint32_t)c[t] & LMASK);
+#endif
 #pragma unroll
       for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q;
       const uint64_t v = c[t];
       c[(t + 1) % W] += v >> LB;
+#if ZKP_AND_DPP
+      c[t] = (uint64_t)(from_next<G>((uint32_t)v, gl) & lm);
+#else
       c[t] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+#endif
     }
   }
   uint64_t cy = 0;
