@@ -313,3 +313,39 @@ def test_gpu_whole_range_proof_ni_documents(ctx, oracle, key_enc, enc):
         pswap = zkp.RangeBatch(n_bits, 1, ef, shared_key=False)
         ctx.json_range_proof_ni([docs[0]], zkp.bigint_forms(enc, key_enc), pswap.struct(), st)
         assert st[0] != 0 or L.limbs_to_int(pswap.n[0]) != cases[0][0]["n"]
+
+
+@pytest.mark.gpu
+def test_gpu_json_readers_into_device_resident_batches(ctx, oracle):
+    """ZKP_F_DEVICE_PTRS: the SoA batch and the status bytes live in HBM (documents and offsets stay host text); a document that is
+    not converted as a whole — invalid, or valid but outside the layout (a negative number) — leaves only zero rows behind"""
+    import torch
+    n_bits, ef, kw = 1024, 4, 32
+    n = H.test_key(512)[2]
+    d = pm.Drbg(b"json-device")
+    cs = [d.below(n * n) for _ in range(ef)]
+    good = pairs_json(cs, cs[::-1])
+    docs = [good, good.replace(b'["', b'["-', 1), good[:-1], good]
+    pg = zkp.RangeBatch(n_bits, len(docs), ef, shared_key=True, device="cuda")
+    for f in ("c1", "c2"):
+        getattr(pg, f).fill_(0x5A5A5A5A)
+    st = torch.full((len(docs),), 9, dtype=torch.uint8, device="cuda")
+    ctx.json_encrypted_pairs(docs, pg.struct(), st, device=True)
+    ctx.synchronize()
+    assert st.cpu().tolist() == [zkp.DOC_OK, zkp.DOC_HOST_PATH, zkp.DOC_INVALID, zkp.DOC_OK]
+    c1 = pg.c1.cpu().numpy().view(np.uint32); c2 = pg.c2.cpu().numpy().view(np.uint32)
+    for b in (0, 3):
+        assert [L.limbs_to_int(x) for x in c1[b]] == cs and [L.limbs_to_int(x) for x in c2[b]] == cs[::-1]
+    assert not c1[1:3].any() and not c2[1:3].any()
+    resp = [("open", 1, 2, 3, 4), ("mask", 2, 5, 6), ("open", 7, 8, 9, 10), ("mask", 1, 11, 12)]
+    g = proof_json(resp)
+    pdocs = [g, g.replace(b'"masked_r":"6"', b'"masked_r":"-6"'), g.replace(b'"Open"', b'"Opem"', 1), proof_json(resp[:3])]
+    for f in ("resp_w1", "resp_r1", "resp_w2", "resp_r2"):
+        getattr(pg, f).fill_(0x5A5A5A5A)
+    pg.resp_kind.fill_(7); pg.resp_j.fill_(7)
+    ctx.json_range_proof(pdocs, pg.struct(), st, device=True)
+    ctx.synchronize()
+    assert st.cpu().tolist() == [zkp.DOC_OK, zkp.DOC_HOST_PATH, zkp.DOC_INVALID, zkp.DOC_HOST_PATH]
+    assert pg.resp_kind.cpu().tolist() == [[0, 1, 0, 1]] + [[0, 0, 0, 0]] * 3 and pg.resp_j.cpu().tolist() == [[0, 2, 0, 1]] + [[0, 0, 0, 0]] * 3
+    w1 = pg.resp_w1.cpu().numpy().view(np.uint32)
+    assert [L.limbs_to_int(x) for x in w1[0]] == [1, 5, 7, 11] and not w1[1:].any() and not pg.resp_r2.cpu().numpy()[1:].any()
