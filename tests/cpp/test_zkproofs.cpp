@@ -463,6 +463,42 @@ static void test_interactive_verifier_on_noncanonical_values() {
 static void test_range_proof_correct_proof() { interactive_case(true); }
 static void test_range_proof_incorrect_proof() { interactive_case(false); }
 
+// CompositeDLogProof::verify on shapes the fixed-width call does not carry: a secret of 900 / 2100 bits makes y = r + e s over-wide
+// (the reference does not bound it), a base moved by a multiple of N changes the hash but not the powers
+static void test_dlog_verify_on_noncanonical_values() {
+  auto [ek, dk] = test_keypair().keys();
+  const BigInt N = ek.n;
+  BigInt g = BigInt::sample_below(N - BigInt::one());
+  while (BigInt::gcd(g, N) != BigInt::one()) g = BigInt::sample_below(N - BigInt::one());
+  const BigInt g_inv = BigInt::mod_inv(g, N);
+  for (size_t secret_bits : {256, 900, 2100}) {
+    const BigInt s = BigInt::sample(secret_bits) + BigInt::pow2(secret_bits - 1);
+    const BigInt ni = CompositeDLogProof::mod_pow_wide(g_inv, s, N);                    // ni = g^-s (wi_dlog_proof.rs:128-130)
+    for (int shifted = 0; shifted < 2; shifted++) {
+      DLogStatement st{N, shifted ? g + N * BigInt::pow2(70) : g, shifted ? ni - N : ni};     // same residues, other integers (negative ni)
+      // the prover's side of :53-62 with the statement's own integers in the hash
+      const BigInt r = BigInt::sample_below(BigInt::pow2(512));
+      CompositeDLogProof pr;
+      pr.x = mod_pow(st.g, r, N);
+      const BigInt e = detail::compute_digest({&pr.x, &st.g, &st.N, &st.ni});
+      pr.y = r + e * s;
+      ASSERT(pr.y.bit_length() > secret_bits);
+      ASSERT(pr.verify(st).is_ok());
+      CompositeDLogProof bad = pr; bad.y = bad.y + BigInt::one();
+      ASSERT(bad.verify(st).is_err());
+      CompositeDLogProof badx = pr; badx.x = badx.x + N;                                  // x >= N can never equal a residue
+      ASSERT(badx.verify(st).is_err());
+    }
+  }
+  DLogStatement not_coprime{N, dk.p, BigInt(5)};
+  CompositeDLogProof any{BigInt(3), BigInt::pow2(900)};
+  bool threw = false;
+  try { (void)any.verify(not_coprime); } catch (const Panic&) { threw = true; }
+  ASSERT(threw);
+  CompositeDLogProof negy{BigInt(3), BigInt::zero() - BigInt(7)};
+  ASSERT(negy.verify(DLogStatement{N, g, BigInt(5)}).is_unsupported());
+}
+
 int main() {
   run("serde_json round trip (EncryptedPairs, Proof, NiCorrectKeyProof)", test_serde_round_trip);
   run("multiplication_proof::test_mul_proof", test_mul_proof);
@@ -486,6 +522,7 @@ int main() {
   run("correct_key_ni::test_correct_zk_proof_no_salt_str", test_correct_zk_proof_no_salt_str);
   run("correct_key_ni::test_correct_zk_proof_with_salt_str", test_correct_zk_proof_with_salt_str);
   run("correct_key_ni::verify_batch, non-canonical roots, panic and unsupported key", test_correct_key_verify_batch_and_noncanonical_roots);
+  run("wi_dlog_proof::verify on over-wide responses and shifted bases", test_dlog_verify_on_noncanonical_values);
   run("wi_dlog_proof::test_correct_dlog_proof", test_correct_dlog_proof);
   run("wi_dlog_proof::test_bad_dlog_proof", test_bad_dlog_proof, true);
   run("wi_dlog_proof::test_bad_dlog_proof_2", test_bad_dlog_proof_2, true);

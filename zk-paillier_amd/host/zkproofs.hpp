@@ -838,10 +838,39 @@ class CompositeDLogProof {
     e.check(zkp_dlog_prove_batch(e.ctx(), nb, Y_BITS, 1, N.data(), g.data(), ni.data(), s.data(), rr.data(), x.data(), y.data(), 0), "zkp_dlog_prove_batch");
     return CompositeDLogProof{BigInt::from_limbs(x.data(), kw), BigInt::from_limbs(y.data(), Y_BITS / 32)};
   }
-  // wi_dlog_proof.rs:67-91
+  // base^exp mod N for a non-negative exponent of ANY length (a prover-chosen y is not bounded): exponents wider than the modulus
+  // width go through the GPU in chunks, acc = acc^(2^c) * base^chunk, most significant chunk first
+  static BigInt mod_pow_wide(const BigInt& base, const BigInt& exp, const BigInt& N) {
+    const size_t mb = N.bit_length() <= 2048 ? 2048 : N.bit_length() <= 4096 ? 4096 : 8192, chunk = mb - 32;
+    if (exp.bit_length() <= mb) return mod_pow(base, exp, N);
+    BigInt acc = BigInt::one();
+    for (size_t hi = (exp.bit_length() + chunk - 1) / chunk; hi-- > 0;) {
+      BigInt part;
+      for (size_t b = 0; b < chunk; b++) if (exp.bit(hi * chunk + b)) part = part + BigInt::pow2(b);
+      acc = (mod_pow(acc, BigInt::pow2(chunk), N) * mod_pow(base, part, N)).modulus(N);
+    }
+    return acc;
+  }
+  // wi_dlog_proof.rs:67-91.  Honest shapes (x, g, ni < N, 0 <= y < 2^768) go to zkp_dlog_verify_batch.  Anything else a received proof
+  // or statement may hold — an over-wide y (y = r + e s is not bounded by the reference), g / ni / x that are negative or >= N — is
+  // evaluated as the reference does it: the pre-checks and the hash (over the RAW values' magnitudes) on the host, the two
+  // exponentiations on the GPU (mod_pow reduces its base into [0, N), as mpz_powm does), mod_mul and the compare on the host.
+  // Not carried: a modulus the engine cannot take (even, or wider than 4096 bits) and a NEGATIVE y ([upstream] mod_pow with a negative
+  // exponent: inverse or panic, not recalled with confidence): Result::unsupported.
   Result verify(const DLogStatement& st) const {
     Engine& e = Engine::instance();
+    if (st.N.is_negative() || st.N <= BigInt::pow2(128)) throw Panic("assertion failed: statement.N > BigInt::from(2).pow(K as u32)");   // :69
+    if (!st.N.is_odd() || st.N.bit_length() > 4096) return Result::unsupported("CompositeDLogProof::verify: the modulus is even or wider than 4096 bits");
     const uint32_t nb = width_for(st.N), kw = nb / 32;
+    const bool canonical = !st.g.is_negative() && st.g < st.N && !st.ni.is_negative() && st.ni < st.N && x.fits_limbs(kw) && y.fits_limbs(Y_BITS / 32);
+    if (!canonical) {
+      if (y.is_negative()) return Result::unsupported("CompositeDLogProof::verify: negative response y");
+      if (BigInt::gcd(st.g, st.N) != BigInt::one() || BigInt::gcd(st.ni, st.N) != BigInt::one())
+        throw Panic("assertion failed: `(left == right)` gcd(g, N) / gcd(ni, N)");                                      // :72-73
+      const BigInt ee = detail::compute_digest({&x, &st.g, &st.N, &st.ni});                                               // :75-80
+      const BigInt ni_e = mod_pow(st.ni, ee, st.N), g_y = mod_pow_wide(st.g, y, st.N);                                    // :81-82
+      return Result(x == (g_y * ni_e).modulus(st.N));                                                                     // :83-90
+    }
     std::vector<uint32_t> N(kw), g(kw), ni(kw), xx(kw), yy(Y_BITS / 32);
     st.N.to_limbs(N.data(), kw); st.g.to_limbs(g.data(), kw); st.ni.to_limbs(ni.data(), kw); x.to_limbs(xx.data(), kw); y.to_limbs(yy.data(), Y_BITS / 32);
     uint8_t v = 9;
