@@ -119,6 +119,18 @@ def executed_lane_mads_per_enc(n: int, n_bits: int, verify: bool):
     return L29 * (L29 // 36) * (54.5 * sq + 72.0 * (mul + (9 if verify else 5)))      # L sub-steps x L/36 lanes x multiply-adds per lane per sub-step
 
 
+def executed_lane_mads_per_enc_basen(n: int, n_bits: int):
+    """lane multiply-adds k_enc_basen EXECUTES for one Enc (csrc/kernels_basen.hpp; 29-bit limbs, Lh = 72 / 144 limbs per n-sized integer):
+    a squaring = the a side at 54.5 + the b side at 72 multiply-adds per lane per sub-step, any other base-n product = three n-sized
+    products at 72; Lh more per b side for its initial columns.  Products besides the script: to the Montgomery domain (2 n-sized), the
+    final one by (1, m) (3).  The canonicalisation (k_basen_finish: ~5 n-sized products per Enc) and the Mask rows' k_expected run in
+    kernels of their own inside the same timed region; they are not counted here."""
+    Lh = 72 if n_bits <= 2048 else 144
+    per_product = Lh * (Lh // 36) * 72.0                      # one n-sized product: Lh sub-steps x Lh/36 lanes x 72
+    sq, mul = sliding_ladder_products(n)
+    return sq * (Lh * (Lh // 36) * 54.5 + per_product + Lh) + mul * (3 * per_product + Lh) + 5 * per_product + 2 * Lh
+
+
 HBM_PEAK_GBS = 8000.0
 
 
@@ -126,6 +138,16 @@ def enc_limb_macs(n_bits):
     """algorithmic 32x32->64 limb-MACs of one Enc: 1.2*n_bits modmuls x (2L^2+L), L = 2*n_bits/32"""
     Lw = 2 * n_bits // 32
     return 1.2 * n_bits * (2 * Lw * Lw + Lw)
+
+
+def enc_limb_macs_basen(n_bits):
+    """algorithmic 32x32->64 limb-MACs of one Enc IN BASE-n FORM (csrc/kernels_basen.hpp: x = a + b n, so that a product modulo n^2 is
+    three and a squaring two modular products of n-SIZED operands), priced like SURVEY 8(d) prices the n^2-sized ladder: 1.2 n_bits
+    products of which n_bits are squarings, every n-sized modular product at 2 Lh^2 + Lh, Lh = n_bits / 32.  n = 2048: 4.40e7 against the
+    8.09e7 of enc_limb_macs — the form does 0.54 of the limb products of the schoolbook model, which is why a line of this bench that
+    runs it is NOT priced by enc_limb_macs any more (its fraction of the multiply-add peak would read 1.3)."""
+    Lh = n_bits // 32
+    return n_bits * (2 + 0.2 * 3) * (2 * Lh * Lh + Lh)
 
 
 def modexp_limb_macs(mod_bits, exp_bits):
@@ -479,8 +501,9 @@ def main():
             out.append((max_over_ranks(dt), kms, launches, me))
         return out
 
-    def enc_roofline(kms, launches, modexps, nb, kernel, clock=None, executed_per_enc=None):
-        ach = modexps * enc_limb_macs(nb) / (kms * 1e-3) if kms else 0.0
+    def enc_roofline(kms, launches, modexps, nb, kernel, clock=None, executed_per_enc=None, basen=False):
+        units = enc_limb_macs_basen(nb) if basen else enc_limb_macs(nb)
+        ach = modexps * units / (kms * 1e-3) if kms else 0.0
         per, src = pmc_traffic_per_modexp(kernel.split(" (")[0])            # the kernel's name as rocprofv3 prints it
         rec, _ = pmc_record(kernel.split(" (")[0])
         per_launch = modexps / max(launches, 1)
@@ -497,6 +520,12 @@ def main():
                     "hbm": {"achieved": modexps * bytes_per_enc / (kms * 1e-3) / 1e9 if kms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}})
         if executed_per_enc:
             out["executed_lane_mads_per_enc"] = executed_per_enc
+        out["work_model"] = {"form": "base-n (x = a + b n: 3 / 2 n-sized modular products per product / squaring modulo n^2)" if basen else "n^2-sized products (SURVEY 8(d))",
+                             "algorithmic_limb_macs_per_enc": units, "survey_8d_limb_macs_per_enc": enc_limb_macs(nb),
+                             "achieved_by_the_survey_8d_model_tlimb_mac_per_s": modexps * enc_limb_macs(nb) / (kms * 1e-3) / 1e12 if kms else None,
+                             "note": ("`achieved` and `frac` count the limb products the ALGORITHM THAT RAN needs (enc_limb_macs_basen: 0.54 of SURVEY 8(d)'s schoolbook "
+                                      "figure), so that frac stays a fraction of the multiply-add ceiling; the schoolbook figure over the same time is the form's speed-up, "
+                                      "not a fraction of anything") if basen else "SURVEY 8(d): 1.2 n_bits modular products of 2 L^2 + L limb-MACs, L = 2 n_bits / 32"}
         if not clock and "effective_clock_ghz" in der:
             out["clock_ghz"] = der["effective_clock_ghz"]
             out["clock_note"] = "GRBM_GUI_ACTIVE / wall time of the PMC pass of this kernel (profiles/aggregate_pmc.py)"
@@ -527,8 +556,7 @@ def main():
         prove = {"value": B_total * args.steps / dt, "unit": "proofs/s", "ms_per_step": 1e3 * dt / args.steps, "clock": clk_p.summary(),
                  "gather": args.gather, "gather_recv_bytes_per_rank_per_step": recv_bytes["prove"],
                  "enc_kernel_ms_per_launch": kms / max(launches, 1), "launches": launches,
-                 "achieved_limb_mac_per_s": modexps * enc_limb_macs(n_bits) / (kms * 1e-3) if kms else None,
-                 "frac": modexps * enc_limb_macs(n_bits) / (kms * 1e-3) / PEAK_LIMB_MAC_PER_S if kms else None}
+                 "achieved_limb_mac_per_s": None, "frac": None, "_kms": kms, "_modexps": modexps}
     # tamper every 64th proof (one bit of resp_r1 in row 0): those must be rejected, all others accepted
     tampered = torch.arange(0, B, 64, device=dev)
     pb.resp_r1[tampered, 0, 0] ^= 1
@@ -547,7 +575,20 @@ def main():
         ok = ok and bool(torch.equal(gathered["c1"][my_lo:my_lo + B], pb.c1))
     ok = ok and (("c1" in gathered) == (args.gather == "all" and not args.no_prove_leg))
     value = B_total * args.steps / dt
-    roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc<{144 // lpl}, true> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer; sliding-window ladder, squarings at 3/4 of a product)", clk.summary(), executed_lane_mads_per_enc(n, n_bits, True))
+    bn_lanes, bn_ok = ctx.diag_basen_last()
+    basen = bool(bn_lanes and bn_ok)
+    if prove:
+        pk, pm = prove.pop("_kms"), prove.pop("_modexps")
+        units = enc_limb_macs_basen(n_bits) if basen else enc_limb_macs(n_bits)
+        prove["achieved_limb_mac_per_s"] = pm * units / (pk * 1e-3) if pk else None
+        prove["frac"] = pm * units / (pk * 1e-3) / PEAK_LIMB_MAC_PER_S if pk else None
+        prove["work_model"] = "base-n" if basen else "n^2-sized products (SURVEY 8(d))"
+    if basen:
+        roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc_basen<{bn_lanes}> (Enc in base-n form: {bn_lanes} lanes x 36 limbs per 2048-bit half, {64 // bn_lanes} Enc per wavefront; sliding-window ladder; "
+                                "canonicalisation + comparison in k_basen_finish, Mask-row products in k_expected, inside the same timed region)", clk.summary(),
+                                executed_lane_mads_per_enc_basen(n, n_bits), basen=True)
+    else:
+        roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc<{144 // lpl}, true> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer; sliding-window ladder, squarings at 3/4 of a product)", clk.summary(), executed_lane_mads_per_enc(n, n_bits, True))
     ms_per_step = 1e3 * dt / args.steps
     gathered.clear()
 
@@ -808,11 +849,16 @@ def other_configs(env):
         kp, mp = min(r[1] for r in rp), rp[0][3]
         iv = min(range(len(rv)), key=lambda i: rv[i][1])
         sp, sv = rep_stats(total, rp, "proofs"), rep_stats(total, rv, "verifies")
+        bnl, bnok = ctx.diag_basen_last()
+        bn = bool(bnl and bnok) and isinstance(nkey, int)        # (shared-key legs only; per-proof keys stay on the n^2-sized kernels)
+        if bn:
+            kernel = f"k_enc_basen<{bnl}> (Enc in base-n form, {64 // bnl} Enc per wavefront; + k_basen_finish, k_expected)"
+        units = enc_limb_macs_basen(nb) if bn else enc_limb_macs(nb)
         rec = {"n_gpus": world, "batch_total": total, "batch_per_rank": Bx, "proofs_per_s": sp["proofs_per_s"], "proofs_per_s_median": sp["proofs_per_s_median"],
                "verifies_per_s": sv["verifies_per_s"], "verifies_per_s_median": sv["verifies_per_s_median"],
                "prove_ms": sp["ms_min"], "prove_ms_all": sp["ms_all"], "verify_ms": sv["ms_min"], "verify_ms_all": sv["ms_all"], "reps": sp["reps"],
-               "verdicts_ok": good, "prove_frac": mp * enc_limb_macs(nb) / (kp * 1e-3) / PEAK_LIMB_MAC_PER_S if kp else None,
-               "roofline": enc_roofline(rv[iv][1], rv[iv][2], rv[iv][3], nb, kernel, clkv.summary()),
+               "verdicts_ok": good, "prove_frac": mp * units / (kp * 1e-3) / PEAK_LIMB_MAC_PER_S if kp else None,
+               "roofline": enc_roofline(rv[iv][1], rv[iv][2], rv[iv][3], nb, kernel, clkv.summary(), basen=bn),
                "gpu": gpu_identity(env["local_rank"], rank), "clock_prove": clkx.summary(),
                "gather": args.gather, "gather_recv_bytes_per_rank": recv_x,
                "parallelism": f"proof-index blocks x{world} + all-gather of " + ("c1/c2 (prove) and " if args.gather == "all" else "") + "verdict bytes (verify)"}

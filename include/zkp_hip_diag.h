@@ -20,6 +20,17 @@ extern "C" {
  * counters behind the roofline's `traffic` figure can be calibrated (profiles/collect_pmc.sh).  out_bytes = bytes moved. */
 int32_t zkp_diag_table_traffic(zkp_ctx* ctx, int32_t mode, int32_t passes, uint64_t* out_bytes);
 
+/* One operation of the BASE-n form of Paillier's arithmetic modulo n^2 (csrc/kernels_basen.hpp) on raw 29-bit limbs, for the tests that pin
+ * the kernels' building blocks to tests/basen_model.py.  n_bits = 2048 | 4096, L = 72 | 144 limbs per operand half.
+ *   op 0: (xa, 0) -> Montgomery form        op 1: (xa, xb) * (ya, yb) / R'        op 2: (xa, xb)^2 / R'      -> out[0, L) = a, out[L, 2L) = b
+ *   op 3: the key's constants               -> out = C3 | RRa | RRb | M~ (L limbs each) | n1 | ok */
+int32_t zkp_diag_basen(zkp_ctx* ctx, uint32_t n_bits, const uint32_t* n, int32_t op, const uint32_t* xa, const uint32_t* xb, const uint32_t* ya,
+                       const uint32_t* yb, uint32_t* out);
+
+/* Did the most recent shared-key Paillier launch of this ctx run in base-n form?  out_lanes: lanes per n-sized integer of that launch
+ * (0: there was none), out_qualified: 1 when the key passed the form's set-up (else the n^2-sized kernel did the work). */
+int32_t zkp_diag_basen_last(zkp_ctx* ctx, int32_t* out_lanes, uint32_t* out_qualified);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,7 @@ def hot_blocks(text, kernel):
                     reason="no device assembly beside the built library (run __graft_entry__.build())")
 def test_product_loops_of_the_ladders_are_free_of_scratch_accesses():
     text = open(ISA).read()
-    for extra in ("isa_keys_enc.s", "isa_keys_ck.s"):          # the translation units of the per-item-exponent kernels (zkp_kernels_keys.hip)
+    for extra in ("isa_keys_enc.s", "isa_keys_ck.s", "isa_basen.s"):   # the per-item-exponent kernels (zkp_kernels_keys.hip), the base-n kernels (zkp_kernels_basen.hip)
         text += open(os.path.join(os.path.dirname(ISA), extra)).read()
     # (kernel, most scratch accesses tolerated in the squaring block, ... in the ladder's product block)
     for kernel, sq_max, mul_max in (("k_enc<4, true, false>", 0, 2), ("k_enc<4, false, false>", 0, 0), ("k_ck_check<2, false>", 0, 0),
@@ -45,3 +45,13 @@ def test_product_loops_of_the_ladders_are_free_of_scratch_accesses():
         assert sq and mul, (kernel, blocks)                      # 54.5 and 72 multiply-adds x 36 sub-steps: the montsqr / montmul<ORUP> blocks
         assert min(sq) <= sq_max, (kernel, "squaring block", sq)
         assert min(mul) <= mul_max, (kernel, "product block", mul)
+    # The base-n kernels (kernels_basen.hpp): the a side of a squaring (1962 multiply-adds per block + the 36 of the b side's initial columns,
+    # which the compiler places in the same block) and TWO copies of the n-sized product body — the b side of the squarings on their own
+    # path, and the three slots of every other base-n product.  The first builds of that file carried quotient digits and pending results
+    # through these bodies in registers: 35 - 450 scratch accesses per block and 3.0 s instead of 1.2 s per verify step.
+    for kernel in ("k_enc_basen<2>", "k_enc_basen<4>"):
+        blocks = hot_blocks(text, kernel)
+        sq = [s for m, s in blocks if 1962 <= m <= 1998]
+        mul = [s for m, s in blocks if m == 2592]
+        assert len(sq) == 1 and len(mul) == 2, (kernel, blocks)      # more bodies than these cost instruction-cache room and registers
+        assert sq[0] <= 2 and max(mul) <= 2, (kernel, blocks)

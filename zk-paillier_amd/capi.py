@@ -42,6 +42,8 @@ class RangeNiWitness(C.Structure):
 # include/zkp_hip_diag.h: measurement tooling, not the boundary
 DIAG_EXPORTS = {
     "zkp_diag_table_traffic": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
+    "zkp_diag_basen": (C.c_int32, [C.c_void_p, C.c_uint32] + [C.c_void_p, C.c_int32] + [C.c_void_p] * 5),
+    "zkp_diag_basen_last": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
 }
 
 # include/zkp_hip.h: the boundary
@@ -295,6 +297,24 @@ class Context:
         n = C.c_uint64()
         self.check(self.lib.zkp_diag_table_traffic(self.h, mode, passes, C.byref(n)))
         return n.value
+
+    def diag_basen_last(self):
+        """(lanes per n-sized integer of the most recent base-n launch or 0, whether its key qualified for the form)"""
+        lanes, ok = C.c_int32(), C.c_uint32()
+        self.check(self.lib.zkp_diag_basen_last(self.h, C.byref(lanes), C.byref(ok)))
+        return lanes.value, bool(ok.value)
+
+    def diag_basen(self, n_bits: int, n_words, op: int, xa=None, xb=None, ya=None, yb=None):
+        """one base-n operation on raw 29-bit limbs (include/zkp_hip_diag.h) -> uint32 array of 4 L + 4 words"""
+        import numpy as np
+        L = 72 * (n_bits // 2048)
+        z = np.zeros(L, np.uint32)
+        arrs = [np.ascontiguousarray(z if v is None else v, dtype=np.uint32) for v in (xa, xb, ya, yb)]
+        assert all(a.shape == (L,) for a in arrs)
+        n_words = np.ascontiguousarray(n_words, dtype=np.uint32)
+        out = np.zeros(4 * L + 4, np.uint32)
+        self.check(self.lib.zkp_diag_basen(self.h, n_bits, n_words.ctypes.data, op, *[a.ctypes.data for a in arrs], out.ctypes.data))
+        return out
 
     # ---- L1 primitives (buffers: numpy arrays = host pointers, torch cuda tensors = device pointers)
     @staticmethod

@@ -19,6 +19,9 @@
 #include "kernels_proofs.hpp"
 #include "kernels_inv.hpp"
 #include "kernels_serde.hpp"
+#if ZKP_W == 36
+#include "kernels_basen.hpp"          // the shared-key Paillier kernels in base-n form (throughput engine only)
+#endif
 
 using namespace zkp;
 
@@ -50,6 +53,8 @@ struct zkp_ctx {
   bool side_busy = false;        // work forked onto `side` whose join has not been enqueued on `stream` yet (see ~Stage)
   std::string err;
   DevBuf consts, consts2, table, scratch[48];
+  DevBuf bn_ncst, bn_consts, bn_table, bn_expected, bn_raw;
+  int bn_last_g = 0;                   // lanes per n-sized integer of the most recent base-n launch (0: none yet)   // base-n form (kernels_basen.hpp): set-up record of n, its base-n constants, window tables, Mask-row products
   // timing of the dominant kernels
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -382,8 +387,79 @@ template <int G> static bool pair_ladder(const zkp_ctx* c, uint64_t items) {
 // The latency engine has a third: the right-to-left ladder on pairs of groups (kernels_modexp.hpp: powm_pair), taken while a
 // launch with twice the lanes per item still leaves every SIMD at most one wavefront — the call is then a single chain of
 // products per item, and that chain is 14 % shorter.
+#if ZKP_W == 36
+#ifdef ZKP_SPLIT_TU
+// compiled in zkp_kernels_basen.hip
+extern template __global__ void zkp::k_enc_basen<2>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_enc_basen<4>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_basen_finish<2>(EncArgs, const uint32_t*, const uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_basen_finish<4>(EncArgs, const uint32_t*, const uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_setup_basen<2>(const uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_setup_basen<4>(const uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_expected<4>(EncArgs, uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_expected<8>(EncArgs, uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_diag_basen<2>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_diag_basen<4>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+#endif
+constexpr size_t BASEN_SETUP_LDS = 4096;
+// ZKP_BASEN=0: every Paillier launch stays on the n^2-sized kernels (A/B runs, and the parity tests that pin the two forms against each other)
+static bool basen_enabled() {
+  const char* e = std::getenv("ZKP_BASEN");
+  return !(e && e[0] == '0');
+}
+// base-n constants of ONE key (G lanes per n-sized integer): k_setup<G> on n, then k_setup_basen<G>.  Everything stays on the stream;
+// whether the key qualifies (odd, long enough, digit sums of M~ within the fast-product bound) is a device word the kernels read.
+template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uint32_t n_bits) {
+  int32_t st = run_setup<G>(c, n, 0, (int)(n_bits / 32), 0, 1, c->bn_ncst);
+  if (st) return st;
+  if ((st = ensure(c, c->bn_consts, (size_t)(BnConst<G>::WORDS + 2 * Geo<G>::L) * sizeof(uint32_t)))) return st;
+  hipLaunchKernelGGL(k_setup_basen<G>, dim3(1), dim3(64), BASEN_SETUP_LDS, c->stream, (const uint32_t*)c->bn_ncst.p, (uint32_t*)c->bn_consts.p);
+  HIPCHK(c, hipGetLastError());
+  return ZKP_OK;
+}
+// The base-n launch of a shared-key Enc call (GS: lanes per n^2-sized integer of the k_enc launch it stands in for).  It claims work from
+// the SAME counter as the k_enc launch that follows it: when the key qualifies it leaves nothing to claim, when it does not it returns at
+// once and k_enc runs as before.  Returns false when nothing was launched.
+template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
+  if constexpr (GS != 4 && GS != 8) { (void)c; (void)a; return false; }
+  else {
+    constexpr int G = GS / 2;
+    using BL = BnLds<G>;
+    const int kw = a.n_bits / 32;
+    if (!basen_enabled() || !a.sched || a.n_stride != 0 || a.n_bits != 1024 * G) return false;
+    if (a.mode == 0 && ((a.m_words > kw) || (a.r_words > kw))) return false;
+    if (basen_prepare<G>(c, a.n, (uint32_t)a.n_bits)) return false;
+    static int per_cu = 0;
+    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_basen<G>, 256, BL::BYTES_PER_BLOCK) != hipSuccess || per_cu < 1)) per_cu = 1;
+    const uint64_t need = (a.count + BL::GROUPS_PER_BLOCK - 1) / BL::GROUPS_PER_BLOCK;
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)per_cu * c->cus));
+    if (ensure(c, c->bn_table, (size_t)blocks * BL::GROUPS_PER_BLOCK * BN_TAB_ENTRIES * 2 * Geo<G>::L * sizeof(uint32_t))) return false;
+    if (ensure(c, c->bn_raw, (size_t)a.count * 2 * Geo<G>::L * sizeof(uint32_t))) return false;
+    const uint32_t* ok = (const uint32_t*)c->bn_consts.p + BnConst<G>::OFF_OK;
+    const bool products = a.mode == 1 || (a.mode == 2 && a.cipher_x);
+    if (products) {
+      if (ensure(c, c->bn_expected, (size_t)a.count * 2 * kw * sizeof(uint32_t))) return false;
+      using LS = LdsLayout<GS>;
+      const uint64_t eneed = (a.count + LS::GROUPS_PER_BLOCK - 1) / LS::GROUPS_PER_BLOCK;
+      const unsigned eblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(eneed, 2ull * c->cus));
+      hipLaunchKernelGGL(k_expected<GS>, dim3(eblocks), dim3(256), LS::BYTES_PER_BLOCK, c->stream, a, (uint32_t*)c->bn_expected.p, ok);
+    }
+    c->bn_last_g = G;
+    hipLaunchKernelGGL(k_enc_basen<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_table.p,
+                       (uint32_t*)c->bn_raw.p);
+    const unsigned fblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, 8ull * c->cus));
+    hipLaunchKernelGGL(k_basen_finish<G>, dim3(fblocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (const uint32_t*)c->bn_raw.p,
+                       (const uint32_t*)c->bn_expected.p);
+    return true;
+  }
+}
+#endif
+
 template <int G> static void launch_k_enc(zkp_ctx* c, unsigned blocks, const EncArgs& a) {
   using LL = LdsLayout<G>;
+#if ZKP_W == 36
+  (void)launch_basen<G>(c, a);
+#endif
   if constexpr (PAIR_LADDER_BUILD && 2 * G <= 64) {
     if (pair_ladder<G>(c, a.count)) {                     // (a.count: an upper bound when the count is device resident, verify work list)
       const unsigned pair_blocks = (unsigned)std::max<uint64_t>(1, (a.count + LL::GROUPS_PER_BLOCK / 2 - 1) / (LL::GROUPS_PER_BLOCK / 2));
@@ -455,7 +531,7 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->lat_ctx) (void)c->lat->p_zkp_ctx_destroy(c->lat_ctx);
-  for (DevBuf* b : {&c->consts, &c->consts2, &c->table}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->consts, &c->consts2, &c->table, &c->bn_ncst, &c->bn_consts, &c->bn_table, &c->bn_expected, &c->bn_raw}) if (b->p) (void)hipFree(b->p);
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
@@ -508,6 +584,54 @@ extern "C" int32_t zkp_diag_table_traffic(zkp_ctx* c, int32_t mode, int32_t pass
   if (out_bytes) *out_bytes = (uint64_t)blocks * (256 / G) * TABS * Geo<G>::L * sizeof(uint32_t) * (uint64_t)passes;
   return ZKP_OK;
 } ZKP_CATCH(c)
+
+#if ZKP_W == 36
+// diagnostic: one base-n operation on raw limbs (kernels_basen.hpp: k_diag_basen); tests/test_gpu_basen.py checks it against tests/basen_model.py
+extern "C" int32_t zkp_diag_basen(zkp_ctx* c, uint32_t n_bits, const uint32_t* n, int32_t op, const uint32_t* xa, const uint32_t* xb, const uint32_t* ya,
+                                  const uint32_t* yb, uint32_t* out) try {
+  if (!c || !n || !out || (n_bits != 2048 && n_bits != 4096) || op < 0 || op > 3) return ZKP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int G = n_bits == 2048 ? 2 : 4;
+  const size_t L = (size_t)G * W, kw = n_bits / 32;
+  Stage s(c, 0);
+  const uint32_t* dn = s.in(n, kw);
+  const uint32_t* dxa = s.in(xa, L); const uint32_t* dxb = s.in(xb, L); const uint32_t* dya = s.in(ya, L); const uint32_t* dyb = s.in(yb, L);
+  uint32_t* dout = s.out(out, 4 * L + 4);
+  uint32_t* dscr = (uint32_t*)s.take(2 * L * sizeof(uint32_t));
+  int32_t st = s.st;
+  if (!st) st = G == 2 ? basen_prepare<2>(c, dn, n_bits) : basen_prepare<4>(c, dn, n_bits);
+  if (!st) {
+    if (G == 2) hipLaunchKernelGGL(k_diag_basen<2>, dim3(1), dim3(64), BASEN_SETUP_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
+    else hipLaunchKernelGGL(k_diag_basen<4>, dim3(1), dim3(64), BASEN_SETUP_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
+    if (hipGetLastError() != hipSuccess) st = ZKP_EDEVICE;
+  }
+  const int32_t fin = s.finish();
+  return st ? st : fin;
+} ZKP_CATCH(c)
+// diagnostic: did the most recent shared-key Paillier launch of this ctx run in base-n form?  out_lanes: lanes per n-sized integer of that
+// launch (0: there was none), out_qualified: the key passed k_setup_basen (else the n^2-sized kernel did the work)
+extern "C" int32_t zkp_diag_basen_last(zkp_ctx* c, int32_t* out_lanes, uint32_t* out_qualified) try {
+  if (!c || !out_lanes || !out_qualified) return ZKP_EINVAL;
+  *out_lanes = c->bn_last_g; *out_qualified = 0;
+  if (!c->bn_last_g) return ZKP_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t off = (c->bn_last_g == 2 ? BnConst<2>::OFF_OK : BnConst<4>::OFF_OK) * sizeof(uint32_t);
+  HIPCHK(c, hipMemcpyAsync(c->setup_flag_host + 8, (const char*)c->bn_consts.p + off, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out_qualified = c->setup_flag_host[8];
+  return ZKP_OK;
+} ZKP_CATCH(c)
+#else
+extern "C" int32_t zkp_diag_basen_last(zkp_ctx* c, int32_t* out_lanes, uint32_t* out_qualified) {
+  if (!c || !out_lanes || !out_qualified) return ZKP_EINVAL;
+  *out_lanes = 0; *out_qualified = 0;
+  return ZKP_OK;
+}
+extern "C" int32_t zkp_diag_basen(zkp_ctx* c, uint32_t, const uint32_t*, int32_t, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*) {
+  if (c) c->err = "zkp_diag_basen: the base-n kernels are built into the throughput engine only";
+  return ZKP_EINVAL;
+}
+#endif
 
 extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) try {
   if (!c) return ZKP_EINVAL;
