@@ -95,6 +95,7 @@ def test_enc_batch_equals_python_and_the_n2_sized_kernels(ctx, n_bits):
     rs = [rnd.getrandbits(n_bits) for _ in range(count)]        # r >= n included: (r + k n)^n == r^n (mod n^2)
     ms[0], rs[0] = 0, 1
     ms[1], rs[1] = n - 1, n - 1
+    ms[2], rs[2] = (1 << n_bits) - 1, (1 << n_bits) - 1          # both above n: only m mod n and r mod n matter
     nw = words(n, kw)
     mw = np.stack([words(v, kw) for v in ms])
     rw = np.stack([words(v, kw) for v in rs])

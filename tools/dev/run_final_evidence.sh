@@ -14,11 +14,11 @@ import csv, glob, json
 rows = []
 for f in glob.glob("gpurun_out/prof_${ROUND}_$TAG/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_enc<4, true" in r.get("Kernel_Name", ""):
+        if "k_enc_basen<2>" in r.get("Kernel_Name", ""):
             rows.append(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 3))
-json.dump({"kernel": "k_enc<4, true, false>", "launch_ms_in_dispatch_order": rows,
-           "note": "rocprofv3 --kernel-trace of the default bench run: the ~1.86 s launches are the timed verify steps (roofline.kernel_ms_per_launch), the ~2.5 s ones the merged c1 + c2 launch of a prove step, the short ones warm-ups / small legs"},
-          open("gpurun_out/${ROUND}_kernel_trace_k_enc4_true_launches_$TAG.json", "w"), indent=1)
+json.dump({"kernel": "k_enc_basen<2>", "launch_ms_in_dispatch_order": rows,
+           "note": "rocprofv3 --kernel-trace of the default bench run: the ~1.2 s launches are the timed verify steps (roofline.kernel_ms_per_launch also holds the ~2 ms of k_expected and k_basen_finish beside them), the ~1.6 s ones the merged c1 + c2 launch of a prove step, the short ones warm-ups / small legs"},
+          open("gpurun_out/${ROUND}_kernel_trace_k_enc_basen2_launches_$TAG.json", "w"), indent=1)
 PY
 find gpurun_out/prof_${ROUND}_$TAG -name "*kernel_trace.csv" -delete
 ROUND=$ROUND bash profiles/collect_all.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1

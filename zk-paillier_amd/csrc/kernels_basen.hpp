@@ -93,14 +93,13 @@ template <int G> __device__ __forceinline__ void bn_stage(const Bn<G>& g, uint32
 
 // ---- where the quotient digits of an a side wait for the b side: IN PLACE of the limbs of the staged operand the product has already
 // consumed.  Sub-step (s, t) reads limb s W + t of the staged operand for the last time; its quotient digit takes that word.  Lane 0 of
-// the group writes four digits at a time (one ds_write_b128 per ds_read_b128 of the operand, under an execution mask that is constant
-// for the whole product; writes of all lanes — the others to a dummy unit — cost 1.4 bank-conflict cycles per LDS cycle).  No register
-// holds a digit beyond its four sub-steps: the a side of a squaring stays at the register footprint of bigint29.hpp's montsqr.  (36 registers of digits carried through the product
-// bodies cost them 450 scratch accesses per block in the first build of this file.)
+// the group writes four digits at a time, one ds_write_b128 per ds_read_b128 of the operand.  No register holds a digit beyond its four
+// sub-steps, so the a side of a squaring keeps the register footprint of bigint29.hpp's montsqr — the first build of this file carried
+// the 36 digits of a lane through the product bodies in registers and paid 450 scratch accesses per block for it.
 // The write is ONE instruction under an execution mask that only lane 0 of every group survives, set and restored around it in a
-// single asm statement: written as an `if`, the compiler turns the 18 writes of a product body into s_and_saveexec regions that cost the
-// body 100 - 300 scratch accesses; written for all lanes (the others to a dummy unit), the writes collide in the LDS banks (1.4 - 1.7
-// conflict cycles per LDS cycle, 4.9 instead of 4.0 SIMD-cycles per VALU instruction).  `qmask`: the lanes that write (0 = none).
+// single asm statement.  Written as an `if`, the compiler turns the 18 writes of a product body into s_and_saveexec regions and the body
+// takes 100 - 300 scratch accesses; written for all lanes (the others to a dummy unit) the address needs a multiply-add per write.
+// `qmask`: the lanes that write (0: a product that keeps no digits).  Measured steps: profiles/r04/basen/README.md.
 template <int G> __device__ __forceinline__ uint64_t q_write_mask(bool capture) {
   const uint64_t lanes0 = G == 2 ? 0x5555555555555555ull : G == 4 ? 0x1111111111111111ull : G == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
   return capture ? lanes0 : 0ull;
@@ -117,7 +116,7 @@ __device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) { return
     if (((t) & 3) == 3) q_write((qmask), (row_addr) + ((t) - 3) * 4, qd);                                               \
   } while (0)
 
-// ---- the a side of a squaring: R = X * X / R' on M~ (bigint29.hpp montsqr, out of place), quotient digits into ldsB (see QSink)
+// ---- the a side of a squaring: R = X * X / R' on M~ (bigint29.hpp montsqr, out of place), quotient digits into ldsB (see above)
 template <int G>
 __device__ __forceinline__ void bn_sqr_a(uint32_t (&R)[W], const uint32_t (&X)[W], uint32_t* ldsB, const uint32_t (&N)[W], const Bn<G>& g) {
   constexpr int H = W / 2;
