@@ -128,18 +128,11 @@ def test_lane_level_b_side_takes_the_a_sides_digits(bits, G):
 def test_column_bound_with_the_initial_value():
     """worst-case operands (every limb at its maximum, plus the slack of almost-normalised operands) and a modulus operand exactly at
     COL_FAST_SN_LIMIT_BN: no column exceeds 64 bits although every column of the b side starts at up to 2^58 + 2^29"""
-    G = 2
     lim = sn_limit_basen()
     assert lim < fast_sn_limit(W) and 26 * (1 << LB) < lim < 28 * (1 << LB)
-    big = [MASK] * (G * W)
-    for j in range(G):
-        big[j * W] = MASK + 17
     full = lim // MASK
     lane = [MASK] * full + [lim - full * MASK] + [0] * (W - full - 1)
     assert sum(lane) == lim
-    stats = {"maxcol": 0}
-    init = [(1 << LB) + (1 << (2 * LB))] * (G * W)
-    c = [[init[j * W + k] for k in range(W)] for j in range(G)]
-    # (the model asserts lane 0's bottom limb is zero after the digit, which needs N == -1 mod 2^29: run the bound by hand instead)
+    # the analytic bound of bigint29.hpp "column capacity" with the b side's initial column value (< 2^58 + 2^29) added:
     assert ((1 << LB) + 16) * (W * (1 << LB) + 16) + MASK * lim + (1 << 36) + (1 << (2 * LB)) + (1 << LB) < (1 << 64)
     assert ((1 << LB) + 16) * (W * (1 << LB) + 16) + MASK * (lim + (1 << LB)) + (1 << 36) + (1 << (2 * LB)) + (1 << LB) >= (1 << 64) - (1 << 59)
