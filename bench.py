@@ -850,9 +850,10 @@ def other_configs(env):
         iv = min(range(len(rv)), key=lambda i: rv[i][1])
         sp, sv = rep_stats(total, rp, "proofs"), rep_stats(total, rv, "verifies")
         bnl, bnok = ctx.diag_basen_last()
-        bn = bool(bnl and bnok) and isinstance(nkey, int)        # (shared-key legs only; per-proof keys stay on the n^2-sized kernels)
+        bn = bool(bnl and bnok)
         if bn:
-            kernel = f"k_enc_basen<{bnl}> (Enc in base-n form, {64 // bnl} Enc per wavefront; + k_basen_finish, k_expected)"
+            kernel = (f"k_enc_basen<{bnl}> (Enc in base-n form, {64 // bnl} Enc per wavefront; + k_basen_finish, k_expected)" if isinstance(nkey, int) else
+                      f"k_enc_basen_keys<{bnl}> (Enc in base-n form under per-proof keys: fixed 6-bit windows over the item's n, {64 // bnl} Enc per wavefront; + k_basen_finish, k_expected)")
         units = enc_limb_macs_basen(nb) if bn else enc_limb_macs(nb)
         rec = {"n_gpus": world, "batch_total": total, "batch_per_rank": Bx, "proofs_per_s": sp["proofs_per_s"], "proofs_per_s_median": sp["proofs_per_s_median"],
                "verifies_per_s": sv["verifies_per_s"], "verifies_per_s_median": sv["verifies_per_s_median"],

@@ -126,3 +126,42 @@ def test_enc_batch_equals_python_and_the_n2_sized_kernels(ctx, n_bits):
     ctx.paillier_enc_check(n_bits, count, nw, 0, mw, rw, aw, bw, None, ok)
     assert list(ok) == [0 if i == 5 else 1 for i in range(count)]
     ctx.set_geometry(0)
+
+
+@pytest.mark.parametrize("n_bits", [2048, 4096])
+def test_enc_batch_with_per_item_keys_equals_python(ctx, n_bits):
+    """n_stride != 0: every item under its own key (fixed-window ladder over the item's n, constants per key, C3 from global memory)"""
+    rnd = random.Random(n_bits + 2)
+    kw = n_bits // 32
+    count = 40 if n_bits == 2048 else 20
+    ns = [odd_modulus(rnd, n_bits - (i % 3 == 2)) for i in range(count)]       # some keys one bit short of the field
+    ms = [rnd.randrange(n) for n in ns]
+    rs = [rnd.getrandbits(n_bits) for _ in range(count)]
+    ms[0], rs[0] = 0, 1
+    nw = np.stack([words(v, kw) for v in ns])
+    mw = np.stack([words(v, kw) for v in ms])
+    rw = np.stack([words(v, kw) for v in rs])
+    out = np.zeros((count, 2 * kw), np.uint32)
+    ctx.set_geometry(zkp.load().zkp_build_limbs_per_lane())
+    ctx.paillier_enc(n_bits, count, nw, kw, mw, rw, out)
+    lanes, ok = ctx.diag_basen_last()
+    assert lanes == n_bits // 1024 and ok, "the per-key launch should have run in base-n form"
+    for i in range(count):
+        n = ns[i]
+        got = sum(int(w) << (32 * j) for j, w in enumerate(out[i]))
+        assert got == (1 + ms[i] * n) * pow(rs[i], n, n * n) % (n * n), i
+    # one key that does not qualify (even) sends the WHOLE launch to the n^2-sized kernels: same answers for the others, zeros for it
+    ns2 = list(ns)
+    ns2[3] -= 1
+    nw2 = np.stack([words(v, kw) for v in ns2])
+    out2 = np.zeros((count, 2 * kw), np.uint32)
+    try:
+        ctx.paillier_enc(n_bits, count, nw2, kw, mw, rw, out2)
+    except zkp.ZkpError:
+        pass                                                   # (the entry point reports the even modulus; the outputs of the others are written)
+    lanes, ok = ctx.diag_basen_last()
+    assert lanes == n_bits // 1024 and not ok
+    for i in range(count):
+        if i != 3:
+            assert np.array_equal(out2[i], out[i]), i
+    ctx.set_geometry(0)

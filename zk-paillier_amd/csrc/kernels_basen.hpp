@@ -27,11 +27,12 @@
 namespace zkp {
 
 // ---- per-key constants (uint32 words in global memory), geometry G = lanes per n-sized integer
-//   MT[L] | C3[L] | RRa[L] | RRb[L] | N[L] | R2n[L] | ONE[L] (the integer 1) | n1, ok, -, -
+//   MT[L] | C3[L] | RRa[L] | RRb[L] | N[L] | R2n[L] | ONE[L] (the integer 1) | R1a[L] | R1b[L] (the Montgomery form of 1) | n1, ok, -, - | 2 L words of set-up scratch
 template <int G> struct BnConst {
   static constexpr int L = Geo<G>::L;
-  static constexpr int OFF_MT = 0, OFF_C3 = L, OFF_RRA = 2 * L, OFF_RRB = 3 * L, OFF_N = 4 * L, OFF_R2N = 5 * L, OFF_ONE = 6 * L, OFF_NI = 7 * L, OFF_OK = 7 * L + 1;
-  static constexpr int WORDS = 7 * L + 4;
+  static constexpr int OFF_MT = 0, OFF_C3 = L, OFF_RRA = 2 * L, OFF_RRB = 3 * L, OFF_N = 4 * L, OFF_R2N = 5 * L, OFF_ONE = 6 * L, OFF_R1A = 7 * L, OFF_R1B = 8 * L, OFF_NI = 9 * L, OFF_OK = 9 * L + 1;
+  static constexpr int WORDS = 9 * L + 4;
+  static constexpr int STRIDE = WORDS + 2 * L;      // words between the records of a batch of keys
 };
 
 // ---- per-group LDS: the staged a | the staged b; every conversion area (32-bit words in and out, limb scratch) aliases them and is only
@@ -164,12 +165,15 @@ __device__ __forceinline__ void bn_sqr_a(uint32_t (&R)[W], const uint32_t (&X)[W
 }
 
 // the initial columns of a b side: c_k = C3_k + (2^29 - Q_k) n1 over this lane's block of the digits an a side left in ldsQ
-template <int G> __device__ __forceinline__ void bn_b_init(uint64_t (&c)[W], const Bn<G>& g, const uint32_t* ldsQ) {
+// C3G: C3 from the key's record in global memory (launches with per-proof keys: there is no room for a copy per group in LDS), else from
+// the workgroup's copy in LDS
+template <int G, bool C3G = false> __device__ __forceinline__ void bn_b_init(uint64_t (&c)[W], const Bn<G>& g, const uint32_t* ldsQ) {
   uint32_t Q[W];
+  uint32_t C3[W];
+  if constexpr (C3G) load_limbs_global<G>(C3, g.cst + BnConst<G>::OFF_C3, g.gl);      // (issued before the LDS read of the digits: the longer latency first)
   wave_lds_fence();
   lds_load_block(Q, ldsQ + g.gl * BLK);
-  uint32_t C3[W];
-  lds_load_block(C3, g.c3 + g.gl * BLK);
+  if constexpr (!C3G) lds_load_block(C3, g.c3 + g.gl * BLK);
 #pragma unroll
   for (int k = 0; k < W; k++) c[k] = (uint64_t)C3[k] + (uint64_t)((1u << LB) - Q[k]) * g.n1;
 }
@@ -179,14 +183,14 @@ template <int G> __device__ __forceinline__ void bn_b_init(uint64_t (&c)[W], con
 //   mode 2: c0 = the b-side columns from the digits an a side left in ldsQ (bn_b_init); `pend` (if any) — that a side's result — is staged
 //           into ldsQ once the digits are read
 // FENCE: a scheduling barrier every FENCE sub-steps (bigint29.hpp SCHED_FENCE)
-template <int G, bool PEND, int FENCE = 12>
+template <int G, bool PEND, bool C3G = false, int FENCE = 12>
 __device__ __forceinline__ void bn_mul_impl(uint32_t (&R)[W], const uint32_t (&A)[W], uint32_t* ldsB, const Bn<G>& g, int mode, uint32_t* ldsQ,
                                             const uint32_t (&pend)[W]) {
   const int gl = g.gl;
   const uint64_t writes = q_write_mask<G>(mode == 1);
   uint64_t c[W];
   if (mode == 2) {
-    bn_b_init<G>(c, g, ldsQ);
+    bn_b_init<G, C3G>(c, g, ldsQ);
     if constexpr (PEND) bn_stage<G>(g, ldsQ, pend);
   } else {
 #pragma unroll
@@ -221,12 +225,12 @@ __device__ __forceinline__ void bn_mul_impl(uint32_t (&R)[W], const uint32_t (&A
   }
   R[0] += from_prev<G>((uint32_t)cy, gl);
 }
-template <int G> __device__ __forceinline__ void bn_mul(uint32_t (&R)[W], const uint32_t (&A)[W], uint32_t* ldsB, const Bn<G>& g, int mode, uint32_t* ldsQ = nullptr) {
-  bn_mul_impl<G, false>(R, A, ldsB, g, mode, ldsQ, A);
+template <int G, bool C3G = false> __device__ __forceinline__ void bn_mul(uint32_t (&R)[W], const uint32_t (&A)[W], uint32_t* ldsB, const Bn<G>& g, int mode, uint32_t* ldsQ = nullptr) {
+  bn_mul_impl<G, false, C3G>(R, A, ldsB, g, mode, ldsQ, A);
 }
 // the b side of a squaring: mode 2, and the a side's result `pend` goes into ldsQ once the digits there are read
-template <int G> __device__ __forceinline__ void bn_mul_b(uint32_t (&R)[W], const uint32_t (&A)[W], uint32_t* ldsB, const Bn<G>& g, uint32_t* ldsQ, const uint32_t (&pend)[W]) {
-  bn_mul_impl<G, true>(R, A, ldsB, g, 2, ldsQ, pend);
+template <int G, bool C3G = false> __device__ __forceinline__ void bn_mul_b(uint32_t (&R)[W], const uint32_t (&A)[W], uint32_t* ldsB, const Bn<G>& g, uint32_t* ldsQ, const uint32_t (&pend)[W]) {
+  bn_mul_impl<G, true, C3G>(R, A, ldsB, g, 2, ldsQ, pend);
 }
 
 // X <- 2 X, limbs normalised again (the carry out of a lane's block lands on limb 0 of the next lane; 2 X < R')
@@ -379,18 +383,27 @@ __device__ __forceinline__ void bn_canonical(const Bn<G>& g, uint32_t (&A1)[W], 
   bn_mul_full<G>(HI, LO, N, g.A(), A1, g.gl);      // a0 + bf n
 }
 
-// ---- set-up of the base-n constants of ONE key from the ConstLayout<G> record of the modulus n (k_setup<G>, square = 0)
+// ---- set-up of the base-n constants: one group per key, from the ConstLayout<G> records of the moduli n (k_setup<G>, square = 0).
+// all_ok (preset to 1 by the host): cleared when any key of the batch does not qualify — a launch with per-proof keys runs in base-n form
+// only when all of them do.  One wavefront per workgroup, BN_SETUP_LDS_WORDS of LDS per group.
+constexpr int BN_SETUP_LDS_WORDS = 1024;
 template <int G>
-__global__ void __launch_bounds__(64) k_setup_basen(const uint32_t* __restrict__ ncst /* ConstLayout<G> of n */, uint32_t* __restrict__ out /* BnConst<G> */) {
+__global__ void __launch_bounds__(64) k_setup_basen(const uint32_t* __restrict__ ncst_base /* ConstLayout<G> records */, uint32_t* __restrict__ out_base /* BnConst<G> records */,
+                                                    uint64_t count, uint32_t* __restrict__ all_ok) {
   using CL = ConstLayout<G>;
   using BC = BnConst<G>;
   constexpr int L = Geo<G>::L, CAP = Geo<G>::CAPBITS;
-  extern __shared__ __align__(16) uint32_t lds_raw[];
-  if (threadIdx.x >= G) return;                     // one group
+  extern __shared__ __align__(16) uint32_t lds_all[];
+  const uint64_t gid = (uint64_t)blockIdx.x * (64 / G) + threadIdx.x / G;
+  const bool live = gid < count;
+  const uint64_t key = live ? gid : count - 1;      // idle groups redo the last key (uniform wave operations) and store nothing new
+  const uint32_t* ncst = ncst_base + key * CL::WORDS;
+  uint32_t* out = out_base + key * BC::STRIDE;
+  uint32_t* lds_raw = lds_all + (threadIdx.x / G) * BN_SETUP_LDS_WORDS;
   Bn<G> g;
   g.gl = threadIdx.x & (G - 1);
   g.lds = lds_raw;
-  g.c3 = lds_raw + 704;                             // (this kernel's LDS: 4 KB; the group's areas and the word buffers of the doubling walk stay below)
+  g.c3 = lds_raw + 704;                             // (the group's areas and the word buffers of the doubling walk stay below)
   g.cst = out;
   uint32_t N[W], T[W], U[W], V[W];
   load_limbs_global<G>(N, ncst + CL::OFF_N, g.gl);
@@ -401,7 +414,7 @@ __global__ void __launch_bounds__(64) k_setup_basen(const uint32_t* __restrict__
     uint64_t sn = 0;
 #pragma unroll
     for (int k = 0; k < W; k++) sn += g.NT[k];
-    const unsigned long long gmk = (1ull << G) - 1;
+    const unsigned long long gmk = ((1ull << G) - 1) << ((threadIdx.x & 63) & ~(G - 1));
     ok = ok && (__ballot(sn <= COL_FAST_SN_LIMIT_BN) & gmk) == gmk;
   }
   // the modulus must leave the b parts room: bit length of n at least CAP / 2 + 64 (R' / n is the b part of the Montgomery one)
@@ -503,7 +516,12 @@ __global__ void __launch_bounds__(64) k_setup_basen(const uint32_t* __restrict__
   lds_load_block(Y, g.B() + g.gl * BLK);
   store_limbs_global<G>(out + BC::OFF_RRA, X, g.gl);
   store_limbs_global<G>(out + BC::OFF_RRB, Y, g.gl);
-  if (g.gl == 0) out[BC::OFF_OK] = ok ? 1u : 0u;
+  store_limbs_global<G>(out + BC::OFF_R1A, OA, g.gl);
+  store_limbs_global<G>(out + BC::OFF_R1B, OB, g.gl);
+  if (g.gl == 0) {
+    out[BC::OFF_OK] = ok ? 1u : 0u;
+    if (!ok) atomicAnd(all_ok, 0u);
+  }
 }
 
 // ---- expected ciphertexts of the Mask rows of a verify launch (c_j * cipher_x mod n^2: one product modulo n^2 per row, on the
@@ -537,6 +555,11 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_expected(EncArgs a, uint32_t* 
       mask_row = a.resp_kind[row] != 0;
       const bool use_c1 = mask_row ? (a.resp_j[row] == 1) : !(rw & 1);
       pexp = (use_c1 ? a.c1 : a.c2) + row * 2 * kw;
+    }
+    if (a.const_stride) {                                     // per-proof keys: the n^2 record of this item's key
+      const uint64_t i0 = (a.mode == 0 && a.half && item >= a.half) ? item - a.half : item;
+      cst = a.consts + (a.mode == 1 ? b : i0 / a.items_per_key) * a.const_stride;
+      load_modulus_consts<GS>(g, cst);
     }
     // (uniform control flow: groups of Open rows compute along on their c_j times 1 and store nothing)
     uint32_t A[W], R[W], Y[W];
@@ -608,6 +631,13 @@ __device__ __forceinline__ BnItem bn_item(const EncArgs& a, uint64_t item, const
     it.pexp = it.mask_row ? expected + item * 2 * kw : (use_c1 ? a.c1 : a.c2) + row * 2 * kw;
   }
   return it;
+}
+
+// key index of a work item (launches with per-proof keys; EncArgs as k_enc reads it)
+__device__ __forceinline__ uint64_t bn_key(const EncArgs& a, uint64_t item, const BnItem& it) {
+  if (a.mode == 1) return it.b;
+  const uint64_t i = (a.mode == 0 && a.half && item >= a.half) ? item - a.half : item;
+  return i / a.items_per_key;
 }
 
 constexpr int BN_TAB_ENTRIES = TABS + 4;      // window table | scratch (U, -) | (r, -) | copy of X0^2 | (1, m)
@@ -742,12 +772,162 @@ __global__ void __launch_bounds__(256, 2) k_enc_basen(EncArgs a, const uint32_t*
   }
 }
 
+// ---- the same for launches with PER-PROOF KEYS (EncArgs::n_stride != 0; the exponent of an item is its own key): fixed 6-bit windows
+// over the item's n as in kernels_modexp.hpp powm_fixed — table T[0] = the Montgomery form of 1, T[1] = x~, T[k] = T[k-1] x~, then from the
+// top window down [6 squarings, one product by T[window]] — with uniform control flow whatever the keys are.  Constants come from the
+// item's record (C3 from global memory at the start of every b side), the whole launch runs in base-n form only when EVERY key
+// qualified (`all_ok`); otherwise it returns at once and the n^2-sized k_enc<G, false> behind it does the work.
+// Table slot of a group: 64 entries, then (U | -) scratch, (r | -), (1 | m).
+constexpr int BN_KEYS_WIN = 6, BN_KEYS_TAB = 1 << BN_KEYS_WIN, BN_KEYS_TAB_ENTRIES = BN_KEYS_TAB + 3;
 template <int G>
-__global__ void __launch_bounds__(256) k_basen_finish(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ raw, const uint32_t* __restrict__ expected) {
+__global__ void __launch_bounds__(256, 2) k_enc_basen_keys(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ all_ok, uint32_t* __restrict__ table,
+                                                           uint32_t* __restrict__ raw) {
+  using BC = BnConst<G>;
+  using BL = BnLds<G>;
+  constexpr int L = Geo<G>::L, E = 2 * L, WIN = BN_KEYS_WIN, TB = BN_KEYS_TAB;
+  if (!*all_ok) return;
+  extern __shared__ __align__(16) uint32_t lds_raw[];
+  Bn<G> g;
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    g.gl = lane & (G - 1);
+    g.lds = lds_raw + (wave * (64 / G) + lane / G) * BL::WORDS;
+    g.c3 = nullptr;
+  }
+  const uint64_t ggrp = (uint64_t)blockIdx.x * BL::GROUPS_PER_BLOCK + (threadIdx.x / G);
+  uint32_t* tab = table + ggrp * (uint64_t)(BN_KEYS_TAB_ENTRIES * E);
+  uint32_t* scrU = tab + TB * E;
+  const int kw = a.n_bits / 32;
+  const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
+  const int lane = threadIdx.x & 63;
+  const int nwin = (a.n_bits + WIN - 1) / WIN;
+  for (;;) {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(a.work_counter, (unsigned long long)(64 / G));
+    base = __shfl(base, 0);
+    if (base >= count) break;
+    const uint64_t idx = base + (uint64_t)(lane / G);
+    const bool live = idx < count;
+    const uint64_t item = live ? idx : count - 1;
+    const BnItem it = bn_item(a, item, nullptr);
+    const uint64_t key = bn_key(a, item, it);
+    const uint32_t* cst = bcst + key * BC::STRIDE;
+    const uint32_t* pn = a.n + key * a.n_stride;               // the item's exponent
+    g.cst = cst;
+    load_limbs_global<G>(g.NT, cst + BC::OFF_MT, g.gl);
+    g.n1 = cst[BC::OFF_NI];
+    uint32_t T[W];
+    {
+      bn_load_value<G>(g, T, it.pr, it.rw);
+      store_limbs_global<G>(tab + (TB + 1) * E, T, g.gl);
+      bn_load_value<G>(g, T, it.pm, it.mw);
+      store_limbs_global<G>(tab + (TB + 2) * E + L, T, g.gl);
+#pragma unroll
+      for (int k = 0; k < W; k++) T[k] = (g.gl == 0 && k == 0) ? 1u : 0u;
+      store_limbs_global<G>(tab + (TB + 2) * E, T, g.gl);
+      load_limbs_global<G>(T, cst + BC::OFF_RRA, g.gl);
+      bn_stage<G>(g, g.A(), T);
+      load_limbs_global<G>(T, cst + BC::OFF_RRB, g.gl);
+      bn_stage<G>(g, g.B(), T);
+      // T[0] = the Montgomery form of 1
+      load_limbs_global<G>(T, cst + BC::OFF_R1A, g.gl);
+      store_limbs_global<G>(tab, T, g.gl);
+      load_limbs_global<G>(T, cst + BC::OFF_R1B, g.gl);
+      store_limbs_global<G>(tab + L, T, g.gl);
+    }
+    uint32_t* rawdst = live ? raw + item * E : scrU;
+    auto window = [&](int wi) -> int {
+      const int bit = wi * WIN;
+      const int w0 = bit >> 5, off = bit & 31;
+      const uint64_t x = (uint64_t)pn[w0] | ((uint64_t)(w0 + 1 < kw ? pn[w0 + 1] : 0u) << 32);
+      return (int)((x >> off) & (TB - 1));
+    };
+    enum { D_STAGE = -1, D_RAW = -2 };
+    int phase = 0, k = 2, wi = nwin - 2, sq_left = 0;
+#pragma unroll 1
+    for (;;) {
+      int src, dstk;
+      bool has_p0 = true;
+      if (phase == 0) {
+        src = TB + 1; dstk = D_STAGE; has_p0 = false;        // to the Montgomery domain: (r, -) x RR
+      } else if (phase == 1) {
+        if (k == TB) {
+          // table complete: the running value starts at T[top window]
+          const int e = window(nwin - 1);
+          uint32_t V[W];
+          load_limbs_global<G>(V, tab + e * E, g.gl);
+          bn_stage<G>(g, g.A(), V);
+          load_limbs_global<G>(V, tab + e * E + L, g.gl);
+          bn_stage<G>(g, g.B(), V);
+          phase = wi >= 0 ? 2 : 3;
+          sq_left = WIN;
+          continue;
+        }
+        // T[k] = T[k - 1] * x~ (staged; its a part was consumed by the round before: restage it from T[1])
+        uint32_t V[W];
+        load_limbs_global<G>(V, tab + E, g.gl);
+        bn_stage<G>(g, g.A(), V);
+        src = k - 1; dstk = k; k++;
+      } else if (phase == 2) {
+        if (sq_left) {                                       // ---- a squaring
+          sq_left--;
+          uint32_t A2[W], R[W];
+          lds_load_block(T, g.A() + g.gl * BLK);
+          bn_sqr_a<G>(A2, T, g.A(), g.NT, g);
+          bn_double<G>(T, g.gl);
+          bn_mul_b<G, true>(R, T, g.B(), g, g.A(), A2);
+          bn_stage<G>(g, g.B(), R);
+          continue;
+        }
+        src = window(wi); dstk = D_STAGE;
+        wi--; sq_left = WIN;
+        if (wi < 0) phase = 3;                               // (after this product)
+      } else {
+        src = TB + 2; dstk = D_RAW;                          // the final product: staged x the PLAIN pair (1, m) -> raw
+        phase = 4;
+      }
+      uint32_t* dp = dstk == D_RAW ? rawdst : dstk == D_STAGE ? scrU + L : tab + dstk * E;
+#pragma unroll 1
+      for (int slot = has_p0 ? 0 : 1; slot < 3; slot++) {
+        load_limbs_global<G>(T, tab + src * E + (slot == 0 ? L : 0), g.gl);
+        uint32_t R[W];
+        bn_mul<G, true>(R, T, slot == 2 ? g.B() : g.A(), g, slot, g.A());
+        if (slot == 0) store_limbs_global<G>(scrU, R, g.gl);
+        else if (slot == 1) store_limbs_global<G>(dp, R, g.gl);
+        else {
+          if (has_p0) {
+            uint32_t U[W];
+            load_limbs_global<G>(U, scrU, g.gl);
+            bn_add<G>(R, R, U, g.gl);
+          }
+          if (dstk == D_STAGE) {
+            bn_stage<G>(g, g.B(), R);
+            uint32_t V[W];
+            load_limbs_global<G>(V, dp, g.gl);
+            bn_stage<G>(g, g.A(), V);
+          } else store_limbs_global<G>(dp + L, R, g.gl);
+        }
+      }
+      if (phase == 0) {
+        // x~ is staged: it is T[1]
+        uint32_t V[W];
+        lds_load_block(V, g.A() + g.gl * BLK);
+        store_limbs_global<G>(tab + E, V, g.gl);
+        lds_load_block(V, g.B() + g.gl * BLK);
+        store_limbs_global<G>(tab + E + L, V, g.gl);
+        phase = 1;
+      } else if (phase == 4) break;
+    }
+  }
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_basen_finish(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ ok_word /* the key's OFF_OK, or the batch's all_ok */,
+                                                      int per_key, const uint32_t* __restrict__ raw, const uint32_t* __restrict__ expected) {
   using BC = BnConst<G>;
   using BL = BnLds<G>;
   constexpr int L = Geo<G>::L, E = 2 * L;
-  if (!bcst[BC::OFF_OK]) return;
+  if (!*ok_word) return;
   extern __shared__ __align__(16) uint32_t lds_raw[];
   Bn<G> g;
   bn_init<G>(g, lds_raw, bcst);
@@ -762,6 +942,10 @@ __global__ void __launch_bounds__(256) k_basen_finish(EncArgs a, const uint32_t*
     const bool live = idx < count;
     const uint64_t item = live ? idx : count - 1;
     const BnItem it = bn_item(a, item, expected);
+    if (per_key) {
+      g.cst = bcst + bn_key(a, item, it) * BC::STRIDE;
+      g.n1 = g.cst[BC::OFF_NI];
+    }
     uint32_t A1[W], B1[W], LO[W], HI[W];
     load_limbs_global<G>(A1, raw + item * E, g.gl);
     load_limbs_global<G>(B1, raw + item * E + L, g.gl);

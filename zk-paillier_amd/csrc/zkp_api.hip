@@ -54,7 +54,9 @@ struct zkp_ctx {
   std::string err;
   DevBuf consts, consts2, table, scratch[48];
   DevBuf bn_ncst, bn_consts, bn_table, bn_expected, bn_raw;
-  int bn_last_g = 0;                   // lanes per n-sized integer of the most recent base-n launch (0: none yet)   // base-n form (kernels_basen.hpp): set-up record of n, its base-n constants, window tables, Mask-row products
+  int bn_last_g = 0;                   // lanes per n-sized integer of the most recent base-n launch (0: none yet)
+  bool bn_last_per_key = false;        // ... and whether it ran under per-proof keys
+  DevBuf bn_flag;                      // device word: every key of the last batched base-n set-up qualified   // base-n form (kernels_basen.hpp): set-up record of n, its base-n constants, window tables, Mask-row products
   // timing of the dominant kernels
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -392,50 +394,72 @@ template <int G> static bool pair_ladder(const zkp_ctx* c, uint64_t items) {
 // compiled in zkp_kernels_basen.hip
 extern template __global__ void zkp::k_enc_basen<2>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
 extern template __global__ void zkp::k_enc_basen<4>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
-extern template __global__ void zkp::k_basen_finish<2>(EncArgs, const uint32_t*, const uint32_t*, const uint32_t*);
-extern template __global__ void zkp::k_basen_finish<4>(EncArgs, const uint32_t*, const uint32_t*, const uint32_t*);
-extern template __global__ void zkp::k_setup_basen<2>(const uint32_t*, uint32_t*);
-extern template __global__ void zkp::k_setup_basen<4>(const uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_enc_basen_keys<2>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_enc_basen_keys<4>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_basen_finish<2>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_basen_finish<4>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_setup_basen<2>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
+extern template __global__ void zkp::k_setup_basen<4>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
 extern template __global__ void zkp::k_expected<4>(EncArgs, uint32_t*, const uint32_t*);
 extern template __global__ void zkp::k_expected<8>(EncArgs, uint32_t*, const uint32_t*);
 extern template __global__ void zkp::k_diag_basen<2>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 extern template __global__ void zkp::k_diag_basen<4>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 #endif
-constexpr size_t BASEN_SETUP_LDS = 4096;
-// ZKP_BASEN=0: every Paillier launch stays on the n^2-sized kernels (A/B runs, and the parity tests that pin the two forms against each other)
-static bool basen_enabled() {
+constexpr size_t BASEN_DIAG_LDS = 4096;
+// ZKP_BASEN=0: every Paillier launch stays on the n^2-sized kernels (A/B runs, and the parity tests that pin the two forms against each other);
+// ZKP_BASEN=shared: per-proof keys stay on them (the state of the round's evidence set `basen`)
+static int basen_mode() {
   const char* e = std::getenv("ZKP_BASEN");
-  return !(e && e[0] == '0');
+  if (e && e[0] == '0') return 0;
+  if (e && e[0] == 's') return 1;
+  return 2;
 }
-// base-n constants of ONE key (G lanes per n-sized integer): k_setup<G> on n, then k_setup_basen<G>.  Everything stays on the stream;
-// whether the key qualifies (odd, long enough, digit sums of M~ within the fast-product bound) is a device word the kernels read.
-template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uint32_t n_bits) {
-  int32_t st = run_setup<G>(c, n, 0, (int)(n_bits / 32), 0, 1, c->bn_ncst);
+// base-n constants of `nkeys` keys (G lanes per n-sized integer): k_setup<G> on every n, then k_setup_basen<G>.  Everything stays on the
+// stream; whether the keys qualify (odd, long enough, digit sums of M~ within the fast-product bound) is a device word the kernels read:
+// c->bn_all_ok is 1 only when every key of the batch did.
+template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uint64_t n_stride, uint64_t nkeys, uint32_t n_bits) {
+  int32_t st = run_setup<G>(c, n, n_stride, (int)(n_bits / 32), 0, nkeys, c->bn_ncst);
   if (st) return st;
-  if ((st = ensure(c, c->bn_consts, (size_t)(BnConst<G>::WORDS + 2 * Geo<G>::L) * sizeof(uint32_t)))) return st;
-  hipLaunchKernelGGL(k_setup_basen<G>, dim3(1), dim3(64), BASEN_SETUP_LDS, c->stream, (const uint32_t*)c->bn_ncst.p, (uint32_t*)c->bn_consts.p);
+  if ((st = ensure(c, c->bn_consts, (size_t)nkeys * BnConst<G>::STRIDE * sizeof(uint32_t)))) return st;
+  if ((st = ensure(c, c->bn_flag, 64))) return st;
+  HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->bn_flag.p, 1, 1, c->stream));
+  constexpr unsigned GPB = 64 / G;
+  hipLaunchKernelGGL(k_setup_basen<G>, dim3((unsigned)((nkeys + GPB - 1) / GPB)), dim3(64), GPB * BN_SETUP_LDS_WORDS * sizeof(uint32_t), c->stream,
+                     (const uint32_t*)c->bn_ncst.p, (uint32_t*)c->bn_consts.p, nkeys, (uint32_t*)c->bn_flag.p);
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
 }
-// The base-n launch of a shared-key Enc call (GS: lanes per n^2-sized integer of the k_enc launch it stands in for).  It claims work from
-// the SAME counter as the k_enc launch that follows it: when the key qualifies it leaves nothing to claim, when it does not it returns at
-// once and k_enc runs as before.  Returns false when nothing was launched.
+// The base-n launch of an Enc call (GS: lanes per n^2-sized integer of the k_enc launch it stands in for).  It claims work from the SAME
+// counter as the k_enc launch that follows it: when the keys qualify it leaves nothing to claim, when they do not it returns at once
+// and k_enc runs as before.  Returns false when nothing was launched.
 template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
   if constexpr (GS != 4 && GS != 8) { (void)c; (void)a; return false; }
   else {
     constexpr int G = GS / 2;
     using BL = BnLds<G>;
     const int kw = a.n_bits / 32;
-    if (!basen_enabled() || !a.sched || a.n_stride != 0 || a.n_bits != 1024 * G) return false;
+    const bool per_key = a.n_stride != 0;
+    const int mode = basen_mode();
+    if (mode == 0 || (per_key && mode == 1) || a.n_bits != 1024 * G) return false;
+    if (!per_key && !a.sched) return false;                       // (a shared key whose launch takes the pair ladder of the latency engine)
+    if (per_key && a.n_stride != (uint64_t)kw) return false;
     if (a.mode == 0 && ((a.m_words > kw) || (a.r_words > kw))) return false;
-    if (basen_prepare<G>(c, a.n, (uint32_t)a.n_bits)) return false;
+    uint64_t nkeys = 1;
+    if (per_key) {
+      const uint64_t items = (a.mode == 0 && a.half) ? a.half : a.count;
+      nkeys = a.mode == 1 ? a.count / (2 * (uint64_t)a.ef) : (items + a.items_per_key - 1) / a.items_per_key;      // mode 1: a.count = 2 * batch * ef
+      if (nkeys == 0) return false;
+    }
+    if (basen_prepare<G>(c, a.n, a.n_stride, nkeys, (uint32_t)a.n_bits)) return false;
     static int per_cu = 0;
     if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_basen<G>, 256, BL::BYTES_PER_BLOCK) != hipSuccess || per_cu < 1)) per_cu = 1;
     const uint64_t need = (a.count + BL::GROUPS_PER_BLOCK - 1) / BL::GROUPS_PER_BLOCK;
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)per_cu * c->cus));
-    if (ensure(c, c->bn_table, (size_t)blocks * BL::GROUPS_PER_BLOCK * BN_TAB_ENTRIES * 2 * Geo<G>::L * sizeof(uint32_t))) return false;
+    const size_t entries = per_key ? BN_KEYS_TAB_ENTRIES : BN_TAB_ENTRIES;
+    if (ensure(c, c->bn_table, (size_t)blocks * BL::GROUPS_PER_BLOCK * entries * 2 * Geo<G>::L * sizeof(uint32_t))) return false;
     if (ensure(c, c->bn_raw, (size_t)a.count * 2 * Geo<G>::L * sizeof(uint32_t))) return false;
-    const uint32_t* ok = (const uint32_t*)c->bn_consts.p + BnConst<G>::OFF_OK;
+    // the word that says "this launch runs in base-n form": the key's own flag, or the batch's
+    const uint32_t* ok = per_key ? (const uint32_t*)c->bn_flag.p : (const uint32_t*)c->bn_consts.p + BnConst<G>::OFF_OK;
     const bool products = a.mode == 1 || (a.mode == 2 && a.cipher_x);
     if (products) {
       if (ensure(c, c->bn_expected, (size_t)a.count * 2 * kw * sizeof(uint32_t))) return false;
@@ -444,12 +468,16 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
       const unsigned eblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(eneed, 2ull * c->cus));
       hipLaunchKernelGGL(k_expected<GS>, dim3(eblocks), dim3(256), LS::BYTES_PER_BLOCK, c->stream, a, (uint32_t*)c->bn_expected.p, ok);
     }
-    c->bn_last_g = G;
-    hipLaunchKernelGGL(k_enc_basen<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_table.p,
-                       (uint32_t*)c->bn_raw.p);
+    c->bn_last_g = G; c->bn_last_per_key = per_key;
+    if (per_key)
+      hipLaunchKernelGGL(k_enc_basen_keys<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, ok, (uint32_t*)c->bn_table.p,
+                         (uint32_t*)c->bn_raw.p);
+    else
+      hipLaunchKernelGGL(k_enc_basen<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_table.p,
+                         (uint32_t*)c->bn_raw.p);
     const unsigned fblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, 8ull * c->cus));
-    hipLaunchKernelGGL(k_basen_finish<G>, dim3(fblocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (const uint32_t*)c->bn_raw.p,
-                       (const uint32_t*)c->bn_expected.p);
+    hipLaunchKernelGGL(k_basen_finish<G>, dim3(fblocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, ok, per_key ? 1 : 0,
+                       (const uint32_t*)c->bn_raw.p, (const uint32_t*)c->bn_expected.p);
     return true;
   }
 }
@@ -531,7 +559,7 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->lat_ctx) (void)c->lat->p_zkp_ctx_destroy(c->lat_ctx);
-  for (DevBuf* b : {&c->consts, &c->consts2, &c->table, &c->bn_ncst, &c->bn_consts, &c->bn_table, &c->bn_expected, &c->bn_raw}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->consts, &c->consts2, &c->table, &c->bn_ncst, &c->bn_consts, &c->bn_table, &c->bn_expected, &c->bn_raw, &c->bn_flag}) if (b->p) (void)hipFree(b->p);
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
@@ -599,10 +627,10 @@ extern "C" int32_t zkp_diag_basen(zkp_ctx* c, uint32_t n_bits, const uint32_t* n
   uint32_t* dout = s.out(out, 4 * L + 4);
   uint32_t* dscr = (uint32_t*)s.take(2 * L * sizeof(uint32_t));
   int32_t st = s.st;
-  if (!st) st = G == 2 ? basen_prepare<2>(c, dn, n_bits) : basen_prepare<4>(c, dn, n_bits);
+  if (!st) st = G == 2 ? basen_prepare<2>(c, dn, 0, 1, n_bits) : basen_prepare<4>(c, dn, 0, 1, n_bits);
   if (!st) {
-    if (G == 2) hipLaunchKernelGGL(k_diag_basen<2>, dim3(1), dim3(64), BASEN_SETUP_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
-    else hipLaunchKernelGGL(k_diag_basen<4>, dim3(1), dim3(64), BASEN_SETUP_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
+    if (G == 2) hipLaunchKernelGGL(k_diag_basen<2>, dim3(1), dim3(64), BASEN_DIAG_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
+    else hipLaunchKernelGGL(k_diag_basen<4>, dim3(1), dim3(64), BASEN_DIAG_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
     if (hipGetLastError() != hipSuccess) st = ZKP_EDEVICE;
   }
   const int32_t fin = s.finish();
@@ -616,7 +644,8 @@ extern "C" int32_t zkp_diag_basen_last(zkp_ctx* c, int32_t* out_lanes, uint32_t*
   if (!c->bn_last_g) return ZKP_OK;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t off = (c->bn_last_g == 2 ? BnConst<2>::OFF_OK : BnConst<4>::OFF_OK) * sizeof(uint32_t);
-  HIPCHK(c, hipMemcpyAsync(c->setup_flag_host + 8, (const char*)c->bn_consts.p + off, 4, hipMemcpyDeviceToHost, c->stream));
+  const void* word = c->bn_last_per_key ? c->bn_flag.p : (const void*)((const char*)c->bn_consts.p + off);
+  HIPCHK(c, hipMemcpyAsync(c->setup_flag_host + 8, word, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *out_qualified = c->setup_flag_host[8];
   return ZKP_OK;

@@ -8,10 +8,12 @@
 namespace zkp {
 template __global__ void k_enc_basen<2>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
 template __global__ void k_enc_basen<4>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
-template __global__ void k_basen_finish<2>(EncArgs, const uint32_t*, const uint32_t*, const uint32_t*);
-template __global__ void k_basen_finish<4>(EncArgs, const uint32_t*, const uint32_t*, const uint32_t*);
-template __global__ void k_setup_basen<2>(const uint32_t*, uint32_t*);
-template __global__ void k_setup_basen<4>(const uint32_t*, uint32_t*);
+template __global__ void k_enc_basen_keys<2>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_enc_basen_keys<4>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_basen_finish<2>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
+template __global__ void k_basen_finish<4>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
+template __global__ void k_setup_basen<2>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
+template __global__ void k_setup_basen<4>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
 template __global__ void k_expected<4>(EncArgs, uint32_t*, const uint32_t*);
 template __global__ void k_expected<8>(EncArgs, uint32_t*, const uint32_t*);
 template __global__ void k_diag_basen<2>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
