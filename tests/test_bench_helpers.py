@@ -71,3 +71,30 @@ def test_executed_work_figure_follows_the_kernel_script():
     assert r["frac"] < r["frac_at_sampled_clock"] < 1 and abs(r["frac"] - 0.876) < 0.002
     assert abs(r["valu_issue_busy"] * r["mad_share_of_valu"] - r["mad_issue_frac_at_sampled_clock"]) < 0.01
     assert abs(r["frac_at_sampled_clock"] - r["mad_issue_frac_at_sampled_clock"] / r["executed_over_algorithmic"]) < 1e-9
+
+
+def test_base_n_work_model_and_its_roofline_identity():
+    """the work model of the form that ran: 2 / 3 n-sized modular products per squaring / product — 0.544 of SURVEY 8(d)'s
+    figure —, the executed count of the base-n kernels, and the identity of the evidence line of round 4 (profiles/bench_r04_basen.json with
+    profiles/r04_pmc_basen_enc2048_shared_b4096.json)"""
+    assert abs(bench.enc_limb_macs_basen(2048) / 4.396e7 - 1) < 1e-3
+    assert abs(bench.enc_limb_macs_basen(2048) / bench.enc_limb_macs(2048) - 0.5438) < 1e-3
+    assert abs(bench.enc_limb_macs_basen(4096) / 3.503e8 - 1) < 1e-3
+    ex = bench.executed_lane_mads_per_enc_basen(synth.BENCH_N, 2048)
+    sq, mul = bench.sliding_ladder_products(synth.BENCH_N)
+    # a squaring: 72 sub-steps x 2 lanes x (54.5 + 72) multiply-adds + 72 for the b side's columns; a product: three n-sized products
+    assert ex == sq * (72 * 2 * 126.5 + 72) + mul * (3 * 72 * 2 * 72.0 + 72) + 5 * 72 * 2 * 72.0 + 2 * 72
+    assert 4.7e7 < ex < 4.8e7 and ex < bench.executed_lane_mads_per_enc(synth.BENCH_N, 2048, True) * 0.62
+    for kernel in ("k_enc_basen<2>", "k_enc_basen<4>"):
+        per, src = bench.pmc_traffic_per_modexp(kernel)
+        assert per and per > 1e5 and os.path.exists(os.path.join(H.ROOT, src)), kernel
+    rec, _ = bench.pmc_record("k_enc_basen<2>")
+    der = rec["_derived"]
+    assert der["modexps_per_wavefront"] == 32 and 4.0 <= der["simd_cycles_per_valu_instr"] < 4.4
+    import json
+    line = json.loads(open(os.path.join(H.ROOT, "profiles", "bench_r04_basen.json")).read().strip().splitlines()[-1])
+    r = line["roofline"]
+    assert r["work_model"]["form"].startswith("base-n") and r["frac"] < r["frac_at_sampled_clock"] < 1
+    assert r["work_model"]["achieved_by_the_survey_8d_model_tlimb_mac_per_s"] > r["peak"]          # the schoolbook model would read above the ceiling
+    busy, share = 4.0 / der["simd_cycles_per_valu_instr"], ex * 32 / 64.0 / der["valu_wave_instr_per_wave_modexp"]
+    assert abs(busy * share / r["executed_over_algorithmic"] - r["frac_at_sampled_clock"]) < 0.03   # (PMC pass and timed steps ran at slightly different clocks)
