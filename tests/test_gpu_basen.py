@@ -165,3 +165,29 @@ def test_enc_batch_with_per_item_keys_equals_python(ctx, n_bits):
         if i != 3:
             assert np.array_equal(out2[i], out[i]), i
     ctx.set_geometry(0)
+
+
+def test_small_launches_stay_on_the_n2_sized_kernels(ctx):
+    """the library's own routing (ZKP_BASEN unset): a launch whose n^2-sized wavefronts all find a SIMD of their own stays on those
+    kernels — 64 proofs at n = 2048: prove 51 ms against 64 ms in base-n form —, a larger one takes the form"""
+    rnd = random.Random(11)
+    n_bits, kw = 2048, 64
+    n = odd_modulus(rnd, n_bits)
+    nw = words(n, kw)
+    saved = os.environ.pop("ZKP_BASEN", None)
+    try:
+        ctx.set_geometry(zkp.load().zkp_build_limbs_per_lane())
+        for count, takes_the_form in ((200, False), (4 * 256 * 16 + 32, True)):
+            mw = np.zeros((count, kw), np.uint32); mw[:, 0] = np.arange(count)
+            rw = np.zeros((count, kw), np.uint32); rw[:, 0] = 3 + np.arange(count)
+            out = np.zeros((count, 2 * kw), np.uint32)
+            ctx.paillier_enc(n_bits, count, nw, 0, mw, rw, out)
+            lanes, ok = ctx.diag_basen_last()
+            assert (lanes == 2 and ok) == takes_the_form, (count, lanes, ok)
+            for i in (0, count - 1):
+                got = sum(int(w) << (32 * j) for j, w in enumerate(out[i]))
+                assert got == (1 + i * n) * pow(3 + i, n, n * n) % (n * n)
+    finally:
+        if saved is not None:
+            os.environ["ZKP_BASEN"] = saved
+        ctx.set_geometry(0)

@@ -407,11 +407,12 @@ extern template __global__ void zkp::k_diag_basen<4>(const uint32_t*, int, const
 #endif
 constexpr size_t BASEN_DIAG_LDS = 4096;
 // ZKP_BASEN=0: every Paillier launch stays on the n^2-sized kernels (A/B runs, and the parity tests that pin the two forms against each other);
-// ZKP_BASEN=shared: per-proof keys stay on them (the state of the round's evidence set `basen`)
+// ZKP_BASEN=shared: per-proof keys stay on them; ZKP_BASEN=always: base-n also for launches too small to gain from it
 static int basen_mode() {
   const char* e = std::getenv("ZKP_BASEN");
   if (e && e[0] == '0') return 0;
   if (e && e[0] == 's') return 1;
+  if (e && e[0] == 'a') return 3;      // "always": also the launches that leave SIMDs idle (tests of the small shapes)
   return 2;
 }
 // base-n constants of `nkeys` keys (G lanes per n-sized integer): k_setup<G> on every n, then k_setup_basen<G>.  Everything stays on the
@@ -439,11 +440,16 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
     using BL = BnLds<G>;
     const int kw = a.n_bits / 32;
     const bool per_key = a.n_stride != 0;
+    c->bn_last_g = 0;                                             // (zkp_diag_basen_last: this launch has not taken the form yet)
     const int mode = basen_mode();
     if (mode == 0 || (per_key && mode == 1) || a.n_bits != 1024 * G) return false;
     if (!per_key && !a.sched) return false;                       // (a shared key whose launch takes the pair ladder of the latency engine)
     if (per_key && a.n_stride != (uint64_t)kw) return false;
     if (a.mode == 0 && ((a.m_words > kw) || (a.r_words > kw))) return false;
+    // A launch whose n^2-sized wavefronts (64 / GS items each) all find a SIMD of their own is a single chain per wavefront either way,
+    // and the base-n chain is the longer one (27.4 M against 22.3 M VALU instructions per claim, for twice the items): measured at
+    // n = 2048, 64 proofs: prove 51 -> 64 ms, verify 45 -> 61 ms; from 96 proofs on: 88 -> 65 ms (profiles/r04/basen/midsize_sweep.jsonl)
+    if (mode != 3 && a.count <= 4ull * (uint64_t)c->cus * (64 / GS)) return false;
     uint64_t nkeys = 1;
     if (per_key) {
       const uint64_t items = (a.mode == 0 && a.half) ? a.half : a.count;
