@@ -96,6 +96,9 @@ def test_enc_batch_equals_python_and_the_n2_sized_kernels(ctx, n_bits):
     ms[0], rs[0] = 0, 1
     ms[1], rs[1] = n - 1, n - 1
     ms[2], rs[2] = (1 << n_bits) - 1, (1 << n_bits) - 1          # both above n: only m mod n and r mod n matter
+    ms[3], rs[3] = 5, 0                                            # r = 0 and r = n: Enc = 0
+    ms[4], rs[4] = 7, n
+    ms[5], rs[5] = n, n + 1                                        # m = n: the factor (1 + m n) is 1 modulo n^2
     nw = words(n, kw)
     mw = np.stack([words(v, kw) for v in ms])
     rw = np.stack([words(v, kw) for v in rs])
@@ -107,10 +110,10 @@ def test_enc_batch_equals_python_and_the_n2_sized_kernels(ctx, n_bits):
         assert got == (1 + ms[i] * n) * pow(rs[i], n, nn) % nn, i
     # Enc-and-compare: right and wrong expected values, and products of two ciphertexts as the expected value
     exp = out.copy()
-    exp[3, 5] ^= 1
+    exp[6, 5] ^= 1
     ok = np.full(count, 9, np.uint8)
     ctx.paillier_enc_check(n_bits, count, nw, 0, mw, rw, None, None, exp, ok)
-    assert list(ok) == [0 if i == 3 else 1 for i in range(count)]
+    assert list(ok) == [0 if i == 6 else 1 for i in range(count)]
     # expected = a * b mod n^2 (the Mask rows of RangeProofNi::verify): a = Enc(m, r) / b for an invertible b
     import math
     bs = []
@@ -119,12 +122,12 @@ def test_enc_batch_equals_python_and_the_n2_sized_kernels(ctx, n_bits):
         if math.gcd(v, n) == 1:
             bs.append(v)
     a_ = [(sum(int(w) << (32 * j) for j, w in enumerate(out[i])) * pow(bs[i], -1, nn)) % nn for i in range(count)]
-    a_[5] = (a_[5] + 1) % nn
+    a_[8] = (a_[8] + 1) % nn
     aw = np.stack([words(v, 2 * kw) for v in a_])
     bw = np.stack([words(v, 2 * kw) for v in bs])
     ok = np.full(count, 9, np.uint8)
     ctx.paillier_enc_check(n_bits, count, nw, 0, mw, rw, aw, bw, None, ok)
-    assert list(ok) == [0 if i == 5 else 1 for i in range(count)]
+    assert list(ok) == [0 if i == 8 else 1 for i in range(count)]
     ctx.set_geometry(0)
 
 
