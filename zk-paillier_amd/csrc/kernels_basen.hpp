@@ -736,9 +736,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_basen(EncArgs a, const uint32_t*
       uint32_t* dp = dstk == D_RAW ? rawdst : dstk == D_STAGE ? scrU + L : tab + dstk * E;    // where the a part goes (staged: via the scratch entry)
 #pragma unroll 1
       for (int slot = has_p0 ? 0 : 1; slot < 3; slot++) {
-        if (slot == 2 && (dstk == D_STAGE || dstk == TABS + 2)) {
-          // the digits of the a side are read inside the product; the a part follows them into A() afterwards (below)
-        }
+        // (slot 2 reads the a side's digits inside the product; the a part follows them into A() afterwards, below)
         load_limbs_global<G>(T, tab + src * E + (slot == 0 ? L : 0), g.gl);
         uint32_t R[W];
         bn_mul<G>(R, T, slot == 2 ? g.B() : g.A(), g, slot, g.A());
