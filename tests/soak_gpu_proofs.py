@@ -16,16 +16,16 @@ import oracle_lib
 FIELDS = ("c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2", "range", "ciphertext")
 
 
-def run(ctx, oracle, seed=1000, rounds=3, deadline=None, log=print, tag=b"soakp"):
+def run(ctx, oracle, seed=1000, rounds=3, deadline=None, log=print, tag=b"soakp", n_bits=1024, batches=(48, 1, 5, 300), geometries=(0, 36, 9)):
     """`rounds` rounds (or until `deadline`, time.monotonic()) of prove / tamper / verify; -> proofs checked"""
     import time
     zkp = H.zkp
-    keys = [H.test_key(512, tag=t)[2] for t in range(6)]
+    keys = [H.test_key(n_bits // 2 if n_bits == 1024 else n_bits, tag=t)[2] for t in range(6)]      # (n = 2048: full-size keys, the ones the base-n kernels take)
     total = 0
     for rd in range(rounds):
         rng = np.random.default_rng(seed + rd)
-        n_bits, B = 1024, (48, 1, 5, 300)[rd % 4]          # one proof ... a batch that takes the one-stream verify sequence
-        ctx.set_geometry((0, 36, 9)[rd % 3])               # automatic choice / pinned to either engine
+        B = batches[rd % len(batches)]                     # one proof ... a batch that takes the one-stream verify sequence
+        ctx.set_geometry(geometries[rd % len(geometries)])  # automatic choice / pinned to either engine
         shared = bool(rd % 2)
         klist = [keys[rd % 6]] if shared else [keys[(rd + b) % 6] for b in range(B)]
         cases = H.build_range_case(tag + b"-%d-%d" % (seed, rd), klist, n_bits, B, shared=shared)
@@ -64,11 +64,16 @@ def run(ctx, oracle, seed=1000, rounds=3, deadline=None, log=print, tag=b"soakp"
 
 
 def main():
+    """python tests/soak_gpu_proofs.py [rounds] [n_bits]; n_bits = 2048 (with ZKP_BASEN=always in the environment, or batches large enough)
+    soaks the base-n kernels, shared and per-proof keys in turn"""
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    n_bits = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     ctx = H.zkp.Context(0)
     oracle = oracle_lib.Oracle()
     oracle.set_threads(min(16, oracle.max_threads()))
-    print("PROOF SOAK OK", run(ctx, oracle, 1000, rounds, log=lambda *a: print(*a, flush=True)))
+    batches = (48, 1, 5, 300) if n_bits == 1024 else (24, 3, 40, 17)
+    print("PROOF SOAK OK", run(ctx, oracle, 1000, rounds, log=lambda *a: print(*a, flush=True), n_bits=n_bits, batches=batches,
+                               geometries=(0, 36, 9) if n_bits == 1024 else (36,)))
 
 
 if __name__ == "__main__":
