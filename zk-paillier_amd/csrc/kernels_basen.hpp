@@ -109,7 +109,9 @@ __device__ __forceinline__ void q_write(uint64_t qmask, uint32_t addr /* LDS byt
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 v = {qd[0], qd[1], qd[2], qd[3]};
   uint64_t saved;
-  asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b128 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(qmask), "v"(addr), "v"(v) : "scc");
+  // (the two instructions behind the write are its wait states: a VALU instruction must not overwrite the data registers of a DS write of
+  // more than 64 bits in the two issue slots after it, and the compiler's hazard recogniser does not look inside an asm statement)
+  asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b128 %2, %3\n\ts_mov_b64 exec, %0\n\ts_nop 0" : "=&s"(saved) : "s"(qmask), "v"(addr), "v"(v) : "scc");
 }
 __device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)p; }
 #define ZKP_BN_QWRITE(qmask, row_addr, t, qd)                                                                            \
