@@ -30,6 +30,19 @@ def odd_modulus(rnd, bits):
     return rnd.getrandbits(bits) | 1 | (1 << (bits - 1))
 
 
+@pytest.fixture(autouse=True)
+def force_the_form():
+    """the batches here are small: without this the library would keep them on the n^2-sized kernels (launch_basen's routing rule);
+    the routing test below takes the variable away again"""
+    saved = os.environ.get("ZKP_BASEN")
+    os.environ["ZKP_BASEN"] = "always"
+    yield
+    if saved is None:
+        os.environ.pop("ZKP_BASEN", None)
+    else:
+        os.environ["ZKP_BASEN"] = saved
+
+
 @pytest.fixture(scope="module")
 def ctx():
     c = zkp.Context(0)
