@@ -50,7 +50,7 @@ def test_product_loops_of_the_ladders_are_free_of_scratch_accesses():
     # path, and the three slots of every other base-n product.  The first builds of that file carried quotient digits and pending results
     # through these bodies in registers: 35 - 450 scratch accesses per block and 3.0 s instead of 1.2 s per verify step.
     # (the per-proof-keys variant reads C3 from global memory at the start of a b side: a few reloads around that load are tolerated)
-    for kernel, sq_max in (("k_enc_basen<2>", 2), ("k_enc_basen<4>", 2), ("k_enc_basen_keys<2>", 8), ("k_enc_basen_keys<4>", 8)):
+    for kernel, sq_max in (("k_enc_basen<2>", 2), ("k_enc_basen<4>", 2), ("k_enc_basen_keys<2>", 12), ("k_enc_basen_keys<4>", 12)):
         blocks = hot_blocks(text, kernel)
         sq = [s for m, s in blocks if 1962 <= m <= 1998]
         mul = [s for m, s in blocks if m == 2592]

@@ -185,7 +185,12 @@ template <int G, bool C3G = false> __device__ __forceinline__ void bn_b_init(uin
 //   mode 2: c0 = the b-side columns from the digits an a side left in ldsQ (bn_b_init); `pend` (if any) — that a side's result — is staged
 //           into ldsQ once the digits are read
 // FENCE: a scheduling barrier every FENCE sub-steps (bigint29.hpp SCHED_FENCE)
-template <int G, bool PEND, bool C3G = false, int FENCE = 12>
+// (a scheduling barrier every 18 sub-steps of the product body: A/B on two boxes against 12 — bigint29.hpp's choice for the n^2-sized
+// ladder —: +0.8 ... +1.0 % verifies/s; 9: the same; 24: -0.7 %; none: 100+ scratch accesses per block.  profiles/r04/basen/ab_fences.txt)
+#ifndef ZKP_BN_MUL_FENCE
+#define ZKP_BN_MUL_FENCE 18
+#endif
+template <int G, bool PEND, bool C3G = false, int FENCE = ZKP_BN_MUL_FENCE>
 __device__ __forceinline__ void bn_mul_impl(uint32_t (&R)[W], const uint32_t (&A)[W], uint32_t* ldsB, const Bn<G>& g, int mode, uint32_t* ldsQ,
                                             const uint32_t (&pend)[W]) {
   const int gl = g.gl;
