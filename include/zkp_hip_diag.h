@@ -31,6 +31,17 @@ int32_t zkp_diag_basen(zkp_ctx* ctx, uint32_t n_bits, const uint32_t* n, int32_t
  * (0: there was none), out_qualified: 1 when the key passed the form's set-up (else the n^2-sized kernel did the work). */
 int32_t zkp_diag_basen_last(zkp_ctx* ctx, int32_t* out_lanes, uint32_t* out_qualified);
 
+/* Which Paillier launches of this ctx run in base-n form (csrc/kernels_basen.hpp) and which on the n^2-sized kernels.  The product's
+ * rule is AUTO; the other values exist for A/B measurements and for the parity tests, which pin BOTH forms against the oracle at sizes
+ * where AUTO would only ever pick one.  $ZKP_BASEN (0 | shared | always) presets the value when a ctx is created — the environment is
+ * read there and nowhere else.  Results are bit-identical under every value. */
+#define ZKP_ENC_FORM_AUTO   0   /* launches that fill the chip take the form (under one key or under per-proof keys), smaller ones do not */
+#define ZKP_ENC_FORM_N2     1   /* every launch on the n^2-sized kernels */
+#define ZKP_ENC_FORM_SHARED 2   /* as AUTO, but launches under per-proof keys stay on the n^2-sized kernels */
+#define ZKP_ENC_FORM_ALWAYS 3   /* every launch the form can take, however small */
+int32_t zkp_diag_set_enc_form(zkp_ctx* ctx, int32_t form);
+int32_t zkp_diag_enc_form(zkp_ctx* ctx);   /* the current value; -1 for a null ctx */
+
 #ifdef __cplusplus
 }
 #endif

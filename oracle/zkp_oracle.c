@@ -573,6 +573,16 @@ static void primorial_init(void) {
   g_primorial_ready = 1;
 }
 
+/* test hook: the primorial this oracle computes, as a decimal string — tests/test_reference_constants.py compares it with the string the
+ * reference parses (correct_key_ni.rs:26,87).  Returns the length, or -1 when `cap` is too small. */
+int64_t oracle_primorial_decimal(char* out, uint64_t cap) {
+  primorial_init();
+  size_t need = mpz_sizeinbase(g_primorial, 10) + 2;
+  if (need > cap) return -1;
+  mpz_get_str(out, 10, g_primorial);
+  return (int64_t)strlen(out);
+}
+
 /* correct_key_ni.rs:74-86 + mask_generation :105-117.  rho[i] for i < 11. */
 static void correct_key_rho(mpz_t* rho, const mpz_t n, const uint8_t* salt, uint32_t salt_len) {
   size_t key_length = mpz_sizeinbase(n, 2); /* ek.n.bit_length() :74 */

@@ -12,11 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The suite's batches are small: left to itself the library would send their Paillier launches to the n^2-sized kernels (a launch
-    # that leaves SIMDs idle gains nothing from the base-n form, csrc/zkp_api.hip: launch_basen).  The parity tests are there to pin the
-    # kernels that carry the large batches, so the suite forces the form unless the caller chose (ZKP_BASEN=0 runs the other kernels);
-    # tests/test_gpu_basen.py::test_small_launches_stay_on_the_n2_sized_kernels checks the library's own routing.
-    os.environ.setdefault("ZKP_BASEN", "always")
+    # Nothing here touches $ZKP_BASEN: which Paillier launches take the base-n form is a property of a ctx (zkp_diag_set_enc_form), and
+    # the `ctx` fixture below runs the parity tests under BOTH forms.  Contexts a test creates itself run the library's own routing.
 
 
 def _gpu_present():
@@ -50,13 +47,24 @@ def oracle():
     return oracle_lib.Oracle()
 
 
-@pytest.fixture(scope="session", params=[36, 9], ids=["w36", "w9"])
+# (engine = limbs per lane, Enc form on the throughput engine)
+_CTX_PARAMS = [(36, "basen"), (36, "n2"), (9, None)]
+
+
+@pytest.fixture(scope="session", params=_CTX_PARAMS, ids=["w36-basen", "w36-n2", "w9"])
 def ctx(zkp, request):
     """one GPU context for the whole -m gpu session; fails loudly without GPU / built library.  Every test that takes it runs
-    twice: pinned to the throughput engine (36 limbs per lane) and to the latency engine (9; libzkp_hip_lat.so) — left to
-    itself the library would send these small batches to the latency engine only (tests/test_gpu_geometry.py covers that)."""
+    three times: pinned to the throughput engine (36 limbs per lane) with every Paillier launch in BASE-n form (csrc/kernels_basen.hpp —
+    the kernels that carry the large batches), pinned to it with every launch on the n^2-sized kernels (the product's choice for launches
+    that leave SIMDs idle, for keys the form does not take, and for n = 1024), and pinned to the latency engine (9; libzkp_hip_lat.so) —
+    left to itself the library would send these small batches to the latency engine only (tests/test_gpu_geometry.py covers that;
+    tests/test_gpu_routing.py covers the library's own choice between the two forms at the sizes where it flips)."""
+    geometry, form = request.param
     c = zkp.Context(0)
-    c.set_geometry(request.param)          # raises when the engine is not loaded
-    c.test_geometry = request.param
+    c.set_geometry(geometry)               # raises when the engine is not loaded
+    if form is not None:
+        c.set_enc_form(form)
+    c.test_geometry = geometry
+    c.test_form = form
     yield c
     c.close()

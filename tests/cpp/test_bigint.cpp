@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <sys/wait.h>
+#include <unistd.h>
 #include "../../zk-paillier_amd/host/bigint.hpp"
 using zkproofs::BigInt;
 
@@ -84,6 +86,36 @@ int main(int argc, char** argv) {
     BigInt first = BigInt::sample_range(lo, hi); bool differ = false;
     for (int i = 0; i < 200; i++) { BigInt v = BigInt::sample_range(lo, hi); CHECK(v >= lo && v < hi, "sample_range"); differ |= v != first; }
     CHECK(differ, "sampling is constant");
+  }
+  // a forked child must not replay the parent's stream (round-4 advisor finding): both continue from the same generator state; the child
+  // re-keys from the OS because its pid differs, the parent carries on with its own stream
+  {
+    int it = -2;
+    (void)BigInt::sample(256);                                  // the thread's generator exists and has a block in its buffer
+    int fd[2];
+    CHECK(pipe(fd) == 0, "pipe");
+    const pid_t pid = fork();
+    if (pid == 0) {
+      std::string out;
+      for (int i = 0; i < 6; i++) out += BigInt::sample(256).to_str_radix10() + "\n";     // spans the buffered block and the next ones
+      (void)!write(fd[1], out.data(), out.size());
+      _exit(0);
+    }
+    close(fd[1]);
+    std::string child; char tmp[4096]; ssize_t got;
+    while ((got = read(fd[0], tmp, sizeof tmp)) > 0) child.append(tmp, (size_t)got);
+    int status = 0; waitpid(pid, &status, 0);
+    std::string parent;
+    for (int i = 0; i < 6; i++) parent += BigInt::sample(256).to_str_radix10() + "\n";
+    // (the words buffered at the fork are dropped by the child, not handed out a second time)
+    size_t same_lines = 0, pos_c = 0, pos_p = 0;
+    for (int i = 0; i < 6; i++) {
+      const size_t ec = child.find('\n', pos_c), ep = parent.find('\n', pos_p);
+      CHECK(ec != std::string::npos && ep != std::string::npos, "six samples each");
+      same_lines += child.substr(pos_c, ec - pos_c) == parent.substr(pos_p, ep - pos_p);
+      pos_c = ec + 1; pos_p = ep + 1;
+    }
+    CHECK(WIFEXITED(status) && same_lines == 0, "a forked child replays its parent's random stream");
   }
   std::printf("bigint ok: %d iterations\n", iters);
   return 0;

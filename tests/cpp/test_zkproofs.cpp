@@ -125,6 +125,31 @@ static void test_batch_survives_crafted_proofs() {   // over-wide prover-chosen 
   ASSERT(threw);
 }
 
+// one odd proof at the HEAD of a batch (error_factor 127: the reference then checks rows 0..126 of the same transcript and accepts) must not
+// push the honest proofs behind it off the single-call path (round-4 advisor finding: the batch-wide row count came from proofs[0])
+static void test_odd_error_factor_at_the_head_of_a_batch() {
+  auto [ek, dk] = test_keypair().keys();
+  std::vector<RangeProofNi::Statement> st;
+  for (int i = 0; i < 4; i++) {
+    BigInt range = BigInt::sample(RANGE_BITS);
+    BigInt r = BigInt::sample_below(ek.n), x = BigInt::sample_below(range.div_floor(BigInt(3)));
+    st.push_back({range, Paillier::encrypt_with_chosen_randomness(ek, x, r), x, r});
+  }
+  auto proofs = RangeProofNi::prove_batch(ek, st);
+  proofs[0].error_factor = 127;
+  proofs[3].proof.responses[5].kind = proofs[3].proof.responses[5].kind == Response::Open ? Response::Mask : Response::Open;   // a plain reject among them
+  std::vector<const RangeProofNi*> ptr;
+  for (auto& p : proofs) ptr.push_back(&p);
+  auto res = RangeProofNi::verify_batch(ek, ptr);
+  ASSERT(res[0].is_ok() && res[1].is_ok() && res[2].is_ok() && res[3].is_err());
+  ASSERT(last_host_timing().proofs == 4 && last_host_timing().general_proofs == 1);
+  // and a batch in which EVERY proof carries the other row count still takes the single call
+  for (auto& p : proofs) p.error_factor = 127;
+  res = RangeProofNi::verify_batch(ek, ptr);
+  ASSERT(res[0].is_ok() && res[1].is_ok() && res[2].is_ok() && res[3].is_err());
+  ASSERT(last_host_timing().general_proofs == 4);      // (127 rows declared, 128 stored: not the canonical shape, so the general path — correct, and not the common case)
+}
+
 // c_j[i] + k n^2 on a Mask row.  The row equation only sees the product mod n^2 (range_proof.rs:324-328), but the Fiat-Shamir
 // challenge is hashed over the RAW pairs (range_proof_ni.rs:110-113, utils.rs:9-22): (a) added AFTER the proof was made the
 // challenge changes and the reference rejects; (b) a prover who hashes the raw value itself gets a proof the reference accepts.
@@ -203,12 +228,16 @@ static void test_correct_key_verify_batch_and_noncanonical_roots() {   // many k
   }
   EncryptionKey even{ek.n + BigInt::one(), (ek.n + BigInt::one()) * (ek.n + BigInt::one())};      // gcd(primorial, n) >= 2: Err (correct_key_ni.rs:87-88,95)
   EncryptionKey huge{BigInt::pow2(4200) + BigInt::one(), BigInt::one()};
-  auto res = NiCorrectKeyProof::verify_batch({{&ek, &good}, {&ek, &wide}, {&ek, &neg}, {&ek, &bad}, {&ek, &few}, {&even, &good}, {&huge, &good}});
+  EncryptionKey zero{BigInt(0), BigInt(0)};                                                        // rho_i % n: the reference's division-by-zero panic (:82-85)
+  auto res = NiCorrectKeyProof::verify_batch({{&ek, &good}, {&ek, &wide}, {&ek, &neg}, {&ek, &bad}, {&ek, &few}, {&even, &good}, {&huge, &good},
+                                              {&even, &few}, {&zero, &good}, {&zero, &few}});
   ASSERT(res[0].is_ok() && res[1].is_ok() && res[2].is_ok());
   ASSERT(res[3].is_err());
   ASSERT(res[4].would_panic());
   ASSERT(res[5].is_err());
   ASSERT(res[6].is_unsupported());
+  ASSERT(res[7].would_panic());           // the reference indexes sigma_vec[10] (:92) before it compares anything: the short vector wins over the even key
+  ASSERT(res[8].would_panic() && res[9].would_panic());
 }
 
 // ---- wi_dlog_proof.rs tests
@@ -518,6 +547,7 @@ int main() {
   run("range_proof_ni::verify asserts ek/ciphertext", test_verify_asserts_statement, true);
   run("range_proof_ni::batch round trip", test_batch_round_trip);
   run("range_proof_ni::batch survives crafted proofs", test_batch_survives_crafted_proofs);
+  run("range_proof_ni::an odd error_factor at the head of a batch", test_odd_error_factor_at_the_head_of_a_batch);
   run("range_proof_ni::over-wide pair on a mask row follows the raw transcript", test_overwide_pair_on_a_mask_row_follows_the_raw_transcript);
   run("correct_key_ni::test_correct_zk_proof_no_salt_str", test_correct_zk_proof_no_salt_str);
   run("correct_key_ni::test_correct_zk_proof_with_salt_str", test_correct_zk_proof_with_salt_str);

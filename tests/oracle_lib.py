@@ -36,6 +36,14 @@ class Oracle:
     def max_threads(self):
         return self.lib.oracle_get_max_threads()
 
+    def primorial_decimal(self) -> str:
+        """the product of the primes below 6370 as this oracle computes it (correct_key_ni.rs:26)"""
+        buf = C.create_string_buffer(4096)
+        self.lib.oracle_primorial_decimal.restype = C.c_int64
+        n = self.lib.oracle_primorial_decimal(buf, C.c_uint64(4096))
+        assert n > 0
+        return buf.value.decode()
+
     def sha256(self, data: bytes) -> bytes:
         out = (C.c_uint8 * 32)()
         self.lib.oracle_sha256(data, C.c_uint64(len(data)), out)

@@ -16,7 +16,7 @@ import oracle_lib
 FIELDS = ("c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2", "range", "ciphertext")
 
 
-def run(ctx, oracle, seed=1000, rounds=3, deadline=None, log=print, tag=b"soakp", n_bits=1024, batches=(48, 1, 5, 300), geometries=(0, 36, 9)):
+def run(ctx, oracle, seed=1000, rounds=3, deadline=None, log=print, tag=b"soakp", n_bits=1024, batches=(48, 1, 5, 300), geometries=(0, 36, 9), forms=("auto", "basen", "n2")):
     """`rounds` rounds (or until `deadline`, time.monotonic()) of prove / tamper / verify; -> proofs checked"""
     import time
     zkp = H.zkp
@@ -26,6 +26,7 @@ def run(ctx, oracle, seed=1000, rounds=3, deadline=None, log=print, tag=b"soakp"
         rng = np.random.default_rng(seed + rd)
         B = batches[rd % len(batches)]                     # one proof ... a batch that takes the one-stream verify sequence
         ctx.set_geometry(geometries[rd % len(geometries)])  # automatic choice / pinned to either engine
+        ctx.set_enc_form(forms[(rd // len(geometries)) % len(forms)])      # the library's own choice of Enc form / either form pinned (n = 2048 and up)
         shared = bool(rd % 2)
         klist = [keys[rd % 6]] if shared else [keys[(rd + b) % 6] for b in range(B)]
         cases = H.build_range_case(tag + b"-%d-%d" % (seed, rd), klist, n_bits, B, shared=shared)
@@ -60,11 +61,12 @@ def run(ctx, oracle, seed=1000, rounds=3, deadline=None, log=print, tag=b"soakp"
         if deadline is not None and time.monotonic() > deadline:
             break
     ctx.set_geometry(0)
+    ctx.set_enc_form("auto")
     return total
 
 
 def main():
-    """python tests/soak_gpu_proofs.py [rounds] [n_bits]; n_bits = 2048 (with ZKP_BASEN=always in the environment, or batches large enough)
+    """python tests/soak_gpu_proofs.py [rounds] [n_bits]; n_bits = 2048 (every third round pins the base-n form, every third the n^2-sized kernels)
     soaks the base-n kernels, shared and per-proof keys in turn"""
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     n_bits = int(sys.argv[2]) if len(sys.argv) > 2 else 1024

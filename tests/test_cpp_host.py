@@ -36,7 +36,7 @@ def test_reference_unit_tests_ported_to_cpp_pass():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("PASS") == 35 and "FAIL" not in out.stdout
+    assert out.stdout.count("PASS") == 36 and "FAIL" not in out.stdout
 
 
 def test_host_bigint_against_gmp():

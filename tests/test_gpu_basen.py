@@ -1,7 +1,6 @@
 """The base-n form of Paillier's arithmetic modulo n^2 (csrc/kernels_basen.hpp) on the GPU against tests/basen_model.py: constants and
-single operations limb for limb through the diagnostics entry point, then whole Enc calls against the n^2-sized kernels (ZKP_BASEN=0) and
-the oracle through the ordinary entry points."""
-import os
+single operations limb for limb through the diagnostics entry point, then whole Enc calls against Python's pow() through the ordinary
+entry points (the n^2-sized kernels answer the same calls in tests/test_gpu_l1.py under the `w36-n2` context)."""
 import random
 
 import numpy as np
@@ -30,22 +29,12 @@ def odd_modulus(rnd, bits):
     return rnd.getrandbits(bits) | 1 | (1 << (bits - 1))
 
 
-@pytest.fixture(autouse=True)
-def force_the_form():
-    """the batches here are small: without this the library would keep them on the n^2-sized kernels (launch_basen's routing rule);
-    the routing test below takes the variable away again"""
-    saved = os.environ.get("ZKP_BASEN")
-    os.environ["ZKP_BASEN"] = "always"
-    yield
-    if saved is None:
-        os.environ.pop("ZKP_BASEN", None)
-    else:
-        os.environ["ZKP_BASEN"] = saved
-
-
 @pytest.fixture(scope="module")
 def ctx():
+    """a context of its own: the batches here are small, so every Paillier launch is told to take the base-n form (left to itself the
+    library keeps them on the n^2-sized kernels: launch_basen's routing rule, tests/test_gpu_routing.py)"""
     c = zkp.Context(0)
+    c.set_enc_form("basen")
     yield c
     c.close()
 
@@ -181,29 +170,3 @@ def test_enc_batch_with_per_item_keys_equals_python(ctx, n_bits):
         if i != 3:
             assert np.array_equal(out2[i], out[i]), i
     ctx.set_geometry(0)
-
-
-def test_small_launches_stay_on_the_n2_sized_kernels(ctx):
-    """the library's own routing (ZKP_BASEN unset): a launch whose n^2-sized wavefronts all find a SIMD of their own stays on those
-    kernels — 64 proofs at n = 2048: prove 51 ms against 64 ms in base-n form —, a larger one takes the form"""
-    rnd = random.Random(11)
-    n_bits, kw = 2048, 64
-    n = odd_modulus(rnd, n_bits)
-    nw = words(n, kw)
-    saved = os.environ.pop("ZKP_BASEN", None)
-    try:
-        ctx.set_geometry(zkp.load().zkp_build_limbs_per_lane())
-        for count, takes_the_form in ((200, False), (4 * 256 * 16 + 32, True)):
-            mw = np.zeros((count, kw), np.uint32); mw[:, 0] = np.arange(count)
-            rw = np.zeros((count, kw), np.uint32); rw[:, 0] = 3 + np.arange(count)
-            out = np.zeros((count, 2 * kw), np.uint32)
-            ctx.paillier_enc(n_bits, count, nw, 0, mw, rw, out)
-            lanes, ok = ctx.diag_basen_last()
-            assert (lanes == 2 and ok) == takes_the_form, (count, lanes, ok)
-            for i in (0, count - 1):
-                got = sum(int(w) << (32 * j) for j, w in enumerate(out[i]))
-                assert got == (1 + i * n) * pow(3 + i, n, n * n) % (n * n)
-    finally:
-        if saved is not None:
-            os.environ["ZKP_BASEN"] = saved
-        ctx.set_geometry(0)

@@ -73,6 +73,7 @@ def test_multi_create_rejects_bad_device_list(zkp):
 
 def _build_c_example():
     import os
+import sys
     import subprocess
     src = os.path.join(H.ROOT, "examples", "multi_gpu_verify.c")
     exe = os.path.join(H.ROOT, "build", "multi_gpu_verify")
@@ -218,9 +219,16 @@ def test_c_example_with_the_rccl_gather():
     assert "contexts=1 proofs=24 accepted=23 rejected=1" in out.stdout and "gather=rccl context 0" in out.stdout and "single-context cross-check: identical" in out.stdout
 
 
-def test_library_links_rccl():
+def test_library_loads_rccl_on_demand_only():
+    """RCCL is not a load-time dependency (a single-GPU user needs none installed); the first zkp_multi_set_gather(RCCL) of the process
+    brings it in — the other RCCL tests of this file show that it then works"""
     import subprocess
-    assert "librccl" in subprocess.check_output(["ldd", zkp.LIB_PATH], text=True)
+    assert "librccl" not in subprocess.check_output(["ldd", zkp.LIB_PATH], text=True)
+    code = ("import importlib, sys; sys.path.insert(0, %r); zkp = importlib.import_module('zk-paillier_amd');"
+            "maps = lambda: 'librccl' in open('/proc/self/maps').read();"
+            "m = zkp.MultiContext([0]); before = maps(); m.set_gather(zkp.GATHER_RCCL); after = maps(); m.close(); print(before, after)" % H.ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.split()[-2:] == ["False", "True"], out.stdout + out.stderr
 
 
 def test_multi_last_timing_reports_blocks(oracle):

@@ -1,0 +1,167 @@
+"""The library's OWN choice of kernels — nothing pinned, $ZKP_BASEN not set — at the batch sizes where it flips, against the oracle.
+
+A RangeProofNi call at n = 2048 is served by one of three kernel families (csrc/zkp_api.hip: route_latency, launch_basen):
+  * the latency engine (9 limbs per lane, libzkp_hip_lat.so) while the call is a few proofs,
+  * the n^2-sized throughput kernels (k_enc<4, .>) while a launch still leaves SIMDs idle,
+  * the base-n kernels (k_enc_basen<2>, 32 Enc per wavefront) from there on.
+The parity suites pin each family in turn (tests/conftest.py: ctx); this file lets the library choose, says which family it expects for
+every size (zkp_ctx_last_geometry, zkp_diag_basen_last), and checks prove transcripts and verdict vectors against the C/GMP oracle on
+samples of every batch — and against the OTHER form's bytes for the whole batch."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import L
+
+zkp = H.zkp
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2")
+
+
+@pytest.fixture(scope="module")
+def actx():
+    assert "ZKP_BASEN" not in os.environ, "this file tests the library's default routing: unset ZKP_BASEN"
+    c = zkp.Context(0)
+    assert c.enc_form() == zkp.capi.ENC_FORM_AUTO
+    yield c
+    c.close()
+
+
+def compute_units():
+    import torch
+    return torch.cuda.get_device_properties(0).multi_processor_count
+
+
+def expected_family(c, items):
+    """what csrc/zkp_api.hip is expected to pick for a Paillier launch of `items` Enc under one 2048-bit key"""
+    lat = c.latency_limbs_per_lane()
+    cus = compute_units()
+    if lat and 2 * items <= (5 * 4 * cus * 64) // (144 // lat):
+        return "latency"
+    return "base-n" if items > 4 * cus * 16 else "n2"
+
+
+def family_that_ran(c):
+    if c.last_geometry() != zkp.load().zkp_build_limbs_per_lane():
+        return "latency"
+    lanes, ok = c.diag_basen_last()
+    return "base-n" if (lanes == 2 and ok) else "n2"
+
+
+def sub_batch(pb, idx, n_bits):
+    s = zkp.RangeBatch(n_bits, len(idx), pb.ef, shared_key=True)
+    s.n[:] = pb.n
+    for k, b in enumerate(idx):
+        for f in ("range", "ciphertext") + FIELDS:
+            getattr(s, f)[k] = getattr(pb, f)[b]
+    return s
+
+
+@pytest.mark.parametrize("B", [32, 48, 64, 96, 300])
+def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
+    n_bits, kw = 2048, 64
+    n = H.fixture_key()[2]
+    cases = H.build_range_case(b"routing-%d" % B, [n], n_bits, B)
+    oracle.set_threads(min(16, oracle.max_threads()))
+    pb_o, wt = H.fill_batch(cases, n_bits, True, oracle)
+    pb = zkp.RangeBatch(n_bits, B, 128, shared_key=True)
+    pb.n[:] = pb_o.n; pb.range[:] = pb_o.range; pb.ciphertext[:] = pb_o.ciphertext
+    actx.set_geometry(0)
+    actx.set_enc_form("auto")
+    status = np.full(B, 9, np.uint8)
+    actx.range_ni_prove(pb.struct(), wt.struct(), None, None, status, device=False)
+    want = expected_family(actx, 2 * 128 * B)
+    assert family_that_ran(actx) == want, (B, family_that_ran(actx), want)
+    assert not status.any()
+    # the prove transcripts of a sample of the batch, byte for byte against the oracle
+    idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1})
+    so = sub_batch(pb_o, idx, n_bits)
+    sw = zkp.make_range_witness(n_bits, len(idx))
+    for k, b in enumerate(idx):
+        for f in ("x", "r", "w1", "w2", "r1", "r2"):
+            getattr(sw, f)[k] = getattr(wt, f)[b]
+    oracle.range_ni_prove(so.struct(), sw.struct(), None, None, None)
+    for k, b in enumerate(idx):
+        for f in FIELDS:
+            assert np.array_equal(getattr(so, f)[k], getattr(pb, f)[b]), (B, b, f)
+    # the whole batch against the other kernels of the throughput engine (the same bytes whatever ran)
+    if want != "latency":
+        other = zkp.RangeBatch(n_bits, B, 128, shared_key=True)
+        other.n[:] = pb.n; other.range[:] = pb.range; other.ciphertext[:] = pb.ciphertext
+        actx.set_geometry(zkp.load().zkp_build_limbs_per_lane())
+        actx.set_enc_form("n2" if want == "base-n" else "basen")
+        actx.range_ni_prove(other.struct(), wt.struct(), None, None, None, device=False)
+        assert family_that_ran(actx) == ("n2" if want == "base-n" else "base-n")
+        for f in FIELDS:
+            assert np.array_equal(getattr(other, f), getattr(pb, f)), (B, f)
+        actx.set_geometry(0)
+        actx.set_enc_form("auto")
+    # verify: every 7th proof tampered in one of three ways
+    bad = list(range(3, B, 7))
+    for k, b in enumerate(bad):
+        if k % 3 == 0:
+            pb.resp_r1[b, k % 128, 0] ^= 1
+        elif k % 3 == 1:
+            pb.c2[b, (5 * k) % 128, 7] ^= 0x10
+        else:
+            pb.resp_w1[b, (11 * k) % 128, 1] ^= 2
+    v = np.full(B, 9, np.uint8)
+    actx.range_ni_verify(pb.struct(), v, device=False)
+    assert family_that_ran(actx) == want, (B, "verify", family_that_ran(actx), want)
+    expect = np.ones(B, np.uint8); expect[bad] = 0
+    assert np.array_equal(v, expect)
+    vidx = sorted(set(idx) | set(bad[:3]) | {bad[-1]})
+    vo = np.full(len(vidx), 9, np.uint8)
+    oracle.range_ni_verify(sub_batch(pb, vidx, n_bits).struct(), vo)
+    assert list(vo) == [int(v[b]) for b in vidx]
+
+
+def test_enc_launch_threshold(actx):
+    """zkp_paillier_enc_batch under one key: a launch whose n^2-sized wavefronts all find a SIMD of their own stays on those kernels,
+    a larger one takes the base-n form (pinned to the throughput engine: the latency engine would take the small one)"""
+    import random
+    rnd = random.Random(11)
+    n_bits, kw = 2048, 64
+    n = rnd.getrandbits(n_bits) | 1 | (1 << (n_bits - 1))
+    nw = L.int_to_limbs(n, kw)
+    actx.set_geometry(zkp.load().zkp_build_limbs_per_lane())
+    actx.set_enc_form("auto")
+    try:
+        cus = compute_units()
+        for count in (200, 4 * cus * 16, 4 * cus * 16 + 32):
+            mw = np.zeros((count, kw), np.uint32); mw[:, 0] = np.arange(count)
+            rw = np.zeros((count, kw), np.uint32); rw[:, 0] = 3 + np.arange(count)
+            out = np.zeros((count, 2 * kw), np.uint32)
+            actx.paillier_enc(n_bits, count, nw, 0, mw, rw, out)
+            assert family_that_ran(actx) == expected_family_throughput(cus, count), count
+            for i in (0, count // 2, count - 1):
+                got = sum(int(w) << (32 * j) for j, w in enumerate(out[i]))
+                assert got == (1 + i * n) * pow(3 + i, n, n * n) % (n * n)
+    finally:
+        actx.set_geometry(0)
+
+
+def expected_family_throughput(cus, items):
+    return "base-n" if items > 4 * cus * 16 else "n2"
+
+
+def test_the_environment_is_read_once_at_ctx_create(actx):
+    """$ZKP_BASEN presets a NEW ctx and is never looked at again (round-4 verdict: routing by getenv on every launch)"""
+    assert actx.enc_form() == zkp.capi.ENC_FORM_AUTO
+    os.environ["ZKP_BASEN"] = "0"
+    try:
+        assert actx.enc_form() == zkp.capi.ENC_FORM_AUTO          # the live ctx does not change
+        c2 = zkp.Context(0)
+        assert c2.enc_form() == zkp.capi.ENC_FORM_N2
+        os.environ["ZKP_BASEN"] = "always"
+        assert c2.enc_form() == zkp.capi.ENC_FORM_N2
+        c2.set_enc_form("shared")
+        assert c2.enc_form() == zkp.capi.ENC_FORM_SHARED
+        with pytest.raises(zkp.ZkpError):
+            c2.set_enc_form(7)
+        c2.close()
+    finally:
+        os.environ.pop("ZKP_BASEN", None)

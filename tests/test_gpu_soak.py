@@ -39,9 +39,10 @@ def test_randomised_soak_l1(zkp, oracle):
     try:
         oracle.set_threads(min(16, oracle.max_threads()))
         total = 0
-        for geom in (36, 9):
+        for geom, form in ((36, "basen"), (36, "n2"), (9, "auto")):     # both Enc forms of the throughput engine, then the latency engine
             ctx.set_geometry(geom)
-            total += soak_gpu.run(ctx, oracle, b"soak-%d-%d" % (seed, geom), rounds=1000, deadline=time.monotonic() + _box() / 2,
+            ctx.set_enc_form(form)
+            total += soak_gpu.run(ctx, oracle, b"soak-%d-%d-%s" % (seed, geom, form.encode()), rounds=1000, deadline=time.monotonic() + _box() / 3,
                                   log=lambda *a: print(*a, flush=True))
         assert total > 0
         print("L1 soak items:", total)

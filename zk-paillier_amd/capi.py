@@ -44,7 +44,11 @@ DIAG_EXPORTS = {
     "zkp_diag_table_traffic": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     "zkp_diag_basen": (C.c_int32, [C.c_void_p, C.c_uint32] + [C.c_void_p, C.c_int32] + [C.c_void_p] * 5),
     "zkp_diag_basen_last": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
+    "zkp_diag_set_enc_form": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "zkp_diag_enc_form": (C.c_int32, [C.c_void_p]),
 }
+ENC_FORM_AUTO, ENC_FORM_N2, ENC_FORM_SHARED, ENC_FORM_ALWAYS = 0, 1, 2, 3
+ENC_FORMS = {"auto": ENC_FORM_AUTO, "n2": ENC_FORM_N2, "shared": ENC_FORM_SHARED, "basen": ENC_FORM_ALWAYS, "always": ENC_FORM_ALWAYS}
 
 # include/zkp_hip.h: the boundary
 EXPORTS = {
@@ -297,6 +301,13 @@ class Context:
         n = C.c_uint64()
         self.check(self.lib.zkp_diag_table_traffic(self.h, mode, passes, C.byref(n)))
         return n.value
+
+    def set_enc_form(self, form):
+        """which Paillier launches run in base-n form (include/zkp_hip_diag.h): "auto" | "n2" | "shared" | "basen" (= always), or the number"""
+        self.check(self.lib.zkp_diag_set_enc_form(self.h, ENC_FORMS[form] if isinstance(form, str) else int(form)))
+
+    def enc_form(self) -> int:
+        return self.lib.zkp_diag_enc_form(self.h)
 
     def diag_basen_last(self):
         """(lanes per n-sized integer of the most recent base-n launch or 0, whether its key qualified for the form)"""

@@ -54,6 +54,8 @@ struct zkp_ctx {
   std::string err;
   DevBuf consts, consts2, table, scratch[48];
   DevBuf bn_ncst, bn_consts, bn_table, bn_expected, bn_raw;
+  int enc_form = ZKP_ENC_FORM_AUTO;    // which Paillier launches take the base-n form (zkp_diag_set_enc_form; $ZKP_BASEN is read ONCE, at zkp_ctx_create)
+  int bn_occ[2][2] = {{0, 0}, {0, 0}}; // resident workgroups per CU of k_enc_basen<G> / k_enc_basen_keys<G> ([per-key][G == 4]; 0: not asked yet)
   int bn_last_g = 0;                   // lanes per n-sized integer of the most recent base-n launch (0: none yet)
   bool bn_last_per_key = false;        // ... and whether it ran under per-proof keys
   DevBuf bn_flag;                      // device word: every key of the last batched base-n set-up qualified   // base-n form (kernels_basen.hpp): set-up record of n, its base-n constants, window tables, Mask-row products
@@ -406,14 +408,18 @@ extern template __global__ void zkp::k_diag_basen<2>(const uint32_t*, int, const
 extern template __global__ void zkp::k_diag_basen<4>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 #endif
 constexpr size_t BASEN_DIAG_LDS = 4096;
-// ZKP_BASEN=0: every Paillier launch stays on the n^2-sized kernels (A/B runs, and the parity tests that pin the two forms against each other);
-// ZKP_BASEN=shared: per-proof keys stay on them; ZKP_BASEN=always: base-n also for launches too small to gain from it
-static int basen_mode() {
+// Which Paillier launches take the base-n form is a property of the ctx (include/zkp_hip_diag.h: zkp_diag_set_enc_form):
+//   AUTO   the library's own rule — every launch that fills the chip (launch_basen below), under one key or under per-proof keys
+//   N2     none: every launch stays on the n^2-sized kernels (A/B runs, the parity tests that pin the two forms against each other)
+//   SHARED as AUTO, but launches under per-proof keys stay on the n^2-sized kernels
+//   ALWAYS also the launches too small to gain from it (the parity tests of the small shapes)
+// $ZKP_BASEN (0 | shared | always) presets it when the ctx is created; nothing reads the environment after that.
+static int enc_form_from_env() {
   const char* e = std::getenv("ZKP_BASEN");
-  if (e && e[0] == '0') return 0;
-  if (e && e[0] == 's') return 1;
-  if (e && e[0] == 'a') return 3;      // "always": also the launches that leave SIMDs idle (tests of the small shapes)
-  return 2;
+  if (e && e[0] == '0') return ZKP_ENC_FORM_N2;
+  if (e && e[0] == 's') return ZKP_ENC_FORM_SHARED;
+  if (e && e[0] == 'a') return ZKP_ENC_FORM_ALWAYS;
+  return ZKP_ENC_FORM_AUTO;
 }
 // base-n constants of `nkeys` keys (G lanes per n-sized integer): k_setup<G> on every n, then k_setup_basen<G>.  Everything stays on the
 // stream; whether the keys qualify (odd, long enough, digit sums of M~ within the fast-product bound) is a device word the kernels read:
@@ -441,34 +447,40 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
     const int kw = a.n_bits / 32;
     const bool per_key = a.n_stride != 0;
     c->bn_last_g = 0;                                             // (zkp_diag_basen_last: this launch has not taken the form yet)
-    const int mode = basen_mode();
-    if (mode == 0 || (per_key && mode == 1) || a.n_bits != 1024 * G) return false;
+    const int mode = c->enc_form;
+    if (mode == ZKP_ENC_FORM_N2 || (per_key && mode == ZKP_ENC_FORM_SHARED) || a.n_bits != 1024 * G) return false;
     if (!per_key && !a.sched) return false;                       // (a shared key whose launch takes the pair ladder of the latency engine)
     if (per_key && a.n_stride != (uint64_t)kw) return false;
     if (a.mode == 0 && ((a.m_words > kw) || (a.r_words > kw))) return false;
     // A launch whose n^2-sized wavefronts (64 / GS items each) all find a SIMD of their own is a single chain per wavefront either way,
     // and the base-n chain is the longer one (27.4 M against 22.3 M VALU instructions per claim, for twice the items): measured at
     // n = 2048, 64 proofs: prove 51 -> 64 ms, verify 45 -> 61 ms; from 96 proofs on: 88 -> 65 ms (profiles/r04/basen/midsize_sweep.jsonl)
-    if (mode != 3 && a.count <= 4ull * (uint64_t)c->cus * (64 / GS)) return false;
+    if (mode != ZKP_ENC_FORM_ALWAYS && a.count <= 4ull * (uint64_t)c->cus * (64 / GS)) return false;
     uint64_t nkeys = 1;
     if (per_key) {
       const uint64_t items = (a.mode == 0 && a.half) ? a.half : a.count;
       nkeys = a.mode == 1 ? a.count / (2 * (uint64_t)a.ef) : (items + a.items_per_key - 1) / a.items_per_key;      // mode 1: a.count = 2 * batch * ef
       if (nkeys == 0) return false;
     }
-    if (basen_prepare<G>(c, a.n, a.n_stride, nkeys, (uint32_t)a.n_bits)) return false;
-    static int per_cu = 0;
-    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_basen<G>, 256, BL::BYTES_PER_BLOCK) != hipSuccess || per_cu < 1)) per_cu = 1;
+    // (any failure below — out of memory for the form's tables — leaves the launch to the n^2-sized kernel behind this one: not an error)
+    auto give_up = [&]() { c->err.clear(); return false; };
+    if (basen_prepare<G>(c, a.n, a.n_stride, nkeys, (uint32_t)a.n_bits)) return give_up();
+    int& per_cu = c->bn_occ[per_key ? 1 : 0][G == 4 ? 1 : 0];     // per ctx and per kernel: the two differ in registers, and contexts run on threads of their own
+    if (!per_cu) {
+      const hipError_t e = per_key ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_basen_keys<G>, 256, BL::BYTES_PER_BLOCK)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_basen<G>, 256, BL::BYTES_PER_BLOCK);
+      if (e != hipSuccess || per_cu < 1) per_cu = 1;
+    }
     const uint64_t need = (a.count + BL::GROUPS_PER_BLOCK - 1) / BL::GROUPS_PER_BLOCK;
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)per_cu * c->cus));
     const size_t entries = per_key ? BN_KEYS_TAB_ENTRIES : BN_TAB_ENTRIES;
-    if (ensure(c, c->bn_table, (size_t)blocks * BL::GROUPS_PER_BLOCK * entries * 2 * Geo<G>::L * sizeof(uint32_t))) return false;
-    if (ensure(c, c->bn_raw, (size_t)a.count * 2 * Geo<G>::L * sizeof(uint32_t))) return false;
+    if (ensure(c, c->bn_table, (size_t)blocks * BL::GROUPS_PER_BLOCK * entries * 2 * Geo<G>::L * sizeof(uint32_t))) return give_up();
+    if (ensure(c, c->bn_raw, (size_t)a.count * 2 * Geo<G>::L * sizeof(uint32_t))) return give_up();
     // the word that says "this launch runs in base-n form": the key's own flag, or the batch's
     const uint32_t* ok = per_key ? (const uint32_t*)c->bn_flag.p : (const uint32_t*)c->bn_consts.p + BnConst<G>::OFF_OK;
     const bool products = a.mode == 1 || (a.mode == 2 && a.cipher_x);
     if (products) {
-      if (ensure(c, c->bn_expected, (size_t)a.count * 2 * kw * sizeof(uint32_t))) return false;
+      if (ensure(c, c->bn_expected, (size_t)a.count * 2 * kw * sizeof(uint32_t))) return give_up();
       using LS = LdsLayout<GS>;
       const uint64_t eneed = (a.count + LS::GROUPS_PER_BLOCK - 1) / LS::GROUPS_PER_BLOCK;
       const unsigned eblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(eneed, 2ull * c->cus));
@@ -519,6 +531,9 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
   c->device = device_id;
   c->cus = p.multiProcessorCount;
   c->last_geometry = W;
+#if ZKP_W == 36
+  c->enc_form = enc_form_from_env();
+#endif
   c->owns_stream = own_stream;
   c->stream = stream;
   if (own_stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKP_EDEVICE; }
@@ -586,6 +601,9 @@ extern "C" int32_t zkp_ctx_release_staging(zkp_ctx* c) try {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (auto& b : c->stage_free) (void)hipFree(b.p);
   c->stage_free.clear();
+  // the base-n form's per-launch areas (window tables of pairs: 1.4 GB under one key, 2.5 GB under per-proof keys; raw pairs; Mask-row
+  // products) are sized by the largest launch so far and rebuilt on demand
+  for (DevBuf* b : {&c->bn_table, &c->bn_raw, &c->bn_expected}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
   if (c->lat_ctx) return lat_forward_plain(c, c->lat->p_zkp_ctx_release_staging(c->lat_ctx));
   return ZKP_OK;
 } ZKP_CATCH(c)
@@ -667,6 +685,14 @@ extern "C" int32_t zkp_diag_basen(zkp_ctx* c, uint32_t, const uint32_t*, int32_t
   return ZKP_EINVAL;
 }
 #endif
+
+// which Paillier launches take the base-n form (include/zkp_hip_diag.h); the latency engine has no base-n kernels and ignores it
+extern "C" int32_t zkp_diag_set_enc_form(zkp_ctx* c, int32_t form) try {
+  if (!c || form < ZKP_ENC_FORM_AUTO || form > ZKP_ENC_FORM_ALWAYS) return ZKP_EINVAL;
+  c->enc_form = form;
+  return ZKP_OK;
+} ZKP_CATCH(c)
+extern "C" int32_t zkp_diag_enc_form(zkp_ctx* c) { return c ? c->enc_form : -1; }
 
 extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) try {
   if (!c) return ZKP_EINVAL;

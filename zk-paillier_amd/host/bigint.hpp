@@ -9,10 +9,17 @@
 //   to_bytes()     big-endian MAGNITUDE, zero -> one 00 byte (mpz_export ignores the sign) [upstream, recalled]
 // Division is Knuth's algorithm D on 32-bit limbs; sampling draws from a per-thread ChaCha20 stream keyed from the OS.
 #pragma once
+#include <sys/random.h>
+#include <sys/types.h>
+#include <unistd.h>
+
+#include <pthread.h>
+
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <cstdint>
 #include <cstring>
-#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -21,19 +28,49 @@ namespace zkproofs {
 
 namespace detail {
 // ChaCha20 block function (RFC 8439) as a DRBG: the reference samples through rand's OsRng / thread_rng; one OS read per 32-bit word
-// (std::random_device) costs more than the GPU step at 4096 proofs x 128 rows x 136 words
+// costs more than the GPU step at 4096 proofs x 128 rows x 136 words.  Key and nonce come from the kernel (getrandom(2); it blocks until
+// the pool is initialised and cannot return a deterministic stream the way std::random_device may); the stream is re-keyed
+//   * in a child after fork(): a forked process must not replay the witness randomness and nonces of its parent — a pthread_atfork
+//     handler bumps a process-wide generation number in the child, and every word drawn compares it with the generator's own (one
+//     relaxed load; the words still buffered at the fork are dropped, not handed out twice);
+//   * after RESEED_BLOCKS blocks (64 MiB of output), so that a state captured once does not give away the stream forever;
+// and the state is wiped when the thread's generator is destroyed.
+inline std::atomic<uint32_t>& fork_generation() {
+  static std::atomic<uint32_t> gen{0};
+  static const int registered = pthread_atfork(nullptr, nullptr, [] { fork_generation().fetch_add(1, std::memory_order_relaxed); });
+  (void)registered;
+  return gen;
+}
 struct ChaChaRng {
+  static constexpr uint32_t RESEED_BLOCKS = 1u << 20;
   uint32_t st[16], buf[16];
   int have = 0;
-  ChaChaRng() {
+  uint32_t blocks_left = 0;
+  uint32_t generation = 0;
+  ChaChaRng() { reseed(); }
+  ~ChaChaRng() { wipe(st, sizeof st); wipe(buf, sizeof buf); }
+  static void wipe(void* p, size_t n) { volatile unsigned char* v = (volatile unsigned char*)p; while (n--) *v++ = 0; }
+  static void os_random(void* out, size_t n) {
+    unsigned char* p = (unsigned char*)out;
+    while (n) {
+      const ssize_t got = getrandom(p, n, 0);
+      if (got < 0) { if (errno == EINTR) continue; throw std::runtime_error("getrandom failed: no entropy source for witness randomness"); }
+      p += got; n -= (size_t)got;
+    }
+  }
+  void reseed() {
     static const uint32_t sigma[4] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574};
-    std::random_device rd;
     std::memcpy(st, sigma, 16);
-    for (int i = 4; i < 16; i++) st[i] = rd();
-    st[12] = 0;
+    os_random(st + 4, 48);             // 256-bit key, counter, nonce
+    st[12] = 0; st[13] = 0;            // 64-bit block counter
+    have = 0;
+    blocks_left = RESEED_BLOCKS;
+    generation = fork_generation().load(std::memory_order_relaxed);
   }
   static uint32_t rol(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
   void block() {
+    if (!blocks_left) reseed();
+    blocks_left--;
     uint32_t x[16];
     std::memcpy(x, st, 64);
 #define ZKP_QR(a, b, c, d) x[a] += x[b]; x[d] = rol(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rol(x[b] ^ x[c], 12); x[a] += x[b]; x[d] = rol(x[d] ^ x[a], 8); x[c] += x[d]; x[b] = rol(x[b] ^ x[c], 7);
@@ -46,7 +83,11 @@ struct ChaChaRng {
     if (++st[12] == 0) ++st[13];
     have = 16;
   }
-  uint32_t next() { if (!have) block(); return buf[--have]; }
+  uint32_t next() {
+    if (generation != fork_generation().load(std::memory_order_relaxed)) reseed();      // this is a forked child: new key, buffered words dropped
+    if (!have) block();
+    return buf[--have];
+  }
   static ChaChaRng& local() { static thread_local ChaChaRng r; return r; }
 };
 }  // namespace detail

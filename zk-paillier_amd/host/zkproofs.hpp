@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -399,7 +400,16 @@ class RangeProofNi {
       return std::vector<Result>(B, Result::unsupported("RangeProofNi::verify: the key is not a positive odd integer of at most 4096 bits"));
     Engine& e = Engine::instance();
     const uint32_t nb = width_for(ek.n), kw = nb / 32;
-    const size_t EF = proofs[0]->error_factor;
+    // The batch-wide row count of the single-call path is the one MOST proofs carry (prove always writes SECURITY_PARAMETER, so that is
+    // what wins in practice; ties go to it) — not that of proofs[0]: one odd proof at the head of a batch must not push the honest ones
+    // off the fast path.  Proofs with another error_factor are verified correctly, by verify_general.
+    size_t EF = SECURITY_PARAMETER;
+    {
+      std::map<size_t, size_t> votes;
+      for (const RangeProofNi* p : proofs) votes[p->error_factor]++;
+      size_t best = votes.count(EF) ? votes[EF] : 0;
+      for (const auto& kv : votes) if (kv.second > best && kv.first > 0 && kv.first <= 4096) { best = kv.second; EF = kv.first; }
+    }
     std::vector<size_t> fast, general;
     auto canonical = [&](const RangeProofNi& p) {
       if (p.error_factor != EF || p.proof.responses.size() != EF || p.encrypted_pairs.c1.size() != EF || p.encrypted_pairs.c2.size() != EF) return false;
@@ -512,12 +522,15 @@ class RangeProofNi {
   static std::vector<Result> verify_general(const EncryptionKey& ek, const std::vector<const RangeProofNi*>& proofs,
                                             const std::vector<std::vector<uint8_t>>* challenges = nullptr) {
     struct Row { uint8_t what = 0; size_t enc0 = 0; BigInt expect0, expect1; bool flag = true; };   // what: 0 false, 1 open, 2 mask
-    struct Plan { std::vector<Row> rows; bool panic = false; };
+    using EncList = std::vector<std::pair<const BigInt*, const BigInt*>>;
+    struct Plan { std::vector<Row> rows; bool panic = false; EncList encs; size_t base = 0; };     // (enc0 of a row: relative to the plan's own list until the merge below)
     std::vector<Plan> plans(proofs.size());
-    std::vector<std::pair<const BigInt*, const BigInt*>> encs;
-    for (size_t b = 0; b < proofs.size(); b++) {
+    // one plan per proof, on the host threads: a transcript hash, a BigInt product and a Knuth division per Mask row — for a batch that an
+    // adversarial sender pushed here that is the bulk of the host time
+    parallel_for(proofs.size(), [&](size_t b) {
       const RangeProofNi& p = *proofs[b];
       Plan& pl = plans[b];
+      EncList& encs = pl.encs;
       std::vector<uint8_t> ebytes;
       if (challenges) ebytes = (*challenges)[b];
       else {
@@ -549,6 +562,12 @@ class RangeProofNi {
         }
         pl.rows.push_back(std::move(row));
       }
+    });
+    EncList encs;
+    for (Plan& pl : plans) {
+      pl.base = encs.size();
+      if (pl.panic) continue;                                        // (a proof that panics needs no Enc: the panic wins over any `false`)
+      encs.insert(encs.end(), pl.encs.begin(), pl.encs.end());
     }
     const std::vector<BigInt> E = Paillier::encrypt_with_chosen_randomness_batch(ek, encs);
     std::vector<Result> out;
@@ -557,8 +576,8 @@ class RangeProofNi {
       bool all = true;
       for (const Row& r : pl.rows) {
         bool res = r.what != 0 && r.flag;
-        if (r.what == 1) res = res && E[r.enc0] == r.expect0 && E[r.enc0 + 1] == r.expect1;
-        if (r.what == 2) res = res && E[r.enc0] == r.expect0;
+        if (r.what == 1) res = res && E[pl.base + r.enc0] == r.expect0 && E[pl.base + r.enc0 + 1] == r.expect1;
+        if (r.what == 2) res = res && E[pl.base + r.enc0] == r.expect0;
         all = all && res;
       }
       out.emplace_back(all);
@@ -765,7 +784,7 @@ class NiCorrectKeyProof {
   // correct_key_ni.rs:73-100 for many (key, proof) pairs in ONE zkp_correct_key_ni_verify_batch (keys of one kernel width per call; the
   // widths are grouped here).  sigma_i is prover-chosen: any size, either sign — the reference only uses it as mod_pow(sigma_i, n, n),
   // which depends on sigma_i mod n (floored: mpz_powm), so a non-canonical root is reduced on the host and gets the reference's verdict;
-  // fewer than 11 roots is the reference's index panic (:92); an even key fails the primorial gcd test whatever the roots are (Err); a key
+  // a zero key and fewer than 11 roots are the reference's panics (:82-85, :92), checked in its order; an even key then fails the primorial gcd test whatever the roots are (Err); a key
   // the engine cannot carry (not positive, or wider than 4096 bits) is Result::unsupported.
   static std::vector<Result> verify_batch(const std::vector<std::pair<const EncryptionKey*, const NiCorrectKeyProof*>>& items, const uint8_t* salt = SALT_STRING,
                                           size_t salt_len = 4) {
@@ -776,11 +795,14 @@ class NiCorrectKeyProof {
       std::vector<size_t> idx;
       for (size_t k = 0; k < items.size(); k++) {
         const BigInt& n = items[k].first->n;
-        if (!n.is_negative() && !n.is_zero() && !n.is_odd()) continue;   // an even key: gcd(primorial, n) >= 2, Err(IncorrectProof) whatever the roots are (:87-88,95); `out` holds that already
+        // in the reference's order: rho_i = mask_generation(..) % n panics on n = 0 (:82-85); sigma_vec[i] for i < 11 panics on a short vector
+        // (:90-93) — both BEFORE anything is compared; only then does an even key fail the primorial gcd test whatever the roots are (:87-88,95)
+        if (n.is_zero()) { out[k] = Result::panicked("attempt to calculate the remainder with a divisor of zero"); continue; }
+        if (items[k].second->sigma_vec.size() < M2) { out[k] = Result::panicked("index out of bounds: sigma_vec"); continue; }
+        if (!n.is_negative() && !n.is_odd()) continue;                    // an even key: Err(IncorrectProof); `out` holds that already
         const bool supported = !n.is_negative() && n.is_odd() && n.bit_length() >= 2 && n.bit_length() <= 4096;
         if (!supported) { if (nb == 1024) out[k] = Result::unsupported("NiCorrectKeyProof::verify: the key is not a positive integer of at most 4096 bits"); continue; }
         if (width_for(n) != nb) continue;
-        if (items[k].second->sigma_vec.size() < M2) { out[k] = Result::panicked("index out of bounds: sigma_vec"); continue; }
         idx.push_back(k);
       }
       if (idx.empty()) continue;
