@@ -42,6 +42,12 @@ int32_t zkp_diag_basen_last(zkp_ctx* ctx, int32_t* out_lanes, uint32_t* out_qual
 int32_t zkp_diag_set_enc_form(zkp_ctx* ctx, int32_t form);
 int32_t zkp_diag_enc_form(zkp_ctx* ctx);   /* the current value; -1 for a null ctx */
 
+/* Into how many blocks of proof indices the most recent zkp_range_ni_{prove,verify}_batch call on HOST arrays was cut (1: the plain path —
+ * every input copied in, the kernels, every output copied out; more: copies of block k + 1 / k - 1 under the kernels of block k).
+ * $ZKP_HOST_CHUNKS at ctx create: unset or 1 = never cut (the default: on the boxes measured the copies are 2 % of a call and every extra launch
+ * has a tail of its own), N = N equal blocks, 0 = a quarter | the rest (verify), a quarter | half | a quarter (prove) for calls of 2048 proofs and more. */
+int32_t zkp_diag_last_host_blocks(zkp_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,7 @@
 repeats device 0: two contexts = two independent streams / scratch sets, which is exactly what two GPUs would be to the
 host side (block partition, one thread per context, slabs written into the caller's arrays).  Results must equal the
 single-context entry points and the oracle."""
+import sys
 import numpy as np
 import pytest
 
@@ -73,7 +74,6 @@ def test_multi_create_rejects_bad_device_list(zkp):
 
 def _build_c_example():
     import os
-import sys
     import subprocess
     src = os.path.join(H.ROOT, "examples", "multi_gpu_verify.c")
     exe = os.path.join(H.ROOT, "build", "multi_gpu_verify")

@@ -115,7 +115,8 @@ def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     assert np.array_equal(v, expect)
     vidx = sorted(set(idx) | set(bad[:3]) | {bad[-1]})
     vo = np.full(len(vidx), 9, np.uint8)
-    oracle.range_ni_verify(sub_batch(pb, vidx, n_bits).struct(), vo)
+    sv = sub_batch(pb, vidx, n_bits)                     # (kept alive across the call: struct() holds raw pointers into its arrays)
+    oracle.range_ni_verify(sv.struct(), vo)
     assert list(vo) == [int(v[b]) for b in vidx]
 
 

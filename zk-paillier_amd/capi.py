@@ -46,6 +46,7 @@ DIAG_EXPORTS = {
     "zkp_diag_basen_last": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     "zkp_diag_set_enc_form": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_enc_form": (C.c_int32, [C.c_void_p]),
+    "zkp_diag_last_host_blocks": (C.c_int32, [C.c_void_p]),
 }
 ENC_FORM_AUTO, ENC_FORM_N2, ENC_FORM_SHARED, ENC_FORM_ALWAYS = 0, 1, 2, 3
 ENC_FORMS = {"auto": ENC_FORM_AUTO, "n2": ENC_FORM_N2, "shared": ENC_FORM_SHARED, "basen": ENC_FORM_ALWAYS, "always": ENC_FORM_ALWAYS}
@@ -305,6 +306,10 @@ class Context:
     def set_enc_form(self, form):
         """which Paillier launches run in base-n form (include/zkp_hip_diag.h): "auto" | "n2" | "shared" | "basen" (= always), or the number"""
         self.check(self.lib.zkp_diag_set_enc_form(self.h, ENC_FORMS[form] if isinstance(form, str) else int(form)))
+
+    def last_host_blocks(self) -> int:
+        """proof blocks of the most recent RangeProofNi prove / verify call on host arrays (1: not cut)"""
+        return self.lib.zkp_diag_last_host_blocks(self.h)
 
     def enc_form(self) -> int:
         return self.lib.zkp_diag_enc_form(self.h)

@@ -51,6 +51,12 @@ struct zkp_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_busy = false;        // work forked onto `side` whose join has not been enqueued on `stream` yet (see ~Stage)
+  // copy stream + events of a host-pointer call that runs as a pipeline of proof blocks (Piped below); created on first use
+  hipStream_t copy = nullptr;
+  std::vector<hipEvent_t> ev_pipe;
+  bool copy_busy = false;        // copies enqueued on `copy` that nothing has waited for yet
+  int last_host_blocks = 0;      // proof blocks of the most recent RangeProofNi host-pointer call (1: the plain path)
+  int host_chunks = -1;          // $ZKP_HOST_CHUNKS at zkp_ctx_create: unset (-1) or 1 = a host-pointer call is one block, N = N equal blocks, 0 = uneven blocks (host_blocks)
   std::string err;
   DevBuf consts, consts2, table, scratch[48];
   DevBuf bn_ncst, bn_consts, bn_table, bn_expected, bn_raw;
@@ -210,6 +216,7 @@ struct Stage {
   // An error return between the fork onto the ctx's second stream and the join: the kernels there may still read the staging
   // blocks and the ctx scratch that the next call reuses — wait for them before anything is handed back.
   void join_side() {
+    if (c->copy_busy) { (void)hipStreamSynchronize(c->copy); c->copy_busy = false; }
     if (!c->side_busy) return;
     (void)hipStreamSynchronize(c->side);
     c->side_busy = false;
@@ -294,6 +301,91 @@ struct TimedRegion {
   }
   ~TimedRegion() { if (on) (void)hipEventRecord(c->ev[slot].second, c->stream); }
 };
+
+// ---- host-pointer calls of large batches: the copies run under the kernels -------------------------------------------------------
+// A host-pointer call copies every input in, runs the kernels, copies every output out, all on one stream.  Proofs are independent and the
+// batch is structure-of-arrays, so a block of proof indices is a contiguous slice of every array: such a call CAN be cut into a few blocks,
+// block k + 1 copied in and block k - 1 copied out on a second stream while the kernels of block k run (only the first block's inputs and the
+// last block's outputs stay exposed).  Measured on MI355X boxes of this pool (round 5, profiles/r05/host_pipeline/): pageable host arrays move
+// at ~30 GB/s, so the copies of a 4096-proof call are 25 - 35 ms of 1250 - 1700 ms, while every extra launch of the persistent Enc kernel
+// has a tail of its own (a quarter of the batch is 3 - 4 claims per wavefront): cut in 2 / 3 blocks the call is 20 - 45 ms SLOWER than whole.
+// So the library does not cut by itself; $ZKP_HOST_CHUNKS=N at ctx create (N equal blocks; 0 = a quarter | the rest | [a quarter]) is for hosts
+// whose copies are slow (no large BAR, a remote NUMA node, PCIe Gen3).  What round 4 read as 0.36 s of staging in the host API was the tails
+// and first-touch page faults of ITS four-chunk pipeline, fixed there (host/zkproofs.hpp: prove_batch).
+struct Piped {
+  zkp_ctx* c;
+  Stage& s;
+  struct Field { char* dev; const char* hin; char* hout; size_t per; };        // per: bytes per proof
+  std::vector<Field> f;
+  Piped(zkp_ctx* c_, Stage& s_) : c(c_), s(s_) {}
+  int32_t streams(size_t blocks) {
+    if (!c->copy) HIPCHK(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    while (c->ev_pipe.size() < 2 * blocks) {
+      hipEvent_t e;
+      HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->ev_pipe.push_back(e);
+    }
+    return ZKP_OK;
+  }
+  // an input array of `per` elements per proof: a device block for all of it, copied block by block (h2d)
+  template <class T> const T* in(const T* host, size_t per, size_t B) {
+    if (!host || s.st) return host;
+    char* d = (char*)s.take(per * B * sizeof(T));
+    if (!d) return nullptr;
+    f.push_back({d, (const char*)host, nullptr, per * sizeof(T)});
+    return (const T*)d;
+  }
+  // an output array: zeroed now (on the compute stream, ahead of every kernel), copied back block by block (d2h)
+  template <class T> T* out(T* host, size_t per, size_t B) {
+    if (!host || s.st) return host;
+    char* d = (char*)s.take(per * B * sizeof(T));
+    if (!d) return nullptr;
+    (void)hipMemsetAsync(d, 0, per * B * sizeof(T), c->stream);
+    f.push_back({d, nullptr, (char*)host, per * sizeof(T)});
+    return (T*)d;
+  }
+  // inputs of proofs [lo, hi) on the copy stream; event `ev` says they are resident
+  int32_t h2d(size_t lo, size_t hi, hipEvent_t ev) {
+    for (const Field& x : f)
+      if (x.hin) HIPCHK(c, hipMemcpyAsync(x.dev + lo * x.per, x.hin + lo * x.per, (hi - lo) * x.per, hipMemcpyHostToDevice, c->copy));
+    c->copy_busy = true;
+    HIPCHK(c, hipEventRecord(ev, c->copy));
+    return ZKP_OK;
+  }
+  // outputs of proofs [lo, hi) once the kernels behind `done` (recorded on the compute stream) have finished
+  int32_t d2h(size_t lo, size_t hi, hipEvent_t done) {
+    HIPCHK(c, hipStreamWaitEvent(c->copy, done, 0));
+    for (const Field& x : f)
+      if (x.hout) HIPCHK(c, hipMemcpyAsync(x.hout + lo * x.per, x.dev + lo * x.per, (hi - lo) * x.per, hipMemcpyDeviceToHost, c->copy));
+    c->copy_busy = true;
+    return ZKP_OK;
+  }
+  int32_t finish() {
+    const hipError_t e = hipStreamSynchronize(c->copy);
+    c->copy_busy = false;
+    if (e != hipSuccess) { c->err = "copy stream sync"; return ZKP_EDEVICE; }
+    return ZKP_OK;
+  }
+};
+
+// The blocks of a host-pointer call of B proofs of `rows` rows each (empty: one block, the plain path).  first_small: the exposed copy is
+// the first block's input (verify: [1/4, 3/4]); else both ends are exposed (prove: inputs in, ciphertexts and responses out: [1/4, 1/2, 1/4]).
+static std::vector<size_t> host_blocks(const zkp_ctx* c, size_t B, size_t rows, bool first_small_only) {
+  std::vector<size_t> b;
+  if (c->host_chunks < 0 || c->host_chunks == 1) return b;              // the default: one block
+  if (c->host_chunks > 1) {
+    const size_t n = std::min<size_t>((size_t)c->host_chunks, B);
+    for (size_t k = 0; k <= n; k++) b.push_back(B * k / n);
+    return n > 1 ? b : std::vector<size_t>();
+  }
+  // 0: uneven blocks.  first_small_only: the exposed copy is the first block's input (verify: [1/4, 3/4]); else both ends are exposed
+  // (prove: inputs in, ciphertexts and responses out: [1/4, 1/2, 1/4])
+  if (B * rows < 2048ull * ZKP_SECURITY_PARAMETER) return b;          // below that a block would leave SIMDs idle (one claim per wavefront is 256 proofs)
+  const size_t q = (B / 4 + 63) & ~size_t(63);
+  if (first_small_only) b = {0, q, B};
+  else b = {0, q, B - q, B};
+  return b;
+}
 
 // ---- geometry helpers -----------------------------------------------------------------------
 // lanes per big integer: 72 / 144 / 288 limbs of 29 bits over W limbs per lane
@@ -534,6 +626,7 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
 #if ZKP_W == 36
   c->enc_form = enc_form_from_env();
 #endif
+  if (const char* hc = std::getenv("ZKP_HOST_CHUNKS")) c->host_chunks = std::atoi(hc);
   c->owns_stream = own_stream;
   c->stream = stream;
   if (own_stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKP_EDEVICE; }
@@ -588,6 +681,8 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   if (c->setup_flag) (void)hipFree(c->setup_flag);
   if (c->setup_flag_host) (void)hipHostFree(c->setup_flag_host);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
+  for (hipEvent_t e : c->ev_pipe) (void)hipEventDestroy(e);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -693,6 +788,7 @@ extern "C" int32_t zkp_diag_set_enc_form(zkp_ctx* c, int32_t form) try {
   return ZKP_OK;
 } ZKP_CATCH(c)
 extern "C" int32_t zkp_diag_enc_form(zkp_ctx* c) { return c ? c->enc_form : -1; }
+extern "C" int32_t zkp_diag_last_host_blocks(zkp_ctx* c) { return c ? c->last_host_blocks : -1; }
 
 extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) try {
   if (!c) return ZKP_EINVAL;

@@ -23,6 +23,8 @@
 // Every modular exponentiation runs on the GPU; this layer only samples, hashes small transcripts
 // (NiCorrectKeyProof::proof's MGF), converts BigInt <-> limbs and flattens proofs into batches.
 #pragma once
+#include <sys/mman.h>
+
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -111,11 +113,25 @@ template <class F> inline void parallel_for(size_t count, F body, unsigned max_t
   if (first) std::rethrow_exception(first);
 }
 // staging memory that is written in full before it is read (by to_limbs, or by the GPU call): NOT value-initialised — a
-// std::vector would memset (and page-fault) 2 GB per 4096-proof call on one thread before the work starts
+// std::vector would memset (and page-fault) 2 GB per 4096-proof call on one thread before the work starts.  Large buffers are 2 MB
+// aligned and marked for transparent huge pages: what such a buffer costs is its first touch (a quarter of a million 4 KB faults per
+// gigabyte — the D2H copy of a prove call took 125 ms longer into fresh memory than into touched memory, round 5), and a huge page is
+// one fault per 2 MB where the kernel grants it.
 template <class T> struct RawBuf {
-  std::unique_ptr<T[]> p;
-  explicit RawBuf(size_t n) : p(new T[n ? n : 1]) {}
-  T* data() { return p.get(); }
+  T* p = nullptr;
+  explicit RawBuf(size_t n) {
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (bytes >= (size_t(4) << 20)) {
+      const size_t huge = size_t(2) << 20, rounded = (bytes + huge - 1) & ~(huge - 1);
+      p = static_cast<T*>(std::aligned_alloc(huge, rounded));
+      if (p) (void)madvise(p, rounded, MADV_HUGEPAGE);
+    } else p = static_cast<T*>(std::malloc(bytes));
+    if (!p) throw std::bad_alloc();
+  }
+  RawBuf(const RawBuf&) = delete;
+  RawBuf& operator=(const RawBuf&) = delete;
+  ~RawBuf() { std::free(p); }
+  T* data() { return p; }
   T& operator[](size_t i) { return p[i]; }
   const T& operator[](size_t i) const { return p[i]; }
 };
@@ -268,16 +284,24 @@ class RangeProofNi {
   struct Statement { BigInt range, ciphertext, secret_x, secret_r; };
 
   // range_proof_ni.rs:47-82 for many provers sharing one key; randomness sampled as range_proof.rs:133-159.
-  // Large batches run as a PIPELINE of up to 4 chunks (>= 1024 proofs each): while the GPU proves chunk k (a blocking C-ABI call on
-  // host buffers), a helper thread samples + flattens chunk k+1 and rebuilds the proof objects of chunk k-1, so that of the host
-  // work only the first chunk's sampling and the last chunk's rebuild stay on the critical path (one extra launch tail of ~38 ms per
-  // extra chunk at n = 2048).  ZKP_HOST_PIPELINE=0 proves the batch in one call.
+  // ONE GPU call per batch (round 5; rounds 3 - 4 ran a pipeline of 4 chunks to hide the rebuild of the proof objects behind the next
+  // chunk's call — and paid a launch tail and a copy per chunk for it: 2022 ms of GPU calls against 1794 ms for one call at B = 4096,
+  // measured on one box).  What made the rebuild expensive was never the copying of 0.8 GB of limbs but the first touch of the heap
+  // they go to (3 million small allocations, a quarter of a million page faults): so the proof objects are ALLOCATED AND TOUCHED WHILE
+  // THE GPU WORKS (`prealloc`: every BigInt of every proof at its full capacity, on a few helper threads under the blocking call), and
+  // after the call `fill` only copies limbs into memory that is already there, on all threads.  ZKP_HOST_PIPELINE=N (N > 1) still cuts
+  // the batch into N calls — the next chunk's sampling and the previous chunk's fill then run under a call as well.
   // chunks of a pipelined batch call: ZKP_HOST_PIPELINE = 0 / 1 (one call) or N (up to N chunks of >= 1024 proofs); default `dflt`
   static size_t pipeline_chunks(size_t B, size_t dflt) {
     const char* pe = std::getenv("ZKP_HOST_PIPELINE");
     size_t want = dflt;
     if (pe && pe[0] >= '0' && pe[0] <= '9') want = std::max<size_t>(1, (size_t)std::atoi(pe));
     return std::max<size_t>(1, std::min<size_t>(want, B / 1024));
+  }
+  // the staging buffers of a finished call (2.2 GB at B = 4096) go back to the OS on a thread of their own: unmapping them is tens of
+  // milliseconds that the caller need not wait for
+  template <class Chunks> static void release_later(Chunks&& chunks) {
+    try { std::thread([held = std::move(chunks)]() mutable { held.clear(); }).detach(); } catch (...) {}     // (no thread: freed here, by `chunks` going out of scope)
   }
   struct ProveChunk {
     size_t lo, hi;
@@ -297,7 +321,7 @@ class RangeProofNi {
     ek.n.to_limbs(n.data(), kw);
     HostTiming& tm = last_host_timing();
     tm = HostTiming(); tm.proofs = B; tm.threads = host_threads();
-    const size_t chunks = pipeline_chunks(B, 4);
+    const size_t chunks = pipeline_chunks(B, 1);
     std::vector<RangeProofNi> out(B);
 
     // stage A: sample (range_proof.rs:133-159) and flatten the statements of a chunk
@@ -323,31 +347,45 @@ class RangeProofNi {
       zkp_range_ni_witness w{c.x.data(), c.r.data(), c.w1.data(), c.w2.data(), c.r1.data(), c.r2.data()};
       e.check(zkp_range_ni_prove_batch(e.ctx(), &p, &w, nullptr, nullptr, c.status.data(), 0), "zkp_range_ni_prove_batch");
     };
-    // stage C: the proof objects of a chunk (0.19 MB each: bound by first-touch page faults, more than 2 threads only contend for
-    // the address space — measured at 4096 proofs: 16 threads 674 ms, one 377 ms)
-    auto rebuild = [&](ProveChunk& c) {
+    // stage C1, under the GPU call: the proof objects of the chunk at their final shape — every BigInt allocated at full capacity and
+    // zero-filled (the first touch of its pages).  Which rows will be Open and which Mask is not known yet: every row gets the four
+    // fields of an Open response; `fill` moves two of them over for a Mask row and lets the other two go.
+    // (more than a few threads only contend for the address space: measured round 4, 16 threads 674 ms against one 377 ms)
+    auto prealloc = [&](ProveChunk& c, unsigned max_threads) {
       parallel_for(c.hi - c.lo, [&](size_t k) {
-        const size_t b = c.lo + k;
+        RangeProofNi& o = out[c.lo + k];
+        o.ek = ek; o.range = st[c.lo + k].range; o.ciphertext = st[c.lo + k].ciphertext; o.error_factor = EF;
+        o.encrypted_pairs.c1.resize(EF); o.encrypted_pairs.c2.resize(EF); o.proof.responses.resize(EF);
+        for (size_t i = 0; i < EF; i++) {
+          o.encrypted_pairs.c1[i].l.resize(2 * kw); o.encrypted_pairs.c2[i].l.resize(2 * kw);
+          Response& rs = o.proof.responses[i];
+          rs.w1.l.resize(kw); rs.r1.l.resize(kw); rs.w2.l.resize(kw); rs.r2.l.resize(kw);
+        }
+      }, max_threads);
+    };
+    // stage C2, after the call: limbs into the memory that is already there (no allocation, no page fault: a copy at memory bandwidth)
+    auto take = [](BigInt& dst, const uint32_t* p, size_t n) { while (n && p[n - 1] == 0) n--; dst.l.assign(p, p + n); dst.neg = false; };
+    auto fill = [&](ProveChunk& c, unsigned max_threads) {
+      parallel_for(c.hi - c.lo, [&](size_t k) {
         if (c.status[k] != 0) throw Panic("RangeProofNi::prove: malformed (the reference would panic)");
-        RangeProofNi& o = out[b];
-        o.ek = ek; o.range = st[b].range; o.ciphertext = st[b].ciphertext; o.error_factor = EF;
-        o.encrypted_pairs.c1.reserve(EF); o.encrypted_pairs.c2.reserve(EF); o.proof.responses.reserve(EF);
+        RangeProofNi& o = out[c.lo + k];
         for (size_t i = 0; i < EF; i++) {
           const size_t t = k * EF + i;
-          o.encrypted_pairs.c1.push_back(BigInt::from_limbs(&c.c1[t * 2 * kw], 2 * kw));
-          o.encrypted_pairs.c2.push_back(BigInt::from_limbs(&c.c2[t * 2 * kw], 2 * kw));
-          Response rs;
+          take(o.encrypted_pairs.c1[i], &c.c1[t * 2 * kw], 2 * kw);
+          take(o.encrypted_pairs.c2[i], &c.c2[t * 2 * kw], 2 * kw);
+          Response& rs = o.proof.responses[i];
+          take(rs.w1, &c.rw1[t * kw], kw); take(rs.r1, &c.rr1[t * kw], kw);
           if (c.kind[t] == ZKP_RESP_OPEN) {
             rs.kind = Response::Open;
-            rs.w1 = BigInt::from_limbs(&c.rw1[t * kw], kw); rs.r1 = BigInt::from_limbs(&c.rr1[t * kw], kw);
-            rs.w2 = BigInt::from_limbs(&c.rw2[t * kw], kw); rs.r2 = BigInt::from_limbs(&c.rr2[t * kw], kw);
+            take(rs.w2, &c.rw2[t * kw], kw); take(rs.r2, &c.rr2[t * kw], kw);
           } else {
             rs.kind = Response::Mask; rs.j = c.jj[t];
-            rs.masked_x = BigInt::from_limbs(&c.rw1[t * kw], kw); rs.masked_r = BigInt::from_limbs(&c.rr1[t * kw], kw);
+            rs.masked_x = std::move(rs.w1); rs.masked_r = std::move(rs.r1);
+            rs.w1.l.clear(); rs.r1.l.clear(); rs.w2.l.clear(); rs.r2.l.clear();      // (zero; w2 / r2 keep their 2 x 256 B: a free() here goes to the
+                                                                                      //  allocating thread's arena and 16 threads queue for its lock)
           }
-          o.proof.responses.push_back(std::move(rs));
         }
-      }, 2);
+      }, max_threads);
     };
 
     std::vector<std::unique_ptr<ProveChunk>> ch(chunks);
@@ -360,11 +398,13 @@ class RangeProofNi {
       std::exception_ptr helper_error;
       std::thread helper([&, k] {
         try {
+          const unsigned few = std::max(1u, std::min(4u, host_threads() / 2));
+          prealloc(*ch[k], few);                    // the objects this call's outputs will go to
           if (k + 1 < chunks) {                     // next chunk's inputs, on a few threads: the GPU call only waits
             ch[k + 1].reset(new ProveChunk(bounds(k + 1).first, bounds(k + 1).second, kw, EF));
             sample_flatten(*ch[k + 1], std::max(1u, host_threads() / 2));
           }
-          if (k > 0) { rebuild(*ch[k - 1]); ch[k - 1].reset(); }
+          if (k > 0) { fill(*ch[k - 1], std::max(1u, host_threads() / 2)); ch[k - 1].reset(); }
         } catch (...) { helper_error = std::current_exception(); }
       });
       StopWatch g;
@@ -374,11 +414,11 @@ class RangeProofNi {
       if (helper_error) std::rethrow_exception(helper_error);
     }
     sw.lap();
-    rebuild(*ch[chunks - 1]);
+    fill(*ch[chunks - 1], ~0u);
     tm.rebuild_ms = sw.lap();
+    release_later(std::move(ch));
     return out;
   }
-
   static RangeProofNi prove(const EncryptionKey& ek, const BigInt& range, const BigInt& ciphertext, const BigInt& secret_x, const BigInt& secret_r) {
     return prove_batch(ek, {Statement{range, ciphertext, secret_x, secret_r}})[0];
   }
@@ -431,11 +471,11 @@ class RangeProofNi {
     tm.general_proofs = general.size();
     std::vector<Result> out(B, Result(false));
     if (!fast.empty()) {
-      // The batch CAN run as a pipeline of chunks like prove_batch (ZKP_HOST_PIPELINE=N: while the GPU verifies chunk k, a helper thread
-      // flattens chunk k + 1), but by default it does not: measured at B = 4096, n = 2048 with the base-n kernels (one box, 1 / 2 / 3 / 4
-      // chunks): 2711 / 2694 / 2687 / 2439 verifies/s — the host work a chunk hides (88 ms of flattening in all) is less than the tail
-      // of the GPU launches it adds (a launch of 1024 proofs is 3 claims per wavefront).  prove_batch gains from 4 chunks (1756 -> 1930
-      // proofs/s): it hides 360 ms of rebuilding proof objects.
+      // ONE GPU call by default.  The batch CAN run as a pipeline of chunks (ZKP_HOST_PIPELINE=N: while the GPU verifies chunk k, a helper
+      // thread flattens chunk k + 1; ZKP_HOST_PIPELINE=0: a quarter, then the rest), but what a chunk hides is small — flattening 0.78 GB of
+      // received proofs takes 13 ms on 16 threads now that the staging memory is huge-page backed (95 ms in round 4: first-touch faults) —
+      // and every extra launch has a tail of its own.  B = 4096, one box, round 5: one call 3025 verifies/s, a quarter + the rest 2940,
+      // 2 / 4 equal chunks 2938 / 2650.
       const size_t F = fast.size();
       struct VerifyChunk {
         size_t lo, hi;
@@ -448,7 +488,9 @@ class RangeProofNi {
       };
       RawBuf<uint32_t> n(kw);
       ek.n.to_limbs(n.data(), kw);
-      const size_t chunks = pipeline_chunks(F, 1);
+      const char* pipe_env = std::getenv("ZKP_HOST_PIPELINE");
+      const bool uneven = pipe_env && pipe_env[0] == '0' && F >= 2048;
+      const size_t chunks = uneven ? 2 : pipeline_chunks(F, 1);
       auto flatten = [&](VerifyChunk& c, unsigned max_threads) {
         parallel_for(c.hi - c.lo, [&](size_t k) {
           const RangeProofNi& p = *proofs[fast[c.lo + k]];
@@ -474,7 +516,10 @@ class RangeProofNi {
         e.check(zkp_range_ni_verify_batch(e.ctx(), &p, c.verdict.data(), 0), "zkp_range_ni_verify_batch");
       };
       std::vector<std::unique_ptr<VerifyChunk>> ch(chunks);
-      auto bounds = [&](size_t k) { return std::make_pair(F * k / chunks, F * (k + 1) / chunks); };
+      auto bounds = [&](size_t k) {
+        if (uneven) return k == 0 ? std::make_pair(size_t(0), F / 4) : std::make_pair(F / 4, F);
+        return std::make_pair(F * k / chunks, F * (k + 1) / chunks);
+      };
       ch[0].reset(new VerifyChunk(bounds(0).first, bounds(0).second, kw, EF));
       flatten(*ch[0], ~0u);
       tm.sample_flatten_ms = sw.lap();
@@ -500,6 +545,7 @@ class RangeProofNi {
           out[fast[f]] = v == ZKP_VERDICT_MALFORMED ? Result::panicked("RangeProofNi::verify: malformed proof (the reference would panic)") : Result(v == ZKP_VERDICT_ACCEPT);
         }
       }
+      release_later(std::move(ch));
       sw.lap();
     }
     if (!general.empty()) {
