@@ -48,6 +48,14 @@ int32_t zkp_diag_enc_form(zkp_ctx* ctx);   /* the current value; -1 for a null c
  * has a tail of its own), N = N equal blocks, 0 = a quarter | the rest (verify), a quarter | half | a quarter (prove) for calls of 2048 proofs and more. */
 int32_t zkp_diag_last_host_blocks(zkp_ctx* ctx);
 
+/* The latency engine's kernel for calls of a few proofs under one 2048-bit key: ONE Enc per wavefront, the base-n exponentiation as a
+ * right-to-left ladder pipelined over five lane groups (csrc/kernels_basen_r2l.hpp).  mode 0 = never (the pair ladder on the n^2-sized
+ * product serves those calls, as before round 5), 1 = the library's rule (launches of up to two wavefronts per SIMD; the default),
+ * 2 = every launch the kernel can take (tests).  $ZKP_R2L presets it at ctx create.  zkp_diag_r2l_last: 1 when the most recent Paillier
+ * launch of the ctx ran on it. */
+int32_t zkp_diag_set_r2l(zkp_ctx* ctx, int32_t mode);
+int32_t zkp_diag_r2l_last(zkp_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,21 +48,25 @@ def oracle():
 
 
 # (engine = limbs per lane, Enc form on the throughput engine)
-_CTX_PARAMS = [(36, "basen"), (36, "n2"), (9, None)]
+_CTX_PARAMS = [(36, "basen"), (36, "n2"), (9, None), (9, "pair")]
 
 
-@pytest.fixture(scope="session", params=_CTX_PARAMS, ids=["w36-basen", "w36-n2", "w9"])
+@pytest.fixture(scope="session", params=_CTX_PARAMS, ids=["w36-basen", "w36-n2", "w9", "w9-pair"])
 def ctx(zkp, request):
     """one GPU context for the whole -m gpu session; fails loudly without GPU / built library.  Every test that takes it runs
     three times: pinned to the throughput engine (36 limbs per lane) with every Paillier launch in BASE-n form (csrc/kernels_basen.hpp —
     the kernels that carry the large batches), pinned to it with every launch on the n^2-sized kernels (the product's choice for launches
-    that leave SIMDs idle, for keys the form does not take, and for n = 1024), and pinned to the latency engine (9; libzkp_hip_lat.so) —
+    that leave SIMDs idle, for keys the form does not take, and for n = 1024), pinned to the latency engine (9; libzkp_hip_lat.so) with its own
+    rules (one 2048-bit key and a few proofs: the one-Enc-per-wavefront base-n ladder of csrc/kernels_basen_r2l.hpp), and pinned to it with
+    that ladder off (the pair ladder on the n^2-sized product, which still serves per-proof keys and 4096-bit keys) —
     left to itself the library would send these small batches to the latency engine only (tests/test_gpu_geometry.py covers that;
     tests/test_gpu_routing.py covers the library's own choice between the two forms at the sizes where it flips)."""
     geometry, form = request.param
     c = zkp.Context(0)
     c.set_geometry(geometry)               # raises when the engine is not loaded
-    if form is not None:
+    if form == "pair":
+        c.set_r2l(0)
+    elif form is not None:
         c.set_enc_form(form)
     c.test_geometry = geometry
     c.test_form = form

@@ -29,14 +29,22 @@ def odd_modulus(rnd, bits):
     return rnd.getrandbits(bits) | 1 | (1 << (bits - 1))
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    """a context of its own: the batches here are small, so every Paillier launch is told to take the base-n form (left to itself the
-    library keeps them on the n^2-sized kernels: launch_basen's routing rule, tests/test_gpu_routing.py)"""
+@pytest.fixture(scope="module", params=[36, 9], ids=["w36", "w9"])
+def ctx(request):
+    """a context of its own per engine — the form exists at 36 limbs per lane (2 / 4 lanes per n-sized integer, the kernels of the large
+    batches) and at 9 (8 / 16 lanes, the latency engine: the kernels of the mid-size batches).  The batches here are small, so every
+    Paillier launch is told to take the form (left to itself the library keeps them on the n^2-sized kernels: launch_basen's routing
+    rule, tests/test_gpu_routing.py)"""
     c = zkp.Context(0)
+    c.set_geometry(request.param)
     c.set_enc_form("basen")
+    c.test_geometry = request.param
     yield c
     c.close()
+
+
+def lanes_per_integer(ctx, n_bits):
+    return (72 // ctx.test_geometry) * (n_bits // 2048)
 
 
 @pytest.mark.parametrize("n_bits", [2048, 4096])
@@ -105,8 +113,9 @@ def test_enc_batch_equals_python_and_the_n2_sized_kernels(ctx, n_bits):
     mw = np.stack([words(v, kw) for v in ms])
     rw = np.stack([words(v, kw) for v in rs])
     out = np.zeros((count, 2 * kw), np.uint32)
-    ctx.set_geometry(zkp.load().zkp_build_limbs_per_lane())    # the throughput engine (a 70-item call would go to the latency engine)
     ctx.paillier_enc(n_bits, count, nw, 0, mw, rw, out)
+    lanes, ok = ctx.diag_basen_last()
+    assert lanes == lanes_per_integer(ctx, n_bits) and ok, "the launch should have run in base-n form"
     for i in range(count):
         got = sum(int(w) << (32 * j) for j, w in enumerate(out[i]))
         assert got == (1 + ms[i] * n) * pow(rs[i], n, nn) % nn, i
@@ -130,7 +139,6 @@ def test_enc_batch_equals_python_and_the_n2_sized_kernels(ctx, n_bits):
     ok = np.full(count, 9, np.uint8)
     ctx.paillier_enc_check(n_bits, count, nw, 0, mw, rw, aw, bw, None, ok)
     assert list(ok) == [0 if i == 8 else 1 for i in range(count)]
-    ctx.set_geometry(0)
 
 
 @pytest.mark.parametrize("n_bits", [2048, 4096])
@@ -147,26 +155,125 @@ def test_enc_batch_with_per_item_keys_equals_python(ctx, n_bits):
     mw = np.stack([words(v, kw) for v in ms])
     rw = np.stack([words(v, kw) for v in rs])
     out = np.zeros((count, 2 * kw), np.uint32)
-    ctx.set_geometry(zkp.load().zkp_build_limbs_per_lane())
     ctx.paillier_enc(n_bits, count, nw, kw, mw, rw, out)
     lanes, ok = ctx.diag_basen_last()
-    assert lanes == n_bits // 1024 and ok, "the per-key launch should have run in base-n form"
+    assert lanes == lanes_per_integer(ctx, n_bits) and ok, "the per-key launch should have run in base-n form"
     for i in range(count):
         n = ns[i]
         got = sum(int(w) << (32 * j) for j, w in enumerate(out[i]))
         assert got == (1 + ms[i] * n) * pow(rs[i], n, n * n) % (n * n), i
-    # one key that does not qualify (even) sends the WHOLE launch to the n^2-sized kernels: same answers for the others, zeros for it
+    # keys the form does not take are PARTITIONED off, item by item (round 5; round 4 sent the whole launch to the n^2-sized kernels):
+    # a short key (1000 bits in the 2048-bit context: no room for the b parts) — its item comes back right from the n^2-sized launch behind
     ns2 = list(ns)
-    ns2[3] -= 1
-    nw2 = np.stack([words(v, kw) for v in ns2])
+    ns2[5] = odd_modulus(rnd, n_bits // 2 - 24)
+    ms2 = list(ms); ms2[5] = ms[5] % ns2[5]
     out2 = np.zeros((count, 2 * kw), np.uint32)
-    try:
-        ctx.paillier_enc(n_bits, count, nw2, kw, mw, rw, out2)
-    except zkp.ZkpError:
-        pass                                                   # (the entry point reports the even modulus; the outputs of the others are written)
+    ctx.paillier_enc(n_bits, count, np.stack([words(v, kw) for v in ns2]), kw, np.stack([words(v, kw) for v in ms2]), rw, out2)
     lanes, ok = ctx.diag_basen_last()
-    assert lanes == n_bits // 1024 and not ok
+    assert lanes == lanes_per_integer(ctx, n_bits) and not ok          # (the batch-wide flag: not every key qualified)
+    for i in range(count):
+        n = ns2[i]
+        got = sum(int(w) << (32 * j) for j, w in enumerate(out2[i]))
+        assert got == (1 + ms2[i] * n) * pow(rs[i], n, n * n) % (n * n), i
+    # an even key: the entry point reports it (no Montgomery form exists), the other items are done and equal to the clean batch's
+    ns3 = list(ns)
+    ns3[3] -= 1
+    out3 = np.zeros((count, 2 * kw), np.uint32)
+    try:
+        ctx.paillier_enc(n_bits, count, np.stack([words(v, kw) for v in ns3]), kw, mw, rw, out3)
+    except zkp.ZkpError:
+        pass
     for i in range(count):
         if i != 3:
-            assert np.array_equal(out2[i], out[i]), i
-    ctx.set_geometry(0)
+            assert np.array_equal(out3[i], out[i]), i
+
+
+def test_range_proofs_under_per_proof_keys_with_keys_outside_the_form(oracle):
+    """RangeProofNi prove + verify of a batch with per-proof keys in which two keys do not qualify for the base-n form (short ones): the
+    base-n launch takes the other proofs' rows, the n^2-sized launch behind it the rows of those two — transcripts and verdicts against the
+    oracle (range_proof.rs:270-348: every proof under its own ek)"""
+    import importlib
+    synth = importlib.import_module("zk-paillier_amd.synth")
+    n_bits, B = 2048, 24
+    keys = synth.distinct_keys_2048(B)
+    keys[4] = H.test_key(1000, tag=1)[2]
+    keys[17] = H.test_key(1024, tag=2)[2]
+    cases = H.build_range_case(b"partition", keys, n_bits, B, shared=False)
+    oracle.set_threads(min(16, oracle.max_threads()))
+    pb_o, wt = H.fill_batch(cases, n_bits, False, oracle)
+    oracle.range_ni_prove(pb_o.struct(), wt.struct(), None, None, None)
+    c = zkp.Context(0)
+    try:
+        for geometry in (36, 9):
+            c.set_geometry(geometry)
+            c.set_enc_form("basen")
+            pb = zkp.RangeBatch(n_bits, B, 128, shared_key=False)
+            pb.n[:] = pb_o.n; pb.range[:] = pb_o.range; pb.ciphertext[:] = pb_o.ciphertext
+            c.range_ni_prove(pb.struct(), wt.struct(), None, None, None, device=False)
+            lanes, ok = c.diag_basen_last()
+            assert lanes == (72 // geometry) and not ok, (geometry, lanes, ok)
+            for f in ("c1", "c2", "resp_kind", "resp_j", "resp_w1", "resp_r1", "resp_w2", "resp_r2"):
+                assert np.array_equal(getattr(pb_o, f), getattr(pb, f)), (geometry, f)
+            pb.resp_r1[4, 9, 0] ^= 1; pb.resp_r1[5, 9, 0] ^= 1; pb.c1[17, 100, 3] ^= 2
+            vo = np.full(B, 9, np.uint8); vg = np.full(B, 9, np.uint8)
+            oracle.range_ni_verify(pb.struct(), vo)
+            c.range_ni_verify(pb.struct(), vg, device=False)
+            assert list(vg) == list(vo) and list(vo) == [0 if b in (4, 5, 17) else 1 for b in range(B)]
+    finally:
+        c.close()
+
+
+def test_one_enc_per_wavefront_ladder_of_the_latency_engine():
+    """csrc/kernels_basen_r2l.hpp: the base-n exponentiation as a right-to-left ladder pipelined over five lane groups, the latency engine's
+    kernel for calls of a few proofs under one 2048-bit key (tests/test_basen_r2l_model.py states the pipeline on values): Enc against
+    Python's pow() with the operand edge cases, Enc-and-compare with plain and product expectations, keys at the edges of the form, and
+    the same items through the pair ladder it replaces (set_r2l(0))."""
+    import math
+    rnd = random.Random(99)
+    n_bits, kw = 2048, 64
+    c = zkp.Context(0)
+    try:
+        c.set_geometry(9)
+        for trial, n in enumerate((odd_modulus(rnd, 2048), odd_modulus(rnd, 2047), H.fixture_key()[2], odd_modulus(rnd, 1200))):
+            nn = n * n
+            count = 37 if trial else 300                          # one launch of more than a wavefront per SIMD-quarter, then small ones
+            ms = [rnd.randrange(n) for _ in range(count)]
+            rs = [rnd.getrandbits(n_bits) for _ in range(count)]
+            ms[0], rs[0] = 0, 1
+            ms[1], rs[1] = n - 1, n - 1
+            ms[2], rs[2] = (1 << n_bits) - 1, (1 << n_bits) - 1
+            ms[3], rs[3] = 5, 0
+            ms[4], rs[4] = 7, n
+            ms[5], rs[5] = n, n + 1
+            nw = words(n, kw)
+            mw = np.stack([words(v, kw) for v in ms]); rw = np.stack([words(v, kw) for v in rs])
+            outs = []
+            for mode in (2, 0):                                     # the ladder whenever it can run; never (the pair ladder / window ladder on n^2)
+                c.set_r2l(mode)
+                out = np.zeros((count, 2 * kw), np.uint32)
+                c.paillier_enc(n_bits, count, nw, 0, mw, rw, out)
+                assert c.last_geometry() == 9 and c.r2l_last() == (mode == 2), (trial, mode)
+                outs.append(out)
+            assert np.array_equal(outs[0], outs[1])
+            for i in range(count):
+                got = sum(int(w) << (32 * j) for j, w in enumerate(outs[0][i]))
+                assert got == (1 + ms[i] * n) * pow(rs[i], n, nn) % nn, (trial, i)
+            c.set_r2l(2)
+            exp = outs[0].copy(); exp[6, 5] ^= 1
+            ok = np.full(count, 9, np.uint8)
+            c.paillier_enc_check(n_bits, count, nw, 0, mw, rw, None, None, exp, ok)
+            assert c.r2l_last() and list(ok) == [0 if i == 6 else 1 for i in range(count)]
+            bs = []
+            while len(bs) < count:
+                v = rnd.randrange(2, nn)
+                if math.gcd(v, n) == 1:
+                    bs.append(v)
+            a_ = [(sum(int(w) << (32 * j) for j, w in enumerate(outs[0][i])) * pow(bs[i], -1, nn)) % nn for i in range(count)]
+            a_[8] = (a_[8] + 1) % nn
+            ok = np.full(count, 9, np.uint8)
+            c.paillier_enc_check(n_bits, count, nw, 0, mw, rw, np.stack([words(v, 2 * kw) for v in a_]), np.stack([words(v, 2 * kw) for v in bs]), None, ok)
+            assert c.r2l_last() and list(ok) == [0 if i == 8 else 1 for i in range(count)]
+        # a key the form does not take (even): the launch behind the ladder does the work, the answers are those of the n^2-sized kernels
+        c.set_r2l(1)
+    finally:
+        c.close()

@@ -1,9 +1,11 @@
 """The library's OWN choice of kernels — nothing pinned, $ZKP_BASEN not set — at the batch sizes where it flips, against the oracle.
 
-A RangeProofNi call at n = 2048 is served by one of three kernel families (csrc/zkp_api.hip: route_latency, launch_basen):
-  * the latency engine (9 limbs per lane, libzkp_hip_lat.so) while the call is a few proofs,
-  * the n^2-sized throughput kernels (k_enc<4, .>) while a launch still leaves SIMDs idle,
-  * the base-n kernels (k_enc_basen<2>, 32 Enc per wavefront) from there on.
+A RangeProofNi call at n = 2048 under one key is served by one of these kernel families (csrc/zkp_api.hip: route_latency, launch_basen):
+  * the latency engine (9 limbs per lane, libzkp_hip_lat.so) up to 96 proofs: ONE Enc per wavefront on the five-group base-n ladder
+    (k_enc_basen_r2l) up to 8 proofs, the window ladder on the n^2-sized product up to 16, 8 Enc per wavefront in base-n form
+    (k_enc_basen<8>) from there on,
+  * the throughput engine's base-n kernels (k_enc_basen<2>, 32 Enc per wavefront) beyond,
+  * its n^2-sized kernels (k_enc<4, .>) for keys the form does not take and for launches pinned to that engine that leave SIMDs idle.
 The parity suites pin each family in turn (tests/conftest.py: ctx); this file lets the library choose, says which family it expects for
 every size (zkp_ctx_last_geometry, zkp_diag_basen_last), and checks prove transcripts and verdict vectors against the C/GMP oracle on
 samples of every batch — and against the OTHER form's bytes for the whole batch."""
@@ -36,17 +38,23 @@ def compute_units():
 
 
 def expected_family(c, items):
-    """what csrc/zkp_api.hip is expected to pick for a Paillier launch of `items` Enc under one 2048-bit key"""
+    """what csrc/zkp_api.hip is expected to pick for a Paillier launch of `items` Enc under ONE 2048-bit key that the base-n form takes
+    (route_latency with one_key_paillier, launch_basen of either engine)"""
     lat = c.latency_limbs_per_lane()
     cus = compute_units()
-    if lat and 2 * items <= (5 * 4 * cus * 64) // (144 // lat):
-        return "latency"
+    if lat == 9 and items <= 3 * 4 * cus * 8:                  # the latency engine: up to three wavefronts per SIMD at 8 Enc per wavefront
+        if items <= 2 * 4 * cus:
+            return "lat-r2l"                                   # one Enc per wavefront, the five-group ladder (kernels_basen_r2l.hpp)
+        return "lat-basen" if items > 4 * cus * 4 else "lat-n2"
     return "base-n" if items > 4 * cus * 16 else "n2"
 
 
 def family_that_ran(c):
     if c.last_geometry() != zkp.load().zkp_build_limbs_per_lane():
-        return "latency"
+        if c.r2l_last():
+            return "lat-r2l"
+        lanes, ok = c.diag_basen_last()
+        return "lat-basen" if (lanes == 8 and ok) else "lat-n2"
     lanes, ok = c.diag_basen_last()
     return "base-n" if (lanes == 2 and ok) else "n2"
 
@@ -60,7 +68,7 @@ def sub_batch(pb, idx, n_bits):
     return s
 
 
-@pytest.mark.parametrize("B", [32, 48, 64, 96, 300])
+@pytest.mark.parametrize("B", [4, 12, 32, 64, 96, 128, 300])
 def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     n_bits, kw = 2048, 64
     n = H.fixture_key()[2]
@@ -77,7 +85,7 @@ def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     assert family_that_ran(actx) == want, (B, family_that_ran(actx), want)
     assert not status.any()
     # the prove transcripts of a sample of the batch, byte for byte against the oracle
-    idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1})
+    idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1} & set(range(B)))
     so = sub_batch(pb_o, idx, n_bits)
     sw = zkp.make_range_witness(n_bits, len(idx))
     for k, b in enumerate(idx):
@@ -87,20 +95,19 @@ def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     for k, b in enumerate(idx):
         for f in FIELDS:
             assert np.array_equal(getattr(so, f)[k], getattr(pb, f)[b]), (B, b, f)
-    # the whole batch against the other kernels of the throughput engine (the same bytes whatever ran)
-    if want != "latency":
-        other = zkp.RangeBatch(n_bits, B, 128, shared_key=True)
-        other.n[:] = pb.n; other.range[:] = pb.range; other.ciphertext[:] = pb.ciphertext
-        actx.set_geometry(zkp.load().zkp_build_limbs_per_lane())
-        actx.set_enc_form("n2" if want == "base-n" else "basen")
-        actx.range_ni_prove(other.struct(), wt.struct(), None, None, None, device=False)
-        assert family_that_ran(actx) == ("n2" if want == "base-n" else "base-n")
-        for f in FIELDS:
-            assert np.array_equal(getattr(other, f), getattr(pb, f)), (B, f)
-        actx.set_geometry(0)
-        actx.set_enc_form("auto")
+    # the whole batch against other kernels: the throughput engine's n^2-sized ones (its base-n ones when those were the choice)
+    other = zkp.RangeBatch(n_bits, B, 128, shared_key=True)
+    other.n[:] = pb.n; other.range[:] = pb.range; other.ciphertext[:] = pb.ciphertext
+    actx.set_geometry(zkp.load().zkp_build_limbs_per_lane())
+    actx.set_enc_form("basen" if want == "n2" else "n2")
+    actx.range_ni_prove(other.struct(), wt.struct(), None, None, None, device=False)
+    assert family_that_ran(actx) == ("base-n" if want == "n2" else "n2")
+    for f in FIELDS:
+        assert np.array_equal(getattr(other, f), getattr(pb, f)), (B, f)
+    actx.set_geometry(0)
+    actx.set_enc_form("auto")
     # verify: every 7th proof tampered in one of three ways
-    bad = list(range(3, B, 7))
+    bad = list(range(3, B, 7)) or [B - 1]
     for k, b in enumerate(bad):
         if k % 3 == 0:
             pb.resp_r1[b, k % 128, 0] ^= 1

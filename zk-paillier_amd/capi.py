@@ -47,6 +47,8 @@ DIAG_EXPORTS = {
     "zkp_diag_set_enc_form": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_enc_form": (C.c_int32, [C.c_void_p]),
     "zkp_diag_last_host_blocks": (C.c_int32, [C.c_void_p]),
+    "zkp_diag_set_r2l": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "zkp_diag_r2l_last": (C.c_int32, [C.c_void_p]),
 }
 ENC_FORM_AUTO, ENC_FORM_N2, ENC_FORM_SHARED, ENC_FORM_ALWAYS = 0, 1, 2, 3
 ENC_FORMS = {"auto": ENC_FORM_AUTO, "n2": ENC_FORM_N2, "shared": ENC_FORM_SHARED, "basen": ENC_FORM_ALWAYS, "always": ENC_FORM_ALWAYS}
@@ -306,6 +308,13 @@ class Context:
     def set_enc_form(self, form):
         """which Paillier launches run in base-n form (include/zkp_hip_diag.h): "auto" | "n2" | "shared" | "basen" (= always), or the number"""
         self.check(self.lib.zkp_diag_set_enc_form(self.h, ENC_FORMS[form] if isinstance(form, str) else int(form)))
+
+    def set_r2l(self, mode: int):
+        """the latency engine's one-Enc-per-wavefront ladder: 0 = never, 1 = the library's rule, 2 = whenever it can run"""
+        self.check(self.lib.zkp_diag_set_r2l(self.h, mode))
+
+    def r2l_last(self) -> bool:
+        return self.lib.zkp_diag_r2l_last(self.h) == 1
 
     def last_host_blocks(self) -> int:
         """proof blocks of the most recent RangeProofNi prove / verify call on host arrays (1: not cut)"""

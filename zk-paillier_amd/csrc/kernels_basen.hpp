@@ -45,13 +45,16 @@ template <int G> struct BnConst {
 template <int G> struct BnLds {
   static constexpr int L = Geo<G>::L;
   static constexpr int OFF_A = 0, OFF_B = G * BLK;
-  static constexpr int WORDS = G == 2 ? 152 : 304;              // >= 2 G BLK + 3 (the limb scratch of the output conversion)
+  // W = 36: 152 / 304 words (strides of 38 / 76 units, above).  W = 9 (the latency build: 8 / 16 lanes per n-sized integer, BLK = 12 words):
+  // 2 G BLK + 8 = 200 / 392 words — 50 / 98 units, 2 mod 16: the 8 / 4 groups of a wavefront read the staged operand from distinct banks
+  static constexpr int WORDS = W == 36 ? (G == 2 ? 152 : 304) : 2 * G * BLK + 8;  // >= 2 G BLK + 3 (the limb scratch of the output conversion)
   static constexpr int NW2 = (L / 72) * 128;                    // 32-bit words of a value mod n^2
-  static_assert(G == 2 || G == 4, "group strides are chosen per geometry");
+  static_assert(W != 36 || G == 2 || G == 4, "group strides are chosen per geometry");
+  static_assert(L == 72 || L == 144, "an n-sized integer is 72 or 144 limbs");
   static_assert(NW2 + 8 <= WORDS && 2 * L + 3 <= WORDS && 2 * G * BLK <= WORDS, "conversion areas alias the operand areas");
   static constexpr int THREADS = 256;
   static constexpr int GROUPS_PER_BLOCK = THREADS / G;
-  static constexpr int BYTES_PER_BLOCK = (WORDS * GROUPS_PER_BLOCK + L) * 4;       // + the workgroup's copy of C3
+  static constexpr int BYTES_PER_BLOCK = (WORDS * GROUPS_PER_BLOCK + G * BLK) * 4; // + the workgroup's copy of C3 (G lane blocks)
 };
 
 // the FAST product of bigint29.hpp with one more 58-bit value in a column (the initial (2^29 - Q_i) n1 + C3_i of the b side)
@@ -72,13 +75,13 @@ template <int G> struct Bn {
   __device__ __forceinline__ uint32_t* B() const { return lds + BnLds<G>::OFF_B; }
 };
 
-// lds_base: GROUPS x BnLds::WORDS words of group areas, then L words for C3 (copied here by the whole workgroup; ends in a barrier)
+// lds_base: GROUPS x BnLds::WORDS words of group areas, then G BLK words for C3 (copied here by the whole workgroup; ends in a barrier)
 template <int G> __device__ __forceinline__ void bn_init(Bn<G>& g, uint32_t* lds_base, const uint32_t* cst, int groups = BnLds<G>::GROUPS_PER_BLOCK) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   g.gl = lane & (G - 1);
   g.lds = lds_base + (wave * (64 / G) + lane / G) * BnLds<G>::WORDS;
   uint32_t* c3 = lds_base + groups * BnLds<G>::WORDS;
-  for (int w = threadIdx.x; w < Geo<G>::L; w += blockDim.x) c3[w] = cst[BnConst<G>::OFF_C3 + w];
+  for (int w = threadIdx.x; w < Geo<G>::L; w += blockDim.x) c3[(w / W) * BLK + (w % W)] = cst[BnConst<G>::OFF_C3 + w];     // (lane blocks of BLK words, as lds_load_block reads them)
   __syncthreads();
   g.c3 = c3;
   g.cst = cst;
@@ -114,10 +117,17 @@ __device__ __forceinline__ void q_write(uint64_t qmask, uint32_t addr /* LDS byt
   asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b128 %2, %3\n\ts_mov_b64 exec, %0\n\ts_nop 0" : "=&s"(saved) : "s"(qmask), "v"(addr), "v"(v) : "scc");
 }
 __device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)p; }
+// (W = 9: eight digits go out in two 16-byte writes, the ninth on its own)
+__device__ __forceinline__ void q_write1(uint64_t qmask, uint32_t addr /* LDS byte address */, uint32_t q) {
+  uint64_t saved;
+  asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(qmask), "v"(addr), "v"(q) : "scc");
+}
 #define ZKP_BN_QWRITE(qmask, row_addr, t, qd)                                                                            \
   do {                                                                                                                  \
     if (((t) & 3) == 3) q_write((qmask), (row_addr) + ((t) - 3) * 4, qd);                                               \
+    else if ((W & 3) == 1 && (t) == W - 1) q_write1((qmask), (row_addr) + (t) * 4, qd[(t) & 3]);                        \
   } while (0)
+static_assert((W & 3) == 0 || (W & 3) == 1, "the digit writes cover blocks of 4 k or 4 k + 1 limbs");
 
 // ---- the a side of a squaring: R = X * X / R' on M~ (bigint29.hpp montsqr, out of place), quotient digits into ldsB (see above)
 template <int G>
@@ -140,7 +150,7 @@ __device__ __forceinline__ void bn_sqr_a(uint32_t (&R)[W], const uint32_t (&X)[W
 #pragma unroll
       for (int k = 0; k < W; k++) {
         const int d = (k - t + W) % W;
-        const bool take = (d >= 1 && d < H) || (d == H && t < H);
+        const bool take = (W & 1) ? (d >= 1 && d <= H) : ((d >= 1 && d < H) || (d == H && t < H));      // (bigint29.hpp montsqr: odd W is a regular tournament)
         if (take) c[(t + k) % W] += (uint64_t)X[k] * b2;
       }
       const uint32_t q = bcast0<G>((uint32_t)c[t] & LMASK);
@@ -650,7 +660,7 @@ __device__ __forceinline__ uint64_t bn_key(const EncArgs& a, uint64_t item, cons
 constexpr int BN_TAB_ENTRIES = TABS + 4;      // window table | scratch (U, -) | (r, -) | copy of X0^2 | (1, m)
 
 template <int G>
-__global__ void __launch_bounds__(256, 2) k_enc_basen(EncArgs a, const uint32_t* __restrict__ bcst, uint32_t* __restrict__ table, uint32_t* __restrict__ raw) {
+__global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen(EncArgs a, const uint32_t* __restrict__ bcst, uint32_t* __restrict__ table, uint32_t* __restrict__ raw) {
   using BC = BnConst<G>;
   using BL = BnLds<G>;
   constexpr int L = Geo<G>::L, E = 2 * L;
@@ -780,17 +790,17 @@ __global__ void __launch_bounds__(256, 2) k_enc_basen(EncArgs a, const uint32_t*
 // ---- the same for launches with PER-PROOF KEYS (EncArgs::n_stride != 0; the exponent of an item is its own key): fixed 6-bit windows
 // over the item's n as in kernels_modexp.hpp powm_fixed — table T[0] = the Montgomery form of 1, T[1] = x~, T[k] = T[k-1] x~, then from the
 // top window down [6 squarings, one product by T[window]] — with uniform control flow whatever the keys are.  Constants come from the
-// item's record (C3 from global memory at the start of every b side), the whole launch runs in base-n form only when EVERY key
-// qualified (`all_ok`); otherwise it returns at once and the n^2-sized k_enc<G, false> behind it does the work.
+// item's record (C3 from global memory at the start of every b side).  Items are PARTITIONED key by key (round 5): the items of keys the
+// form does not take are appended to EncArgs::left_list and done by the n^2-sized k_enc<G, false> launch behind this one.
 // Table slot of a group: 64 entries, then (U | -) scratch, (r | -), (1 | m).
 constexpr int BN_KEYS_WIN = 6, BN_KEYS_TAB = 1 << BN_KEYS_WIN, BN_KEYS_TAB_ENTRIES = BN_KEYS_TAB + 3;
 template <int G>
-__global__ void __launch_bounds__(256, 2) k_enc_basen_keys(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ all_ok, uint32_t* __restrict__ table,
+__global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen_keys(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ all_ok, uint32_t* __restrict__ table,
                                                            uint32_t* __restrict__ raw) {
   using BC = BnConst<G>;
   using BL = BnLds<G>;
   constexpr int L = Geo<G>::L, E = 2 * L, WIN = BN_KEYS_WIN, TB = BN_KEYS_TAB;
-  if (!*all_ok) return;
+  (void)all_ok;      // (the batch-wide flag is a diagnostic now: items are partitioned key by key, below)
   extern __shared__ __align__(16) uint32_t lds_raw[];
   Bn<G> g;
   {
@@ -818,6 +828,11 @@ __global__ void __launch_bounds__(256, 2) k_enc_basen_keys(EncArgs a, const uint
     const uint64_t key = bn_key(a, item, it);
     const uint32_t* cst = bcst + key * BC::STRIDE;
     const uint32_t* pn = a.n + key * a.n_stride;               // the item's exponent
+    // A key the form does not take (even, short, an M~ beyond the digit-sum bound): its group computes along on whatever constants the
+    // set-up left (no address depends on them) and stores nothing; the item goes on the list of the n^2-sized launch behind this one.
+    // One such key in a batch of 4096 costs one Enc on the other kernels, not the whole launch (round 4: the whole launch fell back).
+    const bool key_ok = cst[BC::OFF_OK] != 0;
+    if (live && !key_ok && g.gl == 0) a.left_list[atomicAdd(a.left_count, 1ull)] = (uint32_t)item;
     g.cst = cst;
     load_limbs_global<G>(g.NT, cst + BC::OFF_MT, g.gl);
     g.n1 = cst[BC::OFF_NI];
@@ -840,7 +855,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_basen_keys(EncArgs a, const uint
       load_limbs_global<G>(T, cst + BC::OFF_R1B, g.gl);
       store_limbs_global<G>(tab + L, T, g.gl);
     }
-    uint32_t* rawdst = live ? raw + item * E : scrU;
+    uint32_t* rawdst = (live && key_ok) ? raw + item * E : scrU;
     auto window = [&](int wi) -> int {
       const int bit = wi * WIN;
       const int w0 = bit >> 5, off = bit & 31;
@@ -947,9 +962,11 @@ __global__ void __launch_bounds__(256) k_basen_finish(EncArgs a, const uint32_t*
     const bool live = idx < count;
     const uint64_t item = live ? idx : count - 1;
     const BnItem it = bn_item(a, item, expected);
+    bool mine = live;
     if (per_key) {
       g.cst = bcst + bn_key(a, item, it) * BC::STRIDE;
       g.n1 = g.cst[BC::OFF_NI];
+      mine = live && g.cst[BC::OFF_OK] != 0;                   // (an item of a key outside the form belongs to the n^2-sized launch)
     }
     uint32_t A1[W], B1[W], LO[W], HI[W];
     load_limbs_global<G>(A1, raw + item * E, g.gl);
@@ -962,7 +979,7 @@ __global__ void __launch_bounds__(256) k_basen_finish(EncArgs a, const uint32_t*
       for (int k = 0; k < W; k++) { g.lds[g.gl * W + k] = LO[k]; g.lds[L + g.gl * W + k] = HI[k]; }
       if (g.gl == 0) { g.lds[2 * L] = 0; g.lds[2 * L + 1] = 0; g.lds[2 * L + 2] = 0; }
       wave_lds_fence();
-      if (live) {
+      if (mine) {
         for (int w = g.gl; w < 2 * kw; w += G) {
           const int bit = w * 32;
           const int i0 = bit / LB, off = bit - i0 * LB;
@@ -988,8 +1005,8 @@ __global__ void __launch_bounds__(256) k_basen_finish(EncArgs a, const uint32_t*
       wave_lds_fence();
       const unsigned long long mk = __ballot(same);
       const bool pass = (mk & gmask) == gmask;
-      if (a.mode == 2) { if (live && g.gl == 0) a.verdict[it.b] = pass ? 1 : 0; }
-      else if (live && g.gl == 0 && !pass) a.verdict[it.b] = ZKP_VERDICT_REJECT;
+      if (a.mode == 2) { if (mine && g.gl == 0) a.verdict[it.b] = pass ? 1 : 0; }
+      else if (mine && g.gl == 0 && !pass) a.verdict[it.b] = ZKP_VERDICT_REJECT;
     }
   }
 }

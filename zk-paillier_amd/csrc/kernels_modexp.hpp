@@ -768,6 +768,11 @@ struct EncArgs {
   const uint8_t* sched;                  // sliding-window schedule when every item uses the same key (exponent n), or null
   unsigned long long* work_counter;      // zeroed per launch: wavefronts claim work items (64/G at a time) dynamically
   uint32_t ef;
+  // launches with per-proof keys, base-n form (kernels_basen.hpp: k_enc_basen_keys): the items whose key the form does not take are
+  // LEFT to the n^2-sized launch behind it — appended here by the base-n kernel ...
+  uint32_t* left_list; unsigned long long* left_count;
+  // ... and read here by k_enc: item = remap[claimed index], the count is *remap_count (null: items are claimed directly)
+  const uint32_t* remap; const unsigned long long* remap_count;
 };
 
 // stage a constant (this lane's block of a limb array in global memory) as the B operand
@@ -800,7 +805,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
   constexpr int TSLOT = SHARED_EXP ? TABS : (1 << WIN_KEY);      // (see k_modexp)
   uint32_t* tab = a.table + ggrp * (uint64_t)(TSLOT * L);
   const int kw = a.n_bits / 32;
-  const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
+  const uint64_t count = a.remap_count ? (uint64_t)*a.remap_count : a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
   const int lane = threadIdx.x & 63;
   const unsigned long long gmask = (G == 64 ? ~0ull : (1ull << G) - 1) << (lane & ~(G - 1));
   const int nsteps = a.mode == 0 ? 6 : 10;
@@ -816,7 +821,7 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_enc(EncArgs a) {
     if (base >= count) break;
     const uint64_t idx = base + (uint64_t)(lane / GP);
     const bool live = idx < count && role == 0;           // (the odd group of a pair computes along and stores nothing)
-    const uint64_t item = idx < count ? idx : count - 1;
+    const uint64_t item = a.remap ? (uint64_t)a.remap[idx < count ? idx : count - 1] : (idx < count ? idx : count - 1);
     uint64_t key;
     const uint32_t *pm, *pr;
     const uint32_t* pexp = nullptr;       // expected ciphertext (mode 1)

@@ -19,8 +19,12 @@
 #include "kernels_proofs.hpp"
 #include "kernels_inv.hpp"
 #include "kernels_serde.hpp"
-#if ZKP_W == 36
-#include "kernels_basen.hpp"          // the shared-key Paillier kernels in base-n form (throughput engine only)
+#if ZKP_W == 36 || ZKP_W == 9
+#define ZKP_HAS_BASEN 1
+#include "kernels_basen.hpp"
+#include "kernels_basen_r2l.hpp"      // (W = 9 only: one Enc per wavefront, the five-group right-to-left ladder of calls of a few proofs)          // the Paillier kernels in base-n form: 2 / 4 lanes per n-sized integer in the throughput engine (W = 36), 8 / 16 in the latency engine (W = 9)
+#else
+#define ZKP_HAS_BASEN 0
 #endif
 
 using namespace zkp;
@@ -59,11 +63,13 @@ struct zkp_ctx {
   int host_chunks = -1;          // $ZKP_HOST_CHUNKS at zkp_ctx_create: unset (-1) or 1 = a host-pointer call is one block, N = N equal blocks, 0 = uneven blocks (host_blocks)
   std::string err;
   DevBuf consts, consts2, table, scratch[48];
-  DevBuf bn_ncst, bn_consts, bn_table, bn_expected, bn_raw;
+  DevBuf bn_ncst, bn_consts, bn_table, bn_expected, bn_raw, bn_left;
   int enc_form = ZKP_ENC_FORM_AUTO;    // which Paillier launches take the base-n form (zkp_diag_set_enc_form; $ZKP_BASEN is read ONCE, at zkp_ctx_create)
-  int bn_occ[2][2] = {{0, 0}, {0, 0}}; // resident workgroups per CU of k_enc_basen<G> / k_enc_basen_keys<G> ([per-key][G == 4]; 0: not asked yet)
+  int bn_occ[2][2] = {{0, 0}, {0, 0}}; // resident workgroups per CU of k_enc_basen<G> / k_enc_basen_keys<G> ([per-key][n = 4096]; 0: not asked yet)
   int bn_last_g = 0;                   // lanes per n-sized integer of the most recent base-n launch (0: none yet)
   bool bn_last_per_key = false;        // ... and whether it ran under per-proof keys
+  bool bn_last_r2l = false;            // ... and whether it was the one-Enc-per-wavefront ladder of the latency engine (kernels_basen_r2l.hpp)
+  int bn_r2l = 1;                      // that ladder: 0 = never, 1 = the library's rule (launches of up to two wavefronts per SIMD), 2 = whenever it can run (tests); $ZKP_R2L at ctx create
   DevBuf bn_flag;                      // device word: every key of the last batched base-n set-up qualified   // base-n form (kernels_basen.hpp): set-up record of n, its base-n constants, window tables, Mask-row products
   // timing of the dominant kernels
   bool timing = false;
@@ -107,7 +113,8 @@ static int32_t zkp_caught(zkp_ctx* c, int32_t st, const char* what) noexcept {
   X(zkp_range_verifier_output_batch) X(zkp_correct_key_ni_verify_batch) X(zkp_dlog_prove_batch) X(zkp_dlog_verify_batch)         \
   X(zkp_zero_proof_prove_batch) X(zkp_zero_proof_verify_batch) X(zkp_ciphertext_proof_prove_batch)                               \
   X(zkp_ciphertext_proof_verify_batch) X(zkp_verlin_proof_prove_batch) X(zkp_verlin_proof_verify_batch)                          \
-  X(zkp_mul_proof_prove_batch) X(zkp_mul_proof_verify_batch) X(zkp_correct_message_prove_batch) X(zkp_correct_message_verify_batch)
+  X(zkp_mul_proof_prove_batch) X(zkp_mul_proof_verify_batch) X(zkp_correct_message_prove_batch) X(zkp_correct_message_verify_batch)           \
+  X(zkp_diag_basen) X(zkp_diag_basen_last) X(zkp_diag_set_enc_form) X(zkp_diag_set_r2l) X(zkp_diag_r2l_last)
 
 struct LatEngine {
   void* handle = nullptr;
@@ -162,10 +169,17 @@ static const LatEngine* lat_engine() {
 }
 
 // does this call (items independent modexp chains under mod_bits-bit moduli) go to the latency engine?
-static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits) {
+// one_key_paillier: the items are Paillier Enc under ONE 2048-bit key — the latency engine then runs them in base-n form, 8 Enc per wavefront
+// (k_enc_basen<8>), and stays ahead of the throughput engine up to three wavefronts per SIMD.  Measured round 5 (tools/dev/size_sweep.py,
+// profiles/r05/size_sweep.jsonl, prove / verify ms): 48 proofs 43.9 / 43.5 against 49.3 / 44.2 on the n^2-sized throughput kernels, 64 proofs
+// 45.1 / 44.3 against 51.0 / 44.3, 96 proofs 60.7 / 59.7 against 64.9 / 61.6 on the throughput engine's base-n kernels, 128 proofs 76.7 / 74.5
+// against 66.7 / 61.7: the hand-over is at 96 proofs.
+static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits, bool one_key_paillier = false) {
   c->last_geometry = W;
   if (!c->lat_ctx || c->geometry == W || items == 0) return false;
   bool take = c->geometry == c->lat->limbs_per_lane;
+  if (!take && one_key_paillier && mod_bits == 4096 && c->lat->limbs_per_lane == 9 && c->enc_form != ZKP_ENC_FORM_N2)
+    take = items <= 3ull * 4 * (uint64_t)c->cus * 8;
   if (!take) {
     // automatic: the latency engine wins while its launch stays within a few wavefronts per SIMD — measured on MI355X
     // (tools/dev/sweep.py, both engines pinned): RangeProofNi n = 2048 (16 lanes per integer) 48 proofs = 3 waves per SIMD:
@@ -183,8 +197,15 @@ static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits) {
 }
 #define ZKP_ROUTE(c, items, mod_bits, fn, ...)                                              \
   if ((c) && route_latency((c), (items), (mod_bits))) return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__));
+#define ZKP_ROUTE_ENC(c, items, mod_bits, one_key, fn, ...)                                 \
+  if ((c) && route_latency((c), (items), (mod_bits), (one_key))) return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__));
+// (diagnostics: only when the caller PINNED the latency engine)
+#define ZKP_ROUTE_PINNED(c, fn, ...)                                                        \
+  if ((c) && (c)->lat_ctx && (c)->geometry == (c)->lat->limbs_per_lane) { (c)->last_geometry = (c)->geometry; return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__)); }
 #else
 #define ZKP_ROUTE(c, items, mod_bits, fn, ...)
+#define ZKP_ROUTE_ENC(c, items, mod_bits, one_key, fn, ...)
+#define ZKP_ROUTE_PINNED(c, fn, ...)
 #endif
 
 static int32_t ensure(zkp_ctx* c, DevBuf& b, size_t bytes) {
@@ -474,6 +495,7 @@ template <int G, class K> static int32_t table_for(zkp_ctx* c, K kernel, uint64_
 // share SIMDs two by two).
 constexpr bool PAIR_LADDER_BUILD = ZKP_W <= 9;            // the pair kernels are instantiated in the latency engine only
 template <int G> static bool pair_ladder(const zkp_ctx* c, uint64_t items) {
+  if (c->enc_form == ZKP_ENC_FORM_ALWAYS) return false;      // (tests that pin the base-n kernels of the latency engine on small batches: they need the window script)
   if constexpr (PAIR_LADDER_BUILD && 2 * G <= 64) return items * 2 * G <= 4ull * (uint64_t)c->cus * 64;
   (void)c; (void)items;
   return false;
@@ -483,21 +505,23 @@ template <int G> static bool pair_ladder(const zkp_ctx* c, uint64_t items) {
 // The latency engine has a third: the right-to-left ladder on pairs of groups (kernels_modexp.hpp: powm_pair), taken while a
 // launch with twice the lanes per item still leaves every SIMD at most one wavefront — the call is then a single chain of
 // products per item, and that chain is 14 % shorter.
-#if ZKP_W == 36
+#if ZKP_HAS_BASEN
+// lanes per n-sized integer of the base-n kernels: 72 / 144 limbs over W limbs per lane
+constexpr int BN_GA = 72 / W, BN_GB = 144 / W;
 #ifdef ZKP_SPLIT_TU
 // compiled in zkp_kernels_basen.hip
-extern template __global__ void zkp::k_enc_basen<2>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
-extern template __global__ void zkp::k_enc_basen<4>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
-extern template __global__ void zkp::k_enc_basen_keys<2>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-extern template __global__ void zkp::k_enc_basen_keys<4>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-extern template __global__ void zkp::k_basen_finish<2>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
-extern template __global__ void zkp::k_basen_finish<4>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
-extern template __global__ void zkp::k_setup_basen<2>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
-extern template __global__ void zkp::k_setup_basen<4>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
-extern template __global__ void zkp::k_expected<4>(EncArgs, uint32_t*, const uint32_t*);
-extern template __global__ void zkp::k_expected<8>(EncArgs, uint32_t*, const uint32_t*);
-extern template __global__ void zkp::k_diag_basen<2>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-extern template __global__ void zkp::k_diag_basen<4>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_enc_basen<BN_GA>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_enc_basen<BN_GB>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_enc_basen_keys<BN_GA>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_enc_basen_keys<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_basen_finish<BN_GA>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_basen_finish<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_setup_basen<BN_GA>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
+extern template __global__ void zkp::k_setup_basen<BN_GB>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
+extern template __global__ void zkp::k_expected<2 * BN_GA>(EncArgs, uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_expected<2 * BN_GB>(EncArgs, uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_diag_basen<BN_GA>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_diag_basen<BN_GB>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 #endif
 constexpr size_t BASEN_DIAG_LDS = 4096;
 // Which Paillier launches take the base-n form is a property of the ctx (include/zkp_hip_diag.h: zkp_diag_set_enc_form):
@@ -521,7 +545,7 @@ template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uin
   if (st) return st;
   if ((st = ensure(c, c->bn_consts, (size_t)nkeys * BnConst<G>::STRIDE * sizeof(uint32_t)))) return st;
   if ((st = ensure(c, c->bn_flag, 64))) return st;
-  HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->bn_flag.p, 1, 1, c->stream));
+  HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->bn_flag.p, 1, 2, c->stream));      // word 0: every key of the batch qualified (cleared by k_setup_basen); word 1: the constant 1
   constexpr unsigned GPB = 64 / G;
   hipLaunchKernelGGL(k_setup_basen<G>, dim3((unsigned)((nkeys + GPB - 1) / GPB)), dim3(64), GPB * BN_SETUP_LDS_WORDS * sizeof(uint32_t), c->stream,
                      (const uint32_t*)c->bn_ncst.p, (uint32_t*)c->bn_consts.p, nkeys, (uint32_t*)c->bn_flag.p);
@@ -531,23 +555,32 @@ template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uin
 // The base-n launch of an Enc call (GS: lanes per n^2-sized integer of the k_enc launch it stands in for).  It claims work from the SAME
 // counter as the k_enc launch that follows it: when the keys qualify it leaves nothing to claim, when they do not it returns at once
 // and k_enc runs as before.  Returns false when nothing was launched.
-template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
-  if constexpr (GS != 4 && GS != 8) { (void)c; (void)a; return false; }
+template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncArgs* rest) {
+  if constexpr (GS != 2 * BN_GA && GS != 2 * BN_GB) { (void)c; (void)a_in; (void)rest; return false; }
   else {
     constexpr int G = GS / 2;
     using BL = BnLds<G>;
+    EncArgs a = a_in;
     const int kw = a.n_bits / 32;
     const bool per_key = a.n_stride != 0;
     c->bn_last_g = 0;                                             // (zkp_diag_basen_last: this launch has not taken the form yet)
     const int mode = c->enc_form;
-    if (mode == ZKP_ENC_FORM_N2 || (per_key && mode == ZKP_ENC_FORM_SHARED) || a.n_bits != 1024 * G) return false;
-    if (!per_key && !a.sched) return false;                       // (a shared key whose launch takes the pair ladder of the latency engine)
+    if (mode == ZKP_ENC_FORM_N2 || (per_key && mode == ZKP_ENC_FORM_SHARED) || a.n_bits != (G == BN_GA ? 2048 : 4096)) return false;
+    // The latency engine's smallest calls — up to two wavefronts per SIMD at ONE Enc per wavefront: 8 proofs at n = 2048 — take the five-group
+    // right-to-left ladder (kernels_basen_r2l.hpp): half the chain of the pair ladder that served them (the launch behind this one, which then
+    // finds nothing to claim).  c->bn_r2l: 0 = never, 1 = the library's rule, 2 = whenever the kernel can take the launch (tests).
+    bool r2l_launch = false;
+#if ZKP_W == 9
+    if constexpr (G == r2l::G)
+      r2l_launch = !per_key && c->bn_r2l && a.n_bits == 2048 && (c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && a.count <= 2ull * 4 * (uint64_t)c->cus));
+#endif
+    if (!per_key && !a.sched && !r2l_launch) return false;       // (a shared key whose launch takes the pair ladder of the latency engine)
     if (per_key && a.n_stride != (uint64_t)kw) return false;
     if (a.mode == 0 && ((a.m_words > kw) || (a.r_words > kw))) return false;
     // A launch whose n^2-sized wavefronts (64 / GS items each) all find a SIMD of their own is a single chain per wavefront either way,
     // and the base-n chain is the longer one (27.4 M against 22.3 M VALU instructions per claim, for twice the items): measured at
     // n = 2048, 64 proofs: prove 51 -> 64 ms, verify 45 -> 61 ms; from 96 proofs on: 88 -> 65 ms (profiles/r04/basen/midsize_sweep.jsonl)
-    if (mode != ZKP_ENC_FORM_ALWAYS && a.count <= 4ull * (uint64_t)c->cus * (64 / GS)) return false;
+    if (mode != ZKP_ENC_FORM_ALWAYS && !r2l_launch && a.count <= 4ull * (uint64_t)c->cus * (64 / GS)) return false;
     uint64_t nkeys = 1;
     if (per_key) {
       const uint64_t items = (a.mode == 0 && a.half) ? a.half : a.count;
@@ -555,9 +588,9 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
       if (nkeys == 0) return false;
     }
     // (any failure below — out of memory for the form's tables — leaves the launch to the n^2-sized kernel behind this one: not an error)
-    auto give_up = [&]() { c->err.clear(); return false; };
+    auto give_up = [&]() { c->err.clear(); *rest = a_in; return false; };      // (`rest`: nothing was taken off the launch behind this one)
     if (basen_prepare<G>(c, a.n, a.n_stride, nkeys, (uint32_t)a.n_bits)) return give_up();
-    int& per_cu = c->bn_occ[per_key ? 1 : 0][G == 4 ? 1 : 0];     // per ctx and per kernel: the two differ in registers, and contexts run on threads of their own
+    int& per_cu = c->bn_occ[per_key ? 1 : 0][G == BN_GB ? 1 : 0];     // per ctx and per kernel: the two differ in registers, and contexts run on threads of their own
     if (!per_cu) {
       const hipError_t e = per_key ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_basen_keys<G>, 256, BL::BYTES_PER_BLOCK)
                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_enc_basen<G>, 256, BL::BYTES_PER_BLOCK);
@@ -566,10 +599,20 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
     const uint64_t need = (a.count + BL::GROUPS_PER_BLOCK - 1) / BL::GROUPS_PER_BLOCK;
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)per_cu * c->cus));
     const size_t entries = per_key ? BN_KEYS_TAB_ENTRIES : BN_TAB_ENTRIES;
-    if (ensure(c, c->bn_table, (size_t)blocks * BL::GROUPS_PER_BLOCK * entries * 2 * Geo<G>::L * sizeof(uint32_t))) return give_up();
+    if (!r2l_launch && ensure(c, c->bn_table, (size_t)blocks * BL::GROUPS_PER_BLOCK * entries * 2 * Geo<G>::L * sizeof(uint32_t))) return give_up();
     if (ensure(c, c->bn_raw, (size_t)a.count * 2 * Geo<G>::L * sizeof(uint32_t))) return give_up();
-    // the word that says "this launch runs in base-n form": the key's own flag, or the batch's
-    const uint32_t* ok = per_key ? (const uint32_t*)c->bn_flag.p : (const uint32_t*)c->bn_consts.p + BnConst<G>::OFF_OK;
+    // the word that says "this launch runs in base-n form": the key's own flag under one key; under per-proof keys the launch always runs
+    // (the constant 1 behind the batch's flag) and partitions its items key by key: those of keys the form does not take go on a list that
+    // the n^2-sized launch behind this one works off (`rest`: remapped items, a counter of its own)
+    const uint32_t* ok = per_key ? (const uint32_t*)c->bn_flag.p + 1 : (const uint32_t*)c->bn_consts.p + BnConst<G>::OFF_OK;
+    if (per_key) {
+      if (ensure(c, c->bn_left, 16 + (size_t)a.count * sizeof(uint32_t))) return give_up();
+      if (hipMemsetAsync(c->bn_left.p, 0, 16, c->stream) != hipSuccess) return give_up();
+      a.left_count = (unsigned long long*)c->bn_left.p;
+      a.left_list = (uint32_t*)((char*)c->bn_left.p + 16);
+      rest->remap = a.left_list; rest->remap_count = a.left_count;
+      rest->work_counter = a.work_counter + 1;                     // (fresh_work_counter zeroes 64 bytes: the second slot)
+    }
     const bool products = a.mode == 1 || (a.mode == 2 && a.cipher_x);
     if (products) {
       if (ensure(c, c->bn_expected, (size_t)a.count * 2 * kw * sizeof(uint32_t))) return give_up();
@@ -578,9 +621,17 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
       const unsigned eblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(eneed, 2ull * c->cus));
       hipLaunchKernelGGL(k_expected<GS>, dim3(eblocks), dim3(256), LS::BYTES_PER_BLOCK, c->stream, a, (uint32_t*)c->bn_expected.p, ok);
     }
-    c->bn_last_g = G; c->bn_last_per_key = per_key;
+    c->bn_last_g = G; c->bn_last_per_key = per_key; c->bn_last_r2l = r2l_launch;
+#if ZKP_W == 9
+    if (r2l_launch) {
+      if constexpr (G == r2l::G) {
+        const unsigned waves = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(a.count, 8ull * 4 * (uint64_t)c->cus));
+        hipLaunchKernelGGL(k_enc_basen_r2l, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
+      }
+    } else
+#endif
     if (per_key)
-      hipLaunchKernelGGL(k_enc_basen_keys<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, ok, (uint32_t*)c->bn_table.p,
+      hipLaunchKernelGGL(k_enc_basen_keys<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (const uint32_t*)c->bn_flag.p, (uint32_t*)c->bn_table.p,
                          (uint32_t*)c->bn_raw.p);
     else
       hipLaunchKernelGGL(k_enc_basen<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_table.p,
@@ -593,10 +644,11 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a) {
 }
 #endif
 
-template <int G> static void launch_k_enc(zkp_ctx* c, unsigned blocks, const EncArgs& a) {
+template <int G> static void launch_k_enc(zkp_ctx* c, unsigned blocks, const EncArgs& a_in) {
   using LL = LdsLayout<G>;
-#if ZKP_W == 36
-  (void)launch_basen<G>(c, a);
+  EncArgs a = a_in;
+#if ZKP_HAS_BASEN
+  (void)launch_basen<G>(c, a_in, &a);      // (under per-proof keys `a` now names the items the base-n launch leaves to this one)
 #endif
   if constexpr (PAIR_LADDER_BUILD && 2 * G <= 64) {
     if (pair_ladder<G>(c, a.count)) {                     // (a.count: an upper bound when the count is device resident, verify work list)
@@ -623,10 +675,11 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
   c->device = device_id;
   c->cus = p.multiProcessorCount;
   c->last_geometry = W;
-#if ZKP_W == 36
+#if ZKP_HAS_BASEN
   c->enc_form = enc_form_from_env();
 #endif
   if (const char* hc = std::getenv("ZKP_HOST_CHUNKS")) c->host_chunks = std::atoi(hc);
+  if (const char* rl = std::getenv("ZKP_R2L")) c->bn_r2l = std::atoi(rl);
   c->owns_stream = own_stream;
   c->stream = stream;
   if (own_stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKP_EDEVICE; }
@@ -673,7 +726,7 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->lat_ctx) (void)c->lat->p_zkp_ctx_destroy(c->lat_ctx);
-  for (DevBuf* b : {&c->consts, &c->consts2, &c->table, &c->bn_ncst, &c->bn_consts, &c->bn_table, &c->bn_expected, &c->bn_raw, &c->bn_flag}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->consts, &c->consts2, &c->table, &c->bn_ncst, &c->bn_consts, &c->bn_table, &c->bn_expected, &c->bn_raw, &c->bn_flag, &c->bn_left}) if (b->p) (void)hipFree(b->p);
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
@@ -732,13 +785,14 @@ extern "C" int32_t zkp_diag_table_traffic(zkp_ctx* c, int32_t mode, int32_t pass
   return ZKP_OK;
 } ZKP_CATCH(c)
 
-#if ZKP_W == 36
+#if ZKP_HAS_BASEN
 // diagnostic: one base-n operation on raw limbs (kernels_basen.hpp: k_diag_basen); tests/test_gpu_basen.py checks it against tests/basen_model.py
 extern "C" int32_t zkp_diag_basen(zkp_ctx* c, uint32_t n_bits, const uint32_t* n, int32_t op, const uint32_t* xa, const uint32_t* xb, const uint32_t* ya,
                                   const uint32_t* yb, uint32_t* out) try {
   if (!c || !n || !out || (n_bits != 2048 && n_bits != 4096) || op < 0 || op > 3) return ZKP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  const int G = n_bits == 2048 ? 2 : 4;
+  ZKP_ROUTE_PINNED(c, zkp_diag_basen, n_bits, n, op, xa, xb, ya, yb, out)
+  const int G = n_bits == 2048 ? BN_GA : BN_GB;
   const size_t L = (size_t)G * W, kw = n_bits / 32;
   Stage s(c, 0);
   const uint32_t* dn = s.in(n, kw);
@@ -746,10 +800,10 @@ extern "C" int32_t zkp_diag_basen(zkp_ctx* c, uint32_t n_bits, const uint32_t* n
   uint32_t* dout = s.out(out, 4 * L + 4);
   uint32_t* dscr = (uint32_t*)s.take(2 * L * sizeof(uint32_t));
   int32_t st = s.st;
-  if (!st) st = G == 2 ? basen_prepare<2>(c, dn, 0, 1, n_bits) : basen_prepare<4>(c, dn, 0, 1, n_bits);
+  if (!st) st = G == BN_GA ? basen_prepare<BN_GA>(c, dn, 0, 1, n_bits) : basen_prepare<BN_GB>(c, dn, 0, 1, n_bits);
   if (!st) {
-    if (G == 2) hipLaunchKernelGGL(k_diag_basen<2>, dim3(1), dim3(64), BASEN_DIAG_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
-    else hipLaunchKernelGGL(k_diag_basen<4>, dim3(1), dim3(64), BASEN_DIAG_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
+    if (G == BN_GA) hipLaunchKernelGGL(k_diag_basen<BN_GA>, dim3(1), dim3(64), BASEN_DIAG_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
+    else hipLaunchKernelGGL(k_diag_basen<BN_GB>, dim3(1), dim3(64), BASEN_DIAG_LDS, c->stream, (const uint32_t*)c->bn_consts.p, (int)op, dxa, dxb, dya, dyb, dout, dscr);
     if (hipGetLastError() != hipSuccess) st = ZKP_EDEVICE;
   }
   const int32_t fin = s.finish();
@@ -759,10 +813,14 @@ extern "C" int32_t zkp_diag_basen(zkp_ctx* c, uint32_t n_bits, const uint32_t* n
 // launch (0: there was none), out_qualified: the key passed k_setup_basen (else the n^2-sized kernel did the work)
 extern "C" int32_t zkp_diag_basen_last(zkp_ctx* c, int32_t* out_lanes, uint32_t* out_qualified) try {
   if (!c || !out_lanes || !out_qualified) return ZKP_EINVAL;
+#ifndef ZKP_SECONDARY_ENGINE
+  if (c->lat_ctx && c->last_geometry == c->lat->limbs_per_lane)        // the most recent call ran on the latency engine: its twin ctx knows
+    return lat_forward_plain(c, c->lat->p_zkp_diag_basen_last(c->lat_ctx, out_lanes, out_qualified));
+#endif
   *out_lanes = c->bn_last_g; *out_qualified = 0;
   if (!c->bn_last_g) return ZKP_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  const size_t off = (c->bn_last_g == 2 ? BnConst<2>::OFF_OK : BnConst<4>::OFF_OK) * sizeof(uint32_t);
+  const size_t off = (c->bn_last_g == BN_GA ? BnConst<BN_GA>::OFF_OK : BnConst<BN_GB>::OFF_OK) * sizeof(uint32_t);
   const void* word = c->bn_last_per_key ? c->bn_flag.p : (const void*)((const char*)c->bn_consts.p + off);
   HIPCHK(c, hipMemcpyAsync(c->setup_flag_host + 8, word, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -781,14 +839,34 @@ extern "C" int32_t zkp_diag_basen(zkp_ctx* c, uint32_t, const uint32_t*, int32_t
 }
 #endif
 
-// which Paillier launches take the base-n form (include/zkp_hip_diag.h); the latency engine has no base-n kernels and ignores it
+// which Paillier launches take the base-n form (include/zkp_hip_diag.h); the twin ctx of the latency engine follows
 extern "C" int32_t zkp_diag_set_enc_form(zkp_ctx* c, int32_t form) try {
   if (!c || form < ZKP_ENC_FORM_AUTO || form > ZKP_ENC_FORM_ALWAYS) return ZKP_EINVAL;
   c->enc_form = form;
+#ifndef ZKP_SECONDARY_ENGINE
+  if (c->lat_ctx) return lat_forward_plain(c, c->lat->p_zkp_diag_set_enc_form(c->lat_ctx, form));
+#endif
   return ZKP_OK;
 } ZKP_CATCH(c)
 extern "C" int32_t zkp_diag_enc_form(zkp_ctx* c) { return c ? c->enc_form : -1; }
 extern "C" int32_t zkp_diag_last_host_blocks(zkp_ctx* c) { return c ? c->last_host_blocks : -1; }
+// the one-Enc-per-wavefront ladder of the latency engine (kernels_basen_r2l.hpp): 0 = never, 1 = the library's rule, 2 = whenever it can run
+extern "C" int32_t zkp_diag_set_r2l(zkp_ctx* c, int32_t mode) try {
+  if (!c || mode < 0 || mode > 2) return ZKP_EINVAL;
+  c->bn_r2l = mode;
+#ifndef ZKP_SECONDARY_ENGINE
+  if (c->lat_ctx) return lat_forward_plain(c, c->lat->p_zkp_diag_set_r2l(c->lat_ctx, mode));
+#endif
+  return ZKP_OK;
+} ZKP_CATCH(c)
+// did the most recent Paillier launch of this ctx run on it?
+extern "C" int32_t zkp_diag_r2l_last(zkp_ctx* c) {
+  if (!c) return -1;
+#ifndef ZKP_SECONDARY_ENGINE
+  if (c->lat_ctx && c->last_geometry == c->lat->limbs_per_lane) return c->lat->p_zkp_diag_r2l_last(c->lat_ctx);
+#endif
+  return (c->bn_last_g && c->bn_last_r2l) ? 1 : 0;
+}
 
 extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) try {
   if (!c) return ZKP_EINVAL;
@@ -1031,7 +1109,7 @@ static int32_t enc_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint3
 
 extern "C" int32_t zkp_paillier_enc_batch(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m,
                                           const uint32_t* r, uint32_t* out_c, uint32_t flags) try {
-  ZKP_ROUTE(c, count, 2 * n_bits, zkp_paillier_enc_batch, n_bits, count, n, n_stride, m, r, out_c, flags)
+  ZKP_ROUTE_ENC(c, count, 2 * n_bits, n_stride == 0, zkp_paillier_enc_batch, n_bits, count, n, n_stride, m, r, out_c, flags)
   if (!c) return ZKP_EINVAL;
   if (count == 0) return ZKP_OK;
   if (!n || !m || !r || !out_c || (n_bits != 1024 && n_bits != 2048 && n_bits != 4096) || count > (1ull << 40) || (n_stride && n_stride < n_bits / 32)) { c->err = "zkp_paillier_enc_batch: invalid argument"; return ZKP_EINVAL; }
@@ -1082,7 +1160,7 @@ static int32_t enc_check_impl(zkp_ctx* c, uint32_t n_bits, uint64_t count, const
 extern "C" int32_t zkp_paillier_enc_check_batch(zkp_ctx* c, uint32_t n_bits, uint64_t count, const uint32_t* n, uint64_t n_stride, const uint32_t* m,
                                                 const uint32_t* r, const uint32_t* mulc_a, const uint32_t* mulc_b, const uint32_t* expected,
                                                 uint8_t* out_ok, uint32_t flags) try {
-  ZKP_ROUTE(c, count, 2 * n_bits, zkp_paillier_enc_check_batch, n_bits, count, n, n_stride, m, r, mulc_a, mulc_b, expected, out_ok, flags)
+  ZKP_ROUTE_ENC(c, count, 2 * n_bits, n_stride == 0, zkp_paillier_enc_check_batch, n_bits, count, n, n_stride, m, r, mulc_a, mulc_b, expected, out_ok, flags)
   if (!c) return ZKP_EINVAL;
   if (count == 0) return ZKP_OK;
   const bool product = mulc_a || mulc_b;

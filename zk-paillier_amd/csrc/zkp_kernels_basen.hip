@@ -6,16 +6,17 @@
 #include "kernels_basen.hpp"
 
 namespace zkp {
-template __global__ void k_enc_basen<2>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
-template __global__ void k_enc_basen<4>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
-template __global__ void k_enc_basen_keys<2>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-template __global__ void k_enc_basen_keys<4>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-template __global__ void k_basen_finish<2>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
-template __global__ void k_basen_finish<4>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
-template __global__ void k_setup_basen<2>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
-template __global__ void k_setup_basen<4>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
-template __global__ void k_expected<4>(EncArgs, uint32_t*, const uint32_t*);
-template __global__ void k_expected<8>(EncArgs, uint32_t*, const uint32_t*);
-template __global__ void k_diag_basen<2>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-template __global__ void k_diag_basen<4>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+constexpr int BN_GA = 72 / W, BN_GB = 144 / W;      // lanes per n-sized integer (2 / 4 at 36 limbs per lane)
+template __global__ void k_enc_basen<BN_GA>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_enc_basen<BN_GB>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_enc_basen_keys<BN_GA>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_enc_basen_keys<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_basen_finish<BN_GA>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
+template __global__ void k_basen_finish<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
+template __global__ void k_setup_basen<BN_GA>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
+template __global__ void k_setup_basen<BN_GB>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
+template __global__ void k_expected<2 * BN_GA>(EncArgs, uint32_t*, const uint32_t*);
+template __global__ void k_expected<2 * BN_GB>(EncArgs, uint32_t*, const uint32_t*);
+template __global__ void k_diag_basen<BN_GA>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_diag_basen<BN_GB>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 }  // namespace zkp
