@@ -223,7 +223,8 @@ def test_range_proofs_under_per_proof_keys_with_keys_outside_the_form(oracle):
         c.close()
 
 
-def test_one_enc_per_wavefront_ladder_of_the_latency_engine():
+@pytest.mark.parametrize("lanes", [12, 8], ids=["12-lanes-x-6-limbs", "8-lanes-x-9-limbs"])
+def test_one_enc_per_wavefront_ladder_of_the_latency_engine(lanes):
     """csrc/kernels_basen_r2l.hpp: the base-n exponentiation as a right-to-left ladder pipelined over five lane groups, the latency engine's
     kernel for calls of a few proofs under one 2048-bit key (tests/test_basen_r2l_model.py states the pipeline on values): Enc against
     Python's pow() with the operand edge cases, Enc-and-compare with plain and product expectations, keys at the edges of the form, and
@@ -231,7 +232,12 @@ def test_one_enc_per_wavefront_ladder_of_the_latency_engine():
     import math
     rnd = random.Random(99)
     n_bits, kw = 2048, 64
-    c = zkp.Context(0)
+    import os
+    os.environ["ZKP_R2L_LANES"] = str(lanes)        # (read when the ctx is created: the kernel's lane geometry, 12 x 6 limbs by default)
+    try:
+        c = zkp.Context(0)
+    finally:
+        os.environ.pop("ZKP_R2L_LANES", None)
     try:
         c.set_geometry(9)
         for trial, n in enumerate((odd_modulus(rnd, 2048), odd_modulus(rnd, 2047), H.fixture_key()[2], odd_modulus(rnd, 1200))):

@@ -60,6 +60,9 @@ template <int G> struct BnLds {
 // the FAST product of bigint29.hpp with one more 58-bit value in a column (the initial (2^29 - Q_i) n1 + C3_i of the b side)
 constexpr uint64_t COL_FAST_SN_LIMIT_BN = ((~0ull) - (1ull << 36) - ((1ull << LB) + 16) * (W * (1ull << LB) + 16) - (1ull << (2 * LB)) - (1ull << LB)) >> LB;
 
+#ifndef ZKP_BN_PEND_PRODUCTS
+#define ZKP_BN_PEND_PRODUCTS 0   /* measured round 5 (profiles/r05/traffic_split.json): 40 % less global traffic, 5 % SLOWER */
+#endif
 #ifndef ZKP_BN_SQR_FENCE
 #define ZKP_BN_SQR_FENCE 12
 #endif
@@ -202,13 +205,13 @@ template <int G, bool C3G = false> __device__ __forceinline__ void bn_b_init(uin
 #endif
 template <int G, bool PEND, bool C3G = false, int FENCE = ZKP_BN_MUL_FENCE>
 __device__ __forceinline__ void bn_mul_impl(uint32_t (&R)[W], const uint32_t (&A)[W], uint32_t* ldsB, const Bn<G>& g, int mode, uint32_t* ldsQ,
-                                            const uint32_t (&pend)[W]) {
+                                            const uint32_t (&pend)[W], bool pend_now = true) {
   const int gl = g.gl;
   const uint64_t writes = q_write_mask<G>(mode == 1);
   uint64_t c[W];
   if (mode == 2) {
     bn_b_init<G, C3G>(c, g, ldsQ);
-    if constexpr (PEND) bn_stage<G>(g, ldsQ, pend);
+    if constexpr (PEND) { if (pend_now) bn_stage<G>(g, ldsQ, pend); }
   } else {
 #pragma unroll
     for (int k = 0; k < W; k++) c[k] = 0;
@@ -427,6 +430,15 @@ __global__ void __launch_bounds__(64) k_setup_basen(const uint32_t* __restrict__
   load_limbs_global<G>(g.NT, ncst + CL::OFF_MT, g.gl);
   g.n1 = ncst[CL::OFF_NI];
   bool ok = ncst[CL::OFF_ST] == 0;
+  // A modulus k_setup rejected (even: there is no Montgomery form) must not be computed WITH: the lane above a group takes the group's
+  // lowest limb for zero after every sub-step (bigint29.hpp from_next), which holds for a proper reduction and for zeros, not for an even
+  // modulus — its group would corrupt the constants of the key next to it.  Such a group runs on zeros (and its record says `not ok`).
+  const bool sane = ok;
+  if (!sane) {
+#pragma unroll
+    for (int k = 0; k < W; k++) { N[k] = 0; g.NT[k] = 0; }
+    g.n1 = 0;
+  }
   {
     uint64_t sn = 0;
 #pragma unroll
@@ -438,6 +450,10 @@ __global__ void __launch_bounds__(64) k_setup_basen(const uint32_t* __restrict__
   store_limbs_global<G>(out + BC::OFF_MT, g.NT, g.gl);
   store_limbs_global<G>(out + BC::OFF_N, N, g.gl);
   load_limbs_global<G>(T, ncst + CL::OFF_R2, g.gl);
+  if (!sane) {
+#pragma unroll
+    for (int k = 0; k < W; k++) T[k] = 0;
+  }
   store_limbs_global<G>(out + BC::OFF_R2N, T, g.gl);
   if (g.gl == 0) out[BC::OFF_NI] = g.n1;
 #pragma unroll
@@ -450,7 +466,7 @@ __global__ void __launch_bounds__(64) k_setup_basen(const uint32_t* __restrict__
     if (g.gl == 0) V[1] = g.n1;
     bn_stage<G>(g, g.A(), V);
     montmul<G, false, true>(T, U, g.A(), N, g.n1, g.gl);            // S v / R'
-    load_limbs_global<G>(V, ncst + CL::OFF_R2, g.gl);
+    load_limbs_global<G>(V, out + BC::OFF_R2N, g.gl);             // (R^2 mod n as stored above: zeros for a rejected modulus)
     bn_stage<G>(g, g.A(), V);
     montmul<G, false, true>(U, T, g.A(), N, g.n1, g.gl);            // S v mod n (< 2 n)
     bn_mod_n<G>(g, U, N, g.A());                                    // canonical (reads R2N from `out`: stored above by this lane)
@@ -458,6 +474,10 @@ __global__ void __launch_bounds__(64) k_setup_basen(const uint32_t* __restrict__
     for (int k = 0; k < W; k++) T[k] = N[k] + (LMASK - U[k]);
     if (g.gl == 0) T[0] += 1;
     normalize_exact<G>(T, g.gl);                                    // n - val (the carry out of the top limb is 2^(29 L): dropped)
+    if (!sane) {
+#pragma unroll
+      for (int k = 0; k < W; k++) T[k] = 0;
+    }
     store_limbs_global<G>(out + BC::OFF_C3, T, g.gl);
     wave_lds_fence();
     lds_store_block(lds_raw + 704 + g.gl * BLK, T);
@@ -506,6 +526,10 @@ __global__ void __launch_bounds__(64) k_setup_basen(const uint32_t* __restrict__
   uint32_t OA[W], OB[W];
   limbs_from_words_at(OA, aw, g.gl * W);
   limbs_from_words_at(OB, bw, g.gl * W);
+  if (!sane) {
+#pragma unroll
+    for (int k = 0; k < W; k++) { OA[k] = 0; OB[k] = 0; }
+  }
   wave_lds_fence();
   // RR = R'^2 mod n^2 = (Montgomery form of 2)^CAP in the Montgomery domain: square-and-multiply on pairs.  The pair is kept in a small
   // table in global memory behind the constants (entry 0: the Montgomery form of 2, the multiplier).
@@ -579,14 +603,16 @@ __global__ void __launch_bounds__(256, ZKP_WPE) k_expected(EncArgs a, uint32_t* 
       load_modulus_consts<GS>(g, cst);
     }
     // (uniform control flow: groups of Open rows compute along on their c_j times 1 and store nothing)
+    // (a key whose set-up was rejected — even —: its groups multiply zeros, so that the lane above them still receives a zero low limb)
+    const bool valid = cst[CL::OFF_ST] == 0;
     uint32_t A[W], R[W], Y[W];
-    load_value<GS>(g, A, pexp, 2 * kw);
+    load_value<GS>(g, A, pexp, valid ? 2 * kw : 0);
     stage_const<GS>(g, cst + CL::OFF_R2);
     mm<GS>(g, R, A);                                          // e R
     {
       uint32_t t[W];
-      load_value<GS>(g, t, a.cipher_x + b * 2 * kw, mask_row ? 2 * kw : 0);
-      if (!mask_row && g.gl == 0) t[0] = 1;
+      load_value<GS>(g, t, a.cipher_x + b * 2 * kw, (mask_row && valid) ? 2 * kw : 0);
+      if (!mask_row && valid && g.gl == 0) t[0] = 1;
       stageB<GS>(g, t);
     }
     mm<GS>(g, Y, R);                                          // e * x   (< 2 n^2)
@@ -751,6 +777,33 @@ __global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen(EncArgs a, c
         }
       }
       uint32_t* dp = dstk == D_RAW ? rawdst : dstk == D_STAGE ? scrU + L : tab + dstk * E;    // where the a part goes (staged: via the scratch entry)
+#if ZKP_BN_PEND_PRODUCTS
+      // A product whose result becomes the staged pair keeps its new a part IN REGISTERS from slot 1 to slot 2 (P: staged into A() inside
+      // slot 2's product, once the digits there are read — what the squarings do with theirs), and slot 2 multiplies by the ra slot 1
+      // loaded: 864 B of global traffic per window multiplication less than parking the a part in the scratch entry and loading ra twice
+      // (round 5, profiles/r05/traffic_split.json).  Table and raw destinations store the a part where it belongs, as before.
+      const bool to_stage = dstk == D_STAGE || dstk == TABS + 2;
+      uint32_t P[W], U[W];
+#pragma unroll 1
+      for (int slot = has_p0 ? 0 : 1; slot < 3; slot++) {
+        if (slot != 2) load_limbs_global<G>(T, tab + src * E + (slot == 0 ? L : 0), g.gl);
+        uint32_t R[W];
+        bn_mul_impl<G, true>(R, T, slot == 2 ? g.B() : g.A(), g, slot, g.A(), P, slot == 2 && to_stage);
+        if (slot == 0) store_limbs_global<G>(scrU, R, g.gl);      // (kept in registers instead, U is spilled around both product bodies: the same bytes by another road)
+        else if (slot == 1) {
+          if (dstk != D_STAGE) store_limbs_global<G>(dp, R, g.gl);
+#pragma unroll
+          for (int k = 0; k < W; k++) P[k] = R[k];
+        } else {
+          if (has_p0) {
+            load_limbs_global<G>(U, scrU, g.gl);
+            bn_add<G>(R, R, U, g.gl);
+          }
+          if (to_stage) bn_stage<G>(g, g.B(), R);
+          if (dstk != D_STAGE) store_limbs_global<G>(dp + L, R, g.gl);
+        }
+      }
+#else      // the round-4 slots: the a part parked in the scratch entry, ra loaded by slot 1 and by slot 2 (A/B builds)
 #pragma unroll 1
       for (int slot = has_p0 ? 0 : 1; slot < 3; slot++) {
         // (slot 2 reads the a side's digits inside the product; the a part follows them into A() afterwards, below)
@@ -774,6 +827,7 @@ __global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen(EncArgs a, c
           if (dstk != D_STAGE) store_limbs_global<G>(dp + L, R, g.gl);
         }
       }
+#endif
       if (stage_id == 0) {
         // the base is in the Montgomery domain and staged: it is entry 0 of the window table
         uint32_t V[W];
@@ -795,12 +849,11 @@ __global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen(EncArgs a, c
 // Table slot of a group: 64 entries, then (U | -) scratch, (r | -), (1 | m).
 constexpr int BN_KEYS_WIN = 6, BN_KEYS_TAB = 1 << BN_KEYS_WIN, BN_KEYS_TAB_ENTRIES = BN_KEYS_TAB + 3;
 template <int G>
-__global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen_keys(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ all_ok, uint32_t* __restrict__ table,
+__global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen_keys(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ zero_rec, uint32_t* __restrict__ table,
                                                            uint32_t* __restrict__ raw) {
   using BC = BnConst<G>;
   using BL = BnLds<G>;
   constexpr int L = Geo<G>::L, E = 2 * L, WIN = BN_KEYS_WIN, TB = BN_KEYS_TAB;
-  (void)all_ok;      // (the batch-wide flag is a diagnostic now: items are partitioned key by key, below)
   extern __shared__ __align__(16) uint32_t lds_raw[];
   Bn<G> g;
   {
@@ -826,12 +879,14 @@ __global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen_keys(EncArgs
     const uint64_t item = live ? idx : count - 1;
     const BnItem it = bn_item(a, item, nullptr);
     const uint64_t key = bn_key(a, item, it);
-    const uint32_t* cst = bcst + key * BC::STRIDE;
     const uint32_t* pn = a.n + key * a.n_stride;               // the item's exponent
-    // A key the form does not take (even, short, an M~ beyond the digit-sum bound): its group computes along on whatever constants the
-    // set-up left (no address depends on them) and stores nothing; the item goes on the list of the n^2-sized launch behind this one.
-    // One such key in a batch of 4096 costs one Enc on the other kernels, not the whole launch (round 4: the whole launch fell back).
-    const bool key_ok = cst[BC::OFF_OK] != 0;
+    // A key the form does not take (even, short, an M~ beyond the digit-sum bound): the item goes on the list of the n^2-sized launch behind
+    // this one, and its group computes along on an ALL-ZERO record (`zero_rec`) and stores nothing.  Zeros, not whatever the set-up left:
+    // the lane above a group takes that group's lowest limb for zero after every sub-step (bigint29.hpp from_next), which only a proper
+    // Montgomery reduction — or zeros — guarantees; an even modulus has neither.  One such key in a batch of 4096 costs one Enc on the
+    // other kernels, not the whole launch (round 4: the whole launch fell back).
+    const bool key_ok = bcst[key * BC::STRIDE + BC::OFF_OK] != 0;
+    const uint32_t* cst = key_ok ? bcst + key * BC::STRIDE : zero_rec;
     if (live && !key_ok && g.gl == 0) a.left_list[atomicAdd(a.left_count, 1ull)] = (uint32_t)item;
     g.cst = cst;
     load_limbs_global<G>(g.NT, cst + BC::OFF_MT, g.gl);
@@ -942,8 +997,8 @@ __global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen_keys(EncArgs
 }
 
 template <int G>
-__global__ void __launch_bounds__(256) k_basen_finish(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ ok_word /* the key's OFF_OK, or the batch's all_ok */,
-                                                      int per_key, const uint32_t* __restrict__ raw, const uint32_t* __restrict__ expected) {
+__global__ void __launch_bounds__(256) k_basen_finish(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ ok_word /* the key's OFF_OK, or the constant 1 */,
+                                                      int per_key, const uint32_t* __restrict__ raw, const uint32_t* __restrict__ expected, const uint32_t* __restrict__ zero_rec) {
   using BC = BnConst<G>;
   using BL = BnLds<G>;
   constexpr int L = Geo<G>::L, E = 2 * L;
@@ -964,13 +1019,19 @@ __global__ void __launch_bounds__(256) k_basen_finish(EncArgs a, const uint32_t*
     const BnItem it = bn_item(a, item, expected);
     bool mine = live;
     if (per_key) {
-      g.cst = bcst + bn_key(a, item, it) * BC::STRIDE;
+      const uint32_t* rec = bcst + bn_key(a, item, it) * BC::STRIDE;
+      const bool key_ok = rec[BC::OFF_OK] != 0;
+      mine = live && key_ok;                                     // (an item of a key outside the form belongs to the n^2-sized launch;
+      g.cst = key_ok ? rec : zero_rec;                          //  its group computes along on zeros: see k_enc_basen_keys)
       g.n1 = g.cst[BC::OFF_NI];
-      mine = live && g.cst[BC::OFF_OK] != 0;                   // (an item of a key outside the form belongs to the n^2-sized launch)
     }
     uint32_t A1[W], B1[W], LO[W], HI[W];
     load_limbs_global<G>(A1, raw + item * E, g.gl);
     load_limbs_global<G>(B1, raw + item * E + L, g.gl);
+    if (per_key && !mine) {
+#pragma unroll
+      for (int k = 0; k < W; k++) { A1[k] = 0; B1[k] = 0; }
+    }
     bn_canonical<G>(g, A1, B1, LO, HI);
     if (a.mode == 0) {
       // exact limbs -> 32-bit words, through the group's LDS (2 L limbs + 3 words of zero padding)

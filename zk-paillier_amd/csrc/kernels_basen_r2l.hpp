@@ -18,7 +18,11 @@
 // (a clear bit multiplies the accumulator by the Montgomery form of 1 — the same value, the same slot, no divergence: the exponent is the
 // launch's key, every wavefront walks the same bits).  2048 + 4 slots of 72 sub-steps instead of 2048 products of 144: half the chain.
 // There is no window table and no schedule; everything an Enc touches between its operands and its raw pair lives in 8 KB of LDS.
-// The raw pair goes to k_basen_finish like that of k_enc_basen.  40 of the 64 lanes work: this is the kernel of calls that leave the chip
+// The raw pair goes to k_basen_finish like that of k_enc_basen.  The kernel carries its own lane geometry (template parameter RW, limbs per
+// lane): 9 — five groups of 8 lanes, the engine's own — or 6 — five groups of 12 lanes: a lone wavefront on a SIMD issues a multiply-add only
+// every 8 cycles whatever it depends on, so what its chain costs is the NUMBER of instructions, and 6 limbs per lane are 12 multiply-adds per
+// sub-step where 9 are 18 (the 60 lanes of five 12-lane groups straddle the 16-lane DPP rows: neighbours by wave_shl / wave_shr, the quotient
+// digit by ds_bpermute).  40 / 60 of the 64 lanes work: this is the kernel of calls that leave the chip
 // idle anyway (up to 2 wavefronts per SIMD: 8 proofs); from there on k_enc_basen<8> (8 Enc per wavefront) and the throughput engine take over.
 //
 // Replaces, like k_enc: kzen-paillier EncryptWithChosenRandomness at range_proof.rs:165-169,179-183,280-291,330-334 — for the call shape
@@ -31,8 +35,6 @@ namespace zkp {
 #if ZKP_W == 9
 
 namespace r2l {
-constexpr int G = 8;                       // lanes per n-sized integer
-constexpr int AW = G * BLK;                // words per LDS area (one staged integer: 8 lane blocks of 12 words)
 // LDS areas of a wavefront (word offsets / AW)
 enum Area {
   SA0, SA1,      // A's staged a_k, then its quotient digits Q_k (by slot parity)
@@ -51,70 +53,156 @@ enum Area {
   RL,            // the item's r as limbs: A's register operand of the step into the Montgomery domain
   NAREAS
 };
-constexpr int LDS_WORDS = NAREAS * AW;
-}  // namespace r2l
+constexpr int LIMBS = 72;                  // an n-sized integer (n of 2048 bits)
 
-// R = (X * B + c0 + q M~) / R' over the group's 8 lanes; digits go, four at a time, over the consumed limbs of B in the lanes of `qmask`
+// lane geometry: RW limbs per lane, RG = 72 / RW lanes per integer, lane blocks of RBLK words in LDS
+template <int RW> struct Geom {
+  static_assert(RW == 9 || RW == 6, "five groups of 8 or of 12 lanes");
+  static constexpr int RG = LIMBS / RW;
+  static constexpr int RBLK = (RW + 3) & ~3;
+  static constexpr int AW = RG * RBLK;                       // words per area: 96 either way
+  static constexpr int LDS_WORDS = NAREAS * AW;
+};
+
+template <int RW> __device__ __forceinline__ void blk_load(uint32_t (&v)[RW], const uint32_t* p) {
+#pragma unroll
+  for (int i = 0; i + 4 <= RW; i += 4) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p + i);
+    v[i] = a.x; v[i + 1] = a.y; v[i + 2] = a.z; v[i + 3] = a.w;
+  }
+  if constexpr (RW % 4 == 1) v[RW - 1] = p[RW - 1];
+  else if constexpr (RW % 4 == 2) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p + RW - 2);
+    v[RW - 2] = a.x; v[RW - 1] = a.y;
+  }
+}
+template <int RW> __device__ __forceinline__ void blk_store(uint32_t* p, const uint32_t (&v)[RW]) {
+#pragma unroll
+  for (int i = 0; i + 4 <= RW; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  if constexpr (RW % 4 == 1) p[RW - 1] = v[RW - 1];
+  else if constexpr (RW % 4 == 2) *reinterpret_cast<uint2*>(p + RW - 2) = make_uint2(v[RW - 2], v[RW - 1]);
+}
+template <int RW> __device__ __forceinline__ void limbs_global_load(uint32_t (&v)[RW], const uint32_t* p, int gl) {
+#pragma unroll
+  for (int k = 0; k < RW; k++) v[k] = p[gl * RW + k];
+}
+template <int RW> __device__ __forceinline__ void limbs_global_store(uint32_t* p, const uint32_t (&v)[RW], int gl) {
+#pragma unroll
+  for (int k = 0; k < RW; k++) p[gl * RW + k] = v[k];
+}
+template <int RW> __device__ __forceinline__ void limbs_from_words(uint32_t (&v)[RW], const uint32_t* words, int gl) {
+#pragma unroll
+  for (int k = 0; k < RW; k++) {
+    const int bit = (gl * RW + k) * LB;
+    const int w0 = bit >> 5, off = bit & 31;
+    const uint64_t x = (uint64_t)words[w0] | ((uint64_t)words[w0 + 1] << 32);
+    v[k] = (uint32_t)(x >> off) & LMASK;
+  }
+}
+// lane j <- lane j + 1 (the top lane of a group receives the next group's lane 0: the low limb of a bottom column the quotient digit has
+// just made zero — idle lanes compute on zeros —, as in bigint29.hpp from_next).  12-lane groups cross the 16-lane DPP rows: wave_shl.
+template <int RW> __device__ __forceinline__ uint32_t next_lane(uint32_t v) {
+  if constexpr (RW == 9) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
+  else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+}
+template <int RW> __device__ __forceinline__ uint32_t prev_lane(uint32_t v, int gl) {
+  uint32_t t;
+  if constexpr (RW == 9) t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+  else t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+  return gl == 0 ? 0u : t;
+}
+// lane 0 of the group -> every lane of the group.  lead4: byte address of the group's lane 0 for ds_bpermute (12-lane groups)
+template <int RW> __device__ __forceinline__ uint32_t lead_bcast(uint32_t v, int lead4) {
+  if constexpr (RW == 9) { (void)lead4; return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0018); }
+  else return (uint32_t)__builtin_amdgcn_ds_bpermute(lead4, (int)v);
+}
+template <int RW> __device__ __forceinline__ void dbl(uint32_t (&X)[RW], int gl) {
+  uint32_t cy = 0;
+#pragma unroll
+  for (int k = 0; k < RW; k++) { const uint32_t t = (X[k] << 1) + cy; X[k] = t & LMASK; cy = t >> LB; }
+  X[0] += prev_lane<RW>(cy, gl);
+}
+template <int RW> __device__ __forceinline__ void add(uint32_t (&R)[RW], const uint32_t (&A)[RW], const uint32_t (&B)[RW], int gl) {
+  uint32_t cy = 0;
+#pragma unroll
+  for (int k = 0; k < RW; k++) { const uint32_t t = A[k] + B[k] + cy; R[k] = t & LMASK; cy = t >> LB; }
+  R[0] += prev_lane<RW>(cy, gl);
+}
+__device__ __forceinline__ void q_write2(uint64_t qmask, uint32_t addr, uint32_t q0, uint32_t q1) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 v = {q0, q1};
+  uint64_t saved;
+  asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0\n\ts_nop 0" : "=&s"(saved) : "s"(qmask), "v"(addr), "v"(v) : "scc");
+}
+
+// R = (X * B + c0 + q M~) / R' over the group's lanes; digits go over the consumed limbs of B in the lanes of `qmask`
 // (bn_mul_impl of kernels_basen.hpp with everything that varies turned into data)
-__device__ __forceinline__ void r2l_product(uint32_t (&R)[W], const uint32_t (&X)[W], const uint32_t* ldsB, const uint32_t (&NT)[W], uint64_t (&c)[W],
-                                            uint64_t qmask, int gl) {
-  constexpr int G = r2l::G;
+template <int RW>
+__device__ __forceinline__ void product(uint32_t (&R)[RW], const uint32_t (&X)[RW], const uint32_t* ldsB, const uint32_t (&NT)[RW], uint64_t (&c)[RW],
+                                        uint64_t qmask, int gl, int lead4) {
+  using GM = Geom<RW>;
 #pragma unroll 1
-  for (int s = 0; s < G; s++) {
+  for (int s = 0; s < GM::RG; s++) {
     uint32_t qd[4];
-    const uint32_t row_addr = lds_byte_address(ldsB + s * BLK);
+    const uint32_t row_addr = lds_byte_address(ldsB + s * GM::RBLK);
 #pragma unroll
-    for (int t = 0; t < W; t++) {
-      const uint32_t b = ldsB[s * BLK + t];
+    for (int t = 0; t < RW; t++) {
+      const uint32_t b = ldsB[s * GM::RBLK + t];
 #pragma unroll
-      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)X[k] * b;
-      const uint32_t q = bcast0<G>((uint32_t)c[t] & LMASK);
+      for (int k = 0; k < RW; k++) c[(t + k) % RW] += (uint64_t)X[k] * b;
+      const uint32_t q = lead_bcast<RW>((uint32_t)c[t] & LMASK, lead4);
       qd[t & 3] = q;
-      ZKP_BN_QWRITE(qmask, row_addr, t, qd);
+      if ((t & 3) == 3) q_write(qmask, row_addr + (t - 3) * 4, qd);
+      else if (t == RW - 1 && (RW & 3) == 1) q_write1(qmask, row_addr + t * 4, qd[t & 3]);
+      else if (t == RW - 1 && (RW & 3) == 2) q_write2(qmask, row_addr + (t - 1) * 4, qd[(t - 1) & 3], qd[t & 3]);
 #pragma unroll
-      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)NT[k] * q;
+      for (int k = 0; k < RW; k++) c[(t + k) % RW] += (uint64_t)NT[k] * q;
       const uint64_t v = c[t];
-      c[(t + 1) % W] += v >> LB;
-      c[t] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+      c[(t + 1) % RW] += v >> LB;
+      c[t] = (uint64_t)next_lane<RW>((uint32_t)v & LMASK);
     }
   }
   uint64_t cy = 0;
 #pragma unroll
-  for (int k = 0; k < W; k++) {
+  for (int k = 0; k < RW; k++) {
     const uint64_t t = c[k] + cy;
     R[k] = (uint32_t)t & LMASK;
     cy = t >> LB;
   }
-  R[0] += from_prev<G>((uint32_t)cy, gl);
+  R[0] += prev_lane<RW>((uint32_t)cy, gl);
 }
+}  // namespace r2l
 
-// One wavefront per workgroup, one Enc per claim.  `ok`: the key's OFF_OK word (a key the form does not take: return at once, the launch
-// behind this one — which claims from the same counter — does the work).
+// One wavefront per workgroup, one Enc per claim.  bcst[OFF_OK] == 0 (a key the form does not take): return at once, the launch behind this
+// one — which claims from the same counter — does the work.
+template <int RW>
 __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t* __restrict__ bcst, uint32_t* __restrict__ raw) {
   using namespace r2l;
-  using BC = BnConst<G>;
-  constexpr int L = Geo<G>::L, E = 2 * L;
+  using GM = Geom<RW>;
+  using BC = BnConst<8>;                     // (the key's record: limb-linear arrays of 72 limbs, whatever the lanes)
+  constexpr int L = LIMBS, E = 2 * L, RG = GM::RG, AW = GM::AW, RBLK = GM::RBLK;
   if (!bcst[BC::OFF_OK]) return;
-  __shared__ __align__(16) uint32_t lds[LDS_WORDS];
-  const int lane = threadIdx.x & 63, role = lane >> 3, gl = lane & 7;
+  __shared__ __align__(16) uint32_t lds[GM::LDS_WORDS];
+  const int lane = threadIdx.x & 63, role = lane / RG, gl = lane - role * RG;
+  const int lead4 = (lane - gl) * 4;
   auto area = [&](int i) -> uint32_t* { return lds + i * AW; };
-  auto blk = [&](int i) -> uint32_t* { return lds + i * AW + gl * BLK; };
+  auto blk = [&](int i) -> uint32_t* { return lds + i * AW + gl * RBLK; };
   const int kw = a.n_bits / 32;
   const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
-  uint32_t NT[W];
-  load_limbs_global<G>(NT, bcst + BC::OFF_MT, gl);
+  uint32_t NT[RW];
+  limbs_global_load<RW>(NT, bcst + BC::OFF_MT, gl);
   const uint32_t n1 = bcst[BC::OFF_NI];
   // constants into their areas (every group stores the same blocks: harmless)
   {
-    uint32_t T[W];
-    load_limbs_global<G>(T, bcst + BC::OFF_C3, gl);  lds_store_block(blk(C3A), T);
-    load_limbs_global<G>(T, bcst + BC::OFF_R1A, gl); lds_store_block(blk(ONEA), T);
-    load_limbs_global<G>(T, bcst + BC::OFF_R1B, gl); lds_store_block(blk(ONEB), T);
+    uint32_t T[RW];
+    limbs_global_load<RW>(T, bcst + BC::OFF_C3, gl);  blk_store<RW>(blk(C3A), T);
+    limbs_global_load<RW>(T, bcst + BC::OFF_R1A, gl); blk_store<RW>(blk(ONEA), T);
+    limbs_global_load<RW>(T, bcst + BC::OFF_R1B, gl); blk_store<RW>(blk(ONEB), T);
 #pragma unroll
-    for (int k = 0; k < W; k++) T[k] = 0;
-    lds_store_block(blk(ZERO), T);
+    for (int k = 0; k < RW; k++) T[k] = 0;
+    blk_store<RW>(blk(ZERO), T);
     if (gl == 0) T[0] = 1;
-    lds_store_block(blk(INT1), T);
+    blk_store<RW>(blk(INT1), T);
   }
   // bit length of the exponent (the key): wave-uniform
   int t_bits = 0;
@@ -131,23 +219,23 @@ __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t*
     if (base >= count) break;
     const uint64_t item = base;
     const BnItem it = bn_item(a, item, nullptr);
-    // ---- the item's r and m as limb blocks: r -> DA1 (B's multiplier of slot 0) and the register operand of A's first slot; m -> MM
+    // ---- the item's r and m as limb blocks: r -> DA1 (B's multiplier of slot 0) and RL (A's register operand of slot -1); m -> MM
     {
-      uint32_t T[W];
+      uint32_t T[RW];
       wave_lds_fence();
       for (int w = lane; w < 72; w += 64) area(WBUF)[w] = (w < it.rw) ? it.pr[w] : 0u;
       wave_lds_fence();
-      limbs_from_words_at(T, area(WBUF), gl * W);
+      limbs_from_words<RW>(T, area(WBUF), gl);
       wave_lds_fence();
-      lds_store_block(blk(DA1), T);
-      lds_store_block(blk(RL), T);
+      blk_store<RW>(blk(DA1), T);
+      blk_store<RW>(blk(RL), T);
       for (int w = lane; w < 72; w += 64) area(WBUF)[w] = (it.pm && w < it.mw) ? it.pm[w] : 0u;
       wave_lds_fence();
-      limbs_from_words_at(T, area(WBUF), gl * W);
+      limbs_from_words<RW>(T, area(WBUF), gl);
       wave_lds_fence();
-      lds_store_block(blk(MM), T);
-      load_limbs_global<G>(T, bcst + BC::OFF_RRA, gl); lds_store_block(blk(SA1), T);      // slot -1: A multiplies r by RR's a part (parity of -1: 1)
-      load_limbs_global<G>(T, bcst + BC::OFF_RRB, gl); lds_store_block(blk(SB), T);       // slot  0: B multiplies r by RR's b part
+      blk_store<RW>(blk(MM), T);
+      limbs_global_load<RW>(T, bcst + BC::OFF_RRA, gl); blk_store<RW>(blk(SA1), T);      // slot -1: A multiplies r by RR's a part (parity of -1: 1)
+      limbs_global_load<RW>(T, bcst + BC::OFF_RRB, gl); blk_store<RW>(blk(SB), T);       // slot  0: B multiplies r by RR's b part
       wave_lds_fence();
     }
     // ---- the slots
@@ -168,60 +256,61 @@ __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t*
       if (role == 4 && actE) { xa = fin1 ? (int)MM : (int)QQ; ba = fin1 ? (int)SE0 + (t_bits & 1) : (bit_prev ? SE0 + prev : (int)ONEA); d0 = fin1 ? (int)UU : dummy; }
       // (fin1: C stages p over PX itself and leaves Q'' there; E needs an untouched copy of p: SE[t & 1] is rewritten with it below, at the end of slot t)
       // lanes that write quotient digits: lane 0 of A, lane 0 of C (an SGPR pair for s_and_saveexec: made uniform explicitly)
-      const uint64_t qmask = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((actA ? 1u : 0u) | ((actC ? 1u : 0u) << 16)));
-      uint32_t X[W], R[W];
-      uint64_t c[W];
+      const uint32_t qlo = (actA ? 1u : 0u) | ((actC && 2 * RG < 32) ? 1u << ((2 * RG) & 31) : 0u);
+      const uint64_t qmask = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)qlo);
+      uint32_t X[RW], R[RW];
+      uint64_t c[RW];
       wave_lds_fence();
-      lds_load_block(X, blk(xa));
+      blk_load<RW>(X, blk(xa));
       {
-        uint32_t Q[W], C3[W];
-        lds_load_block(Q, blk(qa < 0 ? (int)ZERO : qa));
-        lds_load_block(C3, blk(qa < 0 ? (int)ZERO : (int)C3A));
+        uint32_t Q[RW], C3[RW];
+        blk_load<RW>(Q, blk(qa < 0 ? (int)ZERO : qa));
+        blk_load<RW>(C3, blk(qa < 0 ? (int)ZERO : (int)C3A));
         const uint32_t n1e = qa < 0 ? 0u : n1;
 #pragma unroll
-        for (int i = 0; i < W; i++) c[i] = (uint64_t)C3[i] + (uint64_t)((1u << LB) - Q[i]) * n1e;
+        for (int i = 0; i < RW; i++) c[i] = (uint64_t)C3[i] + (uint64_t)((1u << LB) - Q[i]) * n1e;
       }
       wave_lds_fence();
-      r2l_product(R, X, area(ba), NT, c, qmask, gl);
+      product<RW>(R, X, area(ba), NT, c, qmask, gl, lead4);
       wave_lds_fence();
-      lds_store_block(blk(d0), R);
+      blk_store<RW>(blk(d0), R);
       wave_lds_fence();
       // ---- what follows a result
       if (role == 0 && actA) {
-        lds_store_block(blk(SE0 + prev), R);
-        uint32_t T[W];
+        blk_store<RW>(blk(SE0 + prev), R);
+        uint32_t T[RW];
         if (nbit(k + 1)) {
 #pragma unroll
-          for (int i = 0; i < W; i++) T[i] = R[i];
-        } else lds_load_block(T, blk(ONEA));
-        lds_store_block(blk(SC0 + prev), T);                         // C's multiplier of the next slot: a_(k+1), or the Montgomery one
-        if (k < 0) lds_store_block(blk(PC0 + par), R);               // the accumulator starts as s_0: p_1 = a_0 (n is odd), read by C in slot 1
+          for (int i = 0; i < RW; i++) T[i] = R[i];
+        } else blk_load<RW>(T, blk(ONEA));
+        blk_store<RW>(blk(SC0 + prev), T);                           // C's multiplier of the next slot: a_(k+1), or the Montgomery one
+        if (k < 0) blk_store<RW>(blk(PC0 + par), R);                 // the accumulator starts as s_0: p_1 = a_0 (n is odd), read by C in slot 1
 #pragma unroll
-        for (int i = 0; i < W; i++) T[i] = R[i];
-        bn_double<G>(T, gl);
-        lds_store_block(blk(DA0 + prev), T);
+        for (int i = 0; i < RW; i++) T[i] = R[i];
+        dbl<RW>(T, gl);
+        blk_store<RW>(blk(DA0 + prev), T);
       }
-      if (role == 1 && actB && k == 0) lds_store_block(blk(QQ), R);  // q_1 = b_0
+      if (role == 1 && actB && k == 0) blk_store<RW>(blk(QQ), R);    // q_1 = b_0
       if (role == 2 && actC) {
-        if (fin1) { if (item < count) store_limbs_global<G>(raw + item * E, R, gl); }
-        else lds_store_block(blk(PX), R);
+        if (fin1) limbs_global_store<RW>(raw + item * E, R, gl);
+        else blk_store<RW>(blk(PX), R);
       }
       if (role == 2 && k == t_bits) {                                // p_t once more, for E's product by m in the next slot (C stages PX itself there)
-        uint32_t T[W];
-        lds_load_block(T, blk(PX));
-        lds_store_block(blk(SE0 + (t_bits & 1)), T);
+        uint32_t T[RW];
+        blk_load<RW>(T, blk(PX));
+        blk_store<RW>(blk(SE0 + (t_bits & 1)), T);
       }
       if (role == 4 && actE && !fin1) {
-        uint32_t D[W];
-        lds_load_block(D, blk(RD));
-        bn_add<G>(R, R, D, gl);
-        lds_store_block(blk(QQ), R);
+        uint32_t D[RW];
+        blk_load<RW>(D, blk(RD));
+        add<RW>(R, R, D, gl);
+        blk_store<RW>(blk(QQ), R);
       }
       if (role == 3 && fin2) {
-        uint32_t U[W];
-        lds_load_block(U, blk(UU));
-        bn_add<G>(R, R, U, gl);
-        store_limbs_global<G>(raw + item * E + L, R, gl);
+        uint32_t U[RW];
+        blk_load<RW>(U, blk(UU));
+        add<RW>(R, R, U, gl);
+        limbs_global_store<RW>(raw + item * E + L, R, gl);
       }
     }
   }

@@ -69,6 +69,7 @@ struct zkp_ctx {
   int bn_last_g = 0;                   // lanes per n-sized integer of the most recent base-n launch (0: none yet)
   bool bn_last_per_key = false;        // ... and whether it ran under per-proof keys
   bool bn_last_r2l = false;            // ... and whether it was the one-Enc-per-wavefront ladder of the latency engine (kernels_basen_r2l.hpp)
+  int bn_r2l_lanes = 12;               // ... its lane geometry: 12 lanes x 6 limbs per n-sized integer, or 8 x 9 ($ZKP_R2L_LANES at ctx create)
   int bn_r2l = 1;                      // that ladder: 0 = never, 1 = the library's rule (launches of up to two wavefronts per SIMD), 2 = whenever it can run (tests); $ZKP_R2L at ctx create
   DevBuf bn_flag;                      // device word: every key of the last batched base-n set-up qualified   // base-n form (kernels_basen.hpp): set-up record of n, its base-n constants, window tables, Mask-row products
   // timing of the dominant kernels
@@ -514,8 +515,8 @@ extern template __global__ void zkp::k_enc_basen<BN_GA>(EncArgs, const uint32_t*
 extern template __global__ void zkp::k_enc_basen<BN_GB>(EncArgs, const uint32_t*, uint32_t*, uint32_t*);
 extern template __global__ void zkp::k_enc_basen_keys<BN_GA>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 extern template __global__ void zkp::k_enc_basen_keys<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
-extern template __global__ void zkp::k_basen_finish<BN_GA>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
-extern template __global__ void zkp::k_basen_finish<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_basen_finish<BN_GA>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*);
+extern template __global__ void zkp::k_basen_finish<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*);
 extern template __global__ void zkp::k_setup_basen<BN_GA>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
 extern template __global__ void zkp::k_setup_basen<BN_GB>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
 extern template __global__ void zkp::k_expected<2 * BN_GA>(EncArgs, uint32_t*, const uint32_t*);
@@ -543,7 +544,9 @@ static int enc_form_from_env() {
 template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uint64_t n_stride, uint64_t nkeys, uint32_t n_bits) {
   int32_t st = run_setup<G>(c, n, n_stride, (int)(n_bits / 32), 0, nkeys, c->bn_ncst);
   if (st) return st;
-  if ((st = ensure(c, c->bn_consts, (size_t)nkeys * BnConst<G>::STRIDE * sizeof(uint32_t)))) return st;
+  if ((st = ensure(c, c->bn_consts, (size_t)(nkeys + 1) * BnConst<G>::STRIDE * sizeof(uint32_t)))) return st;
+  // record `nkeys`: all zero — what the groups of keys outside the form compute on (k_enc_basen_keys)
+  HIPCHK(c, hipMemsetAsync((char*)c->bn_consts.p + (size_t)nkeys * BnConst<G>::STRIDE * sizeof(uint32_t), 0, BnConst<G>::STRIDE * sizeof(uint32_t), c->stream));
   if ((st = ensure(c, c->bn_flag, 64))) return st;
   HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->bn_flag.p, 1, 2, c->stream));      // word 0: every key of the batch qualified (cleared by k_setup_basen); word 1: the constant 1
   constexpr unsigned GPB = 64 / G;
@@ -571,7 +574,7 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
     // finds nothing to claim).  c->bn_r2l: 0 = never, 1 = the library's rule, 2 = whenever the kernel can take the launch (tests).
     bool r2l_launch = false;
 #if ZKP_W == 9
-    if constexpr (G == r2l::G)
+    if constexpr (G == 8)
       r2l_launch = !per_key && c->bn_r2l && a.n_bits == 2048 && (c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && a.count <= 2ull * 4 * (uint64_t)c->cus));
 #endif
     if (!per_key && !a.sched && !r2l_launch) return false;       // (a shared key whose launch takes the pair ladder of the latency engine)
@@ -624,21 +627,23 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
     c->bn_last_g = G; c->bn_last_per_key = per_key; c->bn_last_r2l = r2l_launch;
 #if ZKP_W == 9
     if (r2l_launch) {
-      if constexpr (G == r2l::G) {
+      if constexpr (G == 8) {
         const unsigned waves = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(a.count, 8ull * 4 * (uint64_t)c->cus));
-        hipLaunchKernelGGL(k_enc_basen_r2l, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
+        // five groups of 12 lanes x 6 limbs (the default), or of 8 lanes x 9 limbs ($ZKP_R2L_LANES=8: A/B runs)
+        if (c->bn_r2l_lanes == 8) hipLaunchKernelGGL(k_enc_basen_r2l<9>, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
+        else hipLaunchKernelGGL(k_enc_basen_r2l<6>, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
       }
     } else
 #endif
     if (per_key)
-      hipLaunchKernelGGL(k_enc_basen_keys<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (const uint32_t*)c->bn_flag.p, (uint32_t*)c->bn_table.p,
+      hipLaunchKernelGGL(k_enc_basen_keys<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (const uint32_t*)c->bn_consts.p + (size_t)nkeys * BnConst<G>::STRIDE, (uint32_t*)c->bn_table.p,
                          (uint32_t*)c->bn_raw.p);
     else
       hipLaunchKernelGGL(k_enc_basen<G>, dim3(blocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_table.p,
                          (uint32_t*)c->bn_raw.p);
     const unsigned fblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, 8ull * c->cus));
     hipLaunchKernelGGL(k_basen_finish<G>, dim3(fblocks), dim3(256), BL::BYTES_PER_BLOCK, c->stream, a, (const uint32_t*)c->bn_consts.p, ok, per_key ? 1 : 0,
-                       (const uint32_t*)c->bn_raw.p, (const uint32_t*)c->bn_expected.p);
+                       (const uint32_t*)c->bn_raw.p, (const uint32_t*)c->bn_expected.p, (const uint32_t*)c->bn_consts.p + (size_t)nkeys * BnConst<G>::STRIDE);
     return true;
   }
 }
@@ -680,6 +685,7 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
 #endif
   if (const char* hc = std::getenv("ZKP_HOST_CHUNKS")) c->host_chunks = std::atoi(hc);
   if (const char* rl = std::getenv("ZKP_R2L")) c->bn_r2l = std::atoi(rl);
+  if (const char* rl = std::getenv("ZKP_R2L_LANES")) c->bn_r2l_lanes = std::atoi(rl) == 8 ? 8 : 12;
   c->owns_stream = own_stream;
   c->stream = stream;
   if (own_stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKP_EDEVICE; }
