@@ -62,10 +62,21 @@ template <int G> struct Geo {
 #ifndef ZKP_BCAST_DPP
 #define ZKP_BCAST_DPP 1
 #endif
+#ifndef ZKP_BCAST8_DPP
+#define ZKP_BCAST8_DPP 0      /* 8-lane groups (latency engine, n-sized integers): two DPP moves instead of ds_swizzle — A/B switch, see DESIGN.md section 8 */
+#endif
 template <int G> __device__ __forceinline__ uint32_t bcast0(uint32_t v) {
   static_assert(G == 2 || G == 4 || G == 8 || G == 16 || G == 32, "group size");
   if constexpr (ZKP_BCAST_DPP && G == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xA0 /*quad_perm:[0,0,2,2]*/, 0xf, 0xf, true);
   else if constexpr (ZKP_BCAST_DPP && G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
+#if ZKP_BCAST8_DPP
+  else if constexpr (G == 8) {
+    // 8-lane groups: lane 0 of every quad over its quad, then lanes 4-7 (and 12-15) of a row take their left neighbour quad's copy
+    // (row_shr:4 under bank mask 0b1010; the other lanes keep the first move's result): two dependent DPP moves, no trip through LDS
+    const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, t, 0x114 /*row_shr:4*/, 0xf, 0xa, false);
+  }
+#endif
   else if constexpr (G == 2) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x001E);
   else if constexpr (G == 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0000);
   else if constexpr (G == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x0010);
