@@ -54,6 +54,10 @@ int32_t zkp_diag_last_host_blocks(zkp_ctx* ctx);
  * 2 = every launch the kernel can take (tests).  $ZKP_R2L presets it at ctx create.  zkp_diag_r2l_last: 1 when the most recent Paillier
  * launch of the ctx ran on it. */
 int32_t zkp_diag_set_r2l(zkp_ctx* ctx, int32_t mode);
+/* limbs per lane of the mid engine (libzkp_hip_mid.so next to the library, or $ZKP_HIP_MID_LIB: the same sources at 18 limbs per lane,
+ * 16 Enc per wavefront in base-n form — Paillier calls of 41 ... 64 and 129 ... 192 proofs under one 2048-bit key); 0 when it is not loaded
+ * (the other engines then take those calls, a little slower, never differently).  zkp_ctx_set_geometry(ctx, 18) pins it. */
+int32_t zkp_diag_mid_limbs_per_lane(zkp_ctx* ctx);
 int32_t zkp_diag_r2l_last(zkp_ctx* ctx);
 
 #ifdef __cplusplus

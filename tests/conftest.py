@@ -48,13 +48,14 @@ def oracle():
 
 
 # (engine = limbs per lane, Enc form on the throughput engine)
-_CTX_PARAMS = [(36, "basen"), (36, "n2"), (9, None), (9, "pair")]
+_CTX_PARAMS = [(36, "basen"), (36, "n2"), (18, "basen"), (9, None), (9, "pair")]
 
 
-@pytest.fixture(scope="session", params=_CTX_PARAMS, ids=["w36-basen", "w36-n2", "w9", "w9-pair"])
+@pytest.fixture(scope="session", params=_CTX_PARAMS, ids=["w36-basen", "w36-n2", "w18-basen", "w9", "w9-pair"])
 def ctx(zkp, request):
     """one GPU context for the whole -m gpu session; fails loudly without GPU / built library.  Every test that takes it runs
-    three times: pinned to the throughput engine (36 limbs per lane) with every Paillier launch in BASE-n form (csrc/kernels_basen.hpp —
+    five times (the mid engine, 18 limbs per lane — libzkp_hip_mid.so, the Paillier calls of 41 ... 64 and 129 ... 192 proofs — with every
+    launch in base-n form is the third): pinned to the throughput engine (36 limbs per lane) with every Paillier launch in BASE-n form (csrc/kernels_basen.hpp —
     the kernels that carry the large batches), pinned to it with every launch on the n^2-sized kernels (the product's choice for launches
     that leave SIMDs idle, for keys the form does not take, and for n = 1024), pinned to the latency engine (9; libzkp_hip_lat.so) with its own
     rules (one 2048-bit key and a few proofs: the one-Enc-per-wavefront base-n ladder of csrc/kernels_basen_r2l.hpp), and pinned to it with

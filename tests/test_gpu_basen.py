@@ -29,7 +29,7 @@ def odd_modulus(rnd, bits):
     return rnd.getrandbits(bits) | 1 | (1 << (bits - 1))
 
 
-@pytest.fixture(scope="module", params=[36, 9], ids=["w36", "w9"])
+@pytest.fixture(scope="module", params=[36, 18, 9], ids=["w36", "w18", "w9"])
 def ctx(request):
     """a context of its own per engine — the form exists at 36 limbs per lane (2 / 4 lanes per n-sized integer, the kernels of the large
     batches) and at 9 (8 / 16 lanes, the latency engine: the kernels of the mid-size batches).  The batches here are small, so every
@@ -204,7 +204,7 @@ def test_range_proofs_under_per_proof_keys_with_keys_outside_the_form(oracle):
     oracle.range_ni_prove(pb_o.struct(), wt.struct(), None, None, None)
     c = zkp.Context(0)
     try:
-        for geometry in (36, 9):
+        for geometry in (36, 18, 9):
             c.set_geometry(geometry)
             c.set_enc_form("basen")
             pb = zkp.RangeBatch(n_bits, B, 128, shared_key=False)

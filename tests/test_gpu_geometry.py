@@ -68,9 +68,9 @@ def test_both_engines_and_the_oracle_agree_on_range_proof_ni(actx, oracle):
 
 
 def test_unknown_geometry_is_refused(actx):
-    with pytest.raises(zkp.ZkpError, match="no engine with 18 limbs"):
-        actx.set_geometry(18)
-    actx.set_geometry(36); actx.set_geometry(9); actx.set_geometry(0)
+    with pytest.raises(zkp.ZkpError, match="no engine with 12 limbs"):
+        actx.set_geometry(12)
+    actx.set_geometry(36); actx.set_geometry(18); actx.set_geometry(9); actx.set_geometry(0)
 
 
 def test_errors_of_a_routed_call_carry_their_text(actx):

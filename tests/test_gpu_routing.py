@@ -3,7 +3,8 @@
 A RangeProofNi call at n = 2048 under one key is served by one of these kernel families (csrc/zkp_api.hip: route_latency, launch_basen):
   * the latency engine (9 limbs per lane, libzkp_hip_lat.so) up to 96 proofs: ONE Enc per wavefront on the five-group base-n ladder
     (k_enc_basen_r2l) up to 8 proofs, the window ladder on the n^2-sized product up to 16, 8 Enc per wavefront in base-n form
-    (k_enc_basen<8>) from there on,
+    (k_enc_basen<8>) from there on — except
+  * 41 ... 64 and 129 ... 192 proofs: the mid engine (18 limbs per lane, libzkp_hip_mid.so), 16 Enc per wavefront in base-n form,
   * the throughput engine's base-n kernels (k_enc_basen<2>, 32 Enc per wavefront) beyond,
   * its n^2-sized kernels (k_enc<4, .>) for keys the form does not take and for launches pinned to that engine that leave SIMDs idle.
 The parity suites pin each family in turn (tests/conftest.py: ctx); this file lets the library choose, says which family it expects for
@@ -40,17 +41,23 @@ def compute_units():
 def expected_family(c, items):
     """what csrc/zkp_api.hip is expected to pick for a Paillier launch of `items` Enc under ONE 2048-bit key that the base-n form takes
     (route_latency with one_key_paillier, launch_basen of either engine)"""
-    lat = c.latency_limbs_per_lane()
-    cus = compute_units()
-    if lat == 9 and items <= 3 * 4 * cus * 8:                  # the latency engine: up to three wavefronts per SIMD at 8 Enc per wavefront
-        if items <= 2 * 4 * cus:
+    lat, mid = c.latency_limbs_per_lane(), c.mid_limbs_per_lane()
+    simds = 4 * compute_units()
+    if mid == 18 and (10 * simds < items <= 16 * simds or 32 * simds < items <= 48 * simds):
+        return "mid-basen"                                     # 16 Enc per wavefront: one (two) wavefronts per SIMD of the mid engine
+    if lat == 9 and items <= 3 * simds * 8:                    # the latency engine: up to three wavefronts per SIMD at 8 Enc per wavefront
+        if items <= 2 * simds:
             return "lat-r2l"                                   # one Enc per wavefront, the five-group ladder (kernels_basen_r2l.hpp)
-        return "lat-basen" if items > 4 * cus * 4 else "lat-n2"
-    return "base-n" if items > 4 * cus * 16 else "n2"
+        return "lat-basen" if items > simds * 4 else "lat-n2"
+    return "base-n" if items > simds * 16 else "n2"
 
 
 def family_that_ran(c):
-    if c.last_geometry() != zkp.load().zkp_build_limbs_per_lane():
+    g = c.last_geometry()
+    if g == 18:
+        lanes, ok = c.diag_basen_last()
+        return "mid-basen" if (lanes == 4 and ok) else "mid-n2"
+    if g != zkp.load().zkp_build_limbs_per_lane():
         if c.r2l_last():
             return "lat-r2l"
         lanes, ok = c.diag_basen_last()
@@ -68,7 +75,7 @@ def sub_batch(pb, idx, n_bits):
     return s
 
 
-@pytest.mark.parametrize("B", [4, 12, 32, 64, 96, 128, 300])
+@pytest.mark.parametrize("B", [4, 12, 32, 64, 96, 128, 160, 300])
 def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     n_bits, kw = 2048, 64
     n = H.fixture_key()[2]

@@ -17,7 +17,9 @@ synth = importlib.import_module("zk-paillier_amd.synth")
 ctx = zkp.Context(0)
 dev = torch.device("cuda", 0)
 sizes = [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 512, 768, 1024]
-FAMILIES = (("w36_n2", 36, "n2"), ("w36_basen", 36, "basen"), ("w9_n2", 9, "n2"), ("w9_basen", 9, "basen"), ("auto", 0, "auto"))
+LAT = ctx.latency_limbs_per_lane()          # 9 as shipped; $ZKP_HIP_LAT_LIB may name another build of the secondary engine (A/B runs)
+MID = ctx.mid_limbs_per_lane()
+FAMILIES = (("w36_n2", 36, "n2"), ("w36_basen", 36, "basen")) + ((("w18_basen", 18, "basen"),) if MID == 18 else ()) + ((f"w{LAT}_n2", LAT, "n2"), (f"w{LAT}_basen", LAT, "basen"), ("auto", 0, "auto"))
 
 
 def best_of(fn, reps=3):
@@ -36,13 +38,13 @@ for B in sizes:
     v = torch.zeros(B, dtype=torch.uint8, device=dev)
     rec = {"B": B}
     for name, geom, form in FAMILIES:
-        if geom == 9 and B > 256 or (name == "w36_basen" and B < 8):
+        if geom == LAT and B > 256 or (name == "w36_basen" and B < 8):
             continue
         ctx.set_geometry(geom); ctx.set_enc_form(form)
         rec[name] = [best_of(lambda: ctx.range_ni_prove(pb.struct(), wt.struct(), None, None, None, device=True)),
                      best_of(lambda: ctx.range_ni_verify(pb.struct(), v, device=True))]
         if name == "auto":
             lanes, ok = ctx.diag_basen_last()
-            rec["auto_ran"] = f"w{ctx.last_geometry()}_" + ("basen" if lanes and ok else "n2")
+            rec["auto_ran"] = f"w{ctx.last_geometry()}_" + ("r2l" if ctx.r2l_last() else "basen" if lanes and ok else "n2")
         assert bool(v.all()), (B, name)
     print(json.dumps(rec), flush=True)

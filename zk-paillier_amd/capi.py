@@ -49,6 +49,7 @@ DIAG_EXPORTS = {
     "zkp_diag_last_host_blocks": (C.c_int32, [C.c_void_p]),
     "zkp_diag_set_r2l": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_r2l_last": (C.c_int32, [C.c_void_p]),
+    "zkp_diag_mid_limbs_per_lane": (C.c_int32, [C.c_void_p]),
 }
 ENC_FORM_AUTO, ENC_FORM_N2, ENC_FORM_SHARED, ENC_FORM_ALWAYS = 0, 1, 2, 3
 ENC_FORMS = {"auto": ENC_FORM_AUTO, "n2": ENC_FORM_N2, "shared": ENC_FORM_SHARED, "basen": ENC_FORM_ALWAYS, "always": ENC_FORM_ALWAYS}
@@ -312,6 +313,10 @@ class Context:
     def set_r2l(self, mode: int):
         """the latency engine's one-Enc-per-wavefront ladder: 0 = never, 1 = the library's rule, 2 = whenever it can run"""
         self.check(self.lib.zkp_diag_set_r2l(self.h, mode))
+
+    def mid_limbs_per_lane(self) -> int:
+        """limbs per lane of the mid engine (libzkp_hip_mid.so), 0 when it is not loaded"""
+        return self.lib.zkp_diag_mid_limbs_per_lane(self.h)
 
     def r2l_last(self) -> bool:
         return self.lib.zkp_diag_r2l_last(self.h) == 1

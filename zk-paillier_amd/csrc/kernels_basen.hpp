@@ -47,7 +47,8 @@ template <int G> struct BnLds {
   static constexpr int OFF_A = 0, OFF_B = G * BLK;
   // W = 36: 152 / 304 words (strides of 38 / 76 units, above).  W = 9 (the latency build: 8 / 16 lanes per n-sized integer, BLK = 12 words):
   // 2 G BLK + 8 = 200 / 392 words — 50 / 98 units, 2 mod 16: the 8 / 4 groups of a wavefront read the staged operand from distinct banks
-  static constexpr int WORDS = W == 36 ? (G == 2 ? 152 : 304) : 2 * G * BLK + 8;  // >= 2 G BLK + 3 (the limb scratch of the output conversion)
+  // W = 18 (the mid engine: 4 / 8 lanes, BLK = 20): 2 G BLK + 12 = 172 / 332 words — 43 / 83 units, odd: the 16 / 8 groups of a wavefront on distinct banks
+  static constexpr int WORDS = W == 36 ? (G == 2 ? 152 : 304) : W == 18 ? 2 * G * BLK + 12 : 2 * G * BLK + 8;  // >= 2 G BLK + 3 (the limb scratch of the output conversion)
   static constexpr int NW2 = (L / 72) * 128;                    // 32-bit words of a value mod n^2
   static_assert(W != 36 || G == 2 || G == 4, "group strides are chosen per geometry");
   static_assert(L == 72 || L == 144, "an n-sized integer is 72 or 144 limbs");
@@ -125,12 +126,20 @@ __device__ __forceinline__ void q_write1(uint64_t qmask, uint32_t addr /* LDS by
   uint64_t saved;
   asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(qmask), "v"(addr), "v"(q) : "scc");
 }
+// (W = 18: sixteen digits in four 16-byte writes, the last two together)
+__device__ __forceinline__ void q_write2(uint64_t qmask, uint32_t addr /* LDS byte address */, uint32_t q0, uint32_t q1) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 v = {q0, q1};
+  uint64_t saved;
+  asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0\n\ts_nop 0" : "=&s"(saved) : "s"(qmask), "v"(addr), "v"(v) : "scc");
+}
 #define ZKP_BN_QWRITE(qmask, row_addr, t, qd)                                                                            \
   do {                                                                                                                  \
     if (((t) & 3) == 3) q_write((qmask), (row_addr) + ((t) - 3) * 4, qd);                                               \
     else if ((W & 3) == 1 && (t) == W - 1) q_write1((qmask), (row_addr) + (t) * 4, qd[(t) & 3]);                        \
+    else if ((W & 3) == 2 && (t) == W - 1) q_write2((qmask), (row_addr) + ((t) - 1) * 4, qd[((t) - 1) & 3], qd[(t) & 3]); \
   } while (0)
-static_assert((W & 3) == 0 || (W & 3) == 1, "the digit writes cover blocks of 4 k or 4 k + 1 limbs");
+static_assert((W & 3) != 3, "the digit writes cover blocks of 4 k, 4 k + 1 or 4 k + 2 limbs");
 
 // ---- the a side of a squaring: R = X * X / R' on M~ (bigint29.hpp montsqr, out of place), quotient digits into ldsB (see above)
 template <int G>
@@ -686,7 +695,7 @@ __device__ __forceinline__ uint64_t bn_key(const EncArgs& a, uint64_t item, cons
 constexpr int BN_TAB_ENTRIES = TABS + 4;      // window table | scratch (U, -) | (r, -) | copy of X0^2 | (1, m)
 
 template <int G>
-__global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen(EncArgs a, const uint32_t* __restrict__ bcst, uint32_t* __restrict__ table, uint32_t* __restrict__ raw) {
+__global__ void __launch_bounds__(256, W == 9 ? 4 : 2) k_enc_basen(EncArgs a, const uint32_t* __restrict__ bcst, uint32_t* __restrict__ table, uint32_t* __restrict__ raw) {
   using BC = BnConst<G>;
   using BL = BnLds<G>;
   constexpr int L = Geo<G>::L, E = 2 * L;
@@ -849,7 +858,7 @@ __global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen(EncArgs a, c
 // Table slot of a group: 64 entries, then (U | -) scratch, (r | -), (1 | m).
 constexpr int BN_KEYS_WIN = 6, BN_KEYS_TAB = 1 << BN_KEYS_WIN, BN_KEYS_TAB_ENTRIES = BN_KEYS_TAB + 3;
 template <int G>
-__global__ void __launch_bounds__(256, W == 36 ? 2 : 4) k_enc_basen_keys(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ zero_rec, uint32_t* __restrict__ table,
+__global__ void __launch_bounds__(256, W == 9 ? 4 : 2) k_enc_basen_keys(EncArgs a, const uint32_t* __restrict__ bcst, const uint32_t* __restrict__ zero_rec, uint32_t* __restrict__ table,
                                                            uint32_t* __restrict__ raw) {
   using BC = BnConst<G>;
   using BL = BnLds<G>;

@@ -128,13 +128,6 @@ template <int RW> __device__ __forceinline__ void add(uint32_t (&R)[RW], const u
   for (int k = 0; k < RW; k++) { const uint32_t t = A[k] + B[k] + cy; R[k] = t & LMASK; cy = t >> LB; }
   R[0] += prev_lane<RW>(cy, gl);
 }
-__device__ __forceinline__ void q_write2(uint64_t qmask, uint32_t addr, uint32_t q0, uint32_t q1) {
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  const u32x2 v = {q0, q1};
-  uint64_t saved;
-  asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0\n\ts_nop 0" : "=&s"(saved) : "s"(qmask), "v"(addr), "v"(v) : "scc");
-}
-
 // R = (X * B + c0 + q M~) / R' over the group's lanes; digits go over the consumed limbs of B in the lanes of `qmask`
 // (bn_mul_impl of kernels_basen.hpp with everything that varies turned into data)
 template <int RW>

@@ -19,7 +19,7 @@
 #include "kernels_proofs.hpp"
 #include "kernels_inv.hpp"
 #include "kernels_serde.hpp"
-#if ZKP_W == 36 || ZKP_W == 9
+#if ZKP_W == 36 || ZKP_W == 18 || ZKP_W == 9
 #define ZKP_HAS_BASEN 1
 #include "kernels_basen.hpp"
 #include "kernels_basen_r2l.hpp"      // (W = 9 only: one Enc per wavefront, the five-group right-to-left ladder of calls of a few proofs)          // the Paillier kernels in base-n form: 2 / 4 lanes per n-sized integer in the throughput engine (W = 36), 8 / 16 in the latency engine (W = 9)
@@ -47,6 +47,10 @@ struct zkp_ctx {
   bool owns_stream = true;
   int cus = 0;
   // the latency engine's twin of this ctx (same device, same stream); null in the latency engine itself or when it is not loaded
+  // (two secondary engines: [0] libzkp_hip_lat.so, 9 limbs per lane — calls of a few proofs; [1] libzkp_hip_mid.so, 18 — mid-size Paillier
+  //  calls under one key.  `lat` / `lat_ctx` name the one the current — or most recent — routed call runs on)
+  const struct LatEngine* eng[2] = {nullptr, nullptr};
+  zkp_ctx* eng_ctx[2] = {nullptr, nullptr};
   const struct LatEngine* lat = nullptr;
   zkp_ctx* lat_ctx = nullptr;
   int geometry = 0;                    // 0 = automatic, else the limbs per lane every call must run on
@@ -131,6 +135,12 @@ static int32_t lat_forward_plain(zkp_ctx* c, int32_t st) {
   return st;
 }
 
+// which of the ctx's secondary engines has this many limbs per lane (-1: none; always -1 inside a secondary engine)
+static int engine_with(const zkp_ctx* c, int limbs_per_lane) {
+  for (int k = 0; k < 2; k++) if (c->eng_ctx[k] && c->eng[k]->limbs_per_lane == limbs_per_lane) return k;
+  return -1;
+}
+
 #ifndef ZKP_SECONDARY_ENGINE
 // directory of this shared library, resolved when it is loaded (a relative load path stops meaning anything once the process
 // changes its working directory)
@@ -148,13 +158,15 @@ static const std::string& own_directory() {
 }
 __attribute__((constructor)) static void resolve_own_directory() { try { (void)own_directory(); } catch (...) {} }
 
-static const LatEngine* lat_engine() {
-  static LatEngine eng;
-  static std::once_flag once;
-  std::call_once(once, [] {
+// secondary engine `which`: 0 = libzkp_hip_lat.so ($ZKP_HIP_LAT_LIB), 1 = libzkp_hip_mid.so ($ZKP_HIP_MID_LIB), next to this library
+static const LatEngine* secondary_engine(int which) {
+  static LatEngine engs[2];
+  static std::once_flag once[2];
+  std::call_once(once[which], [which] {
+    LatEngine& eng = engs[which];
     std::string path;
-    if (const char* e = std::getenv("ZKP_HIP_LAT_LIB")) path = e;
-    else if (!own_directory().empty()) path = own_directory() + "/libzkp_hip_lat.so";
+    if (const char* e = std::getenv(which ? "ZKP_HIP_MID_LIB" : "ZKP_HIP_LAT_LIB")) path = e;
+    else if (!own_directory().empty()) path = own_directory() + (which ? "/libzkp_hip_mid.so" : "/libzkp_hip_lat.so");
     else return;
     void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) return;
@@ -166,7 +178,12 @@ static const LatEngine* lat_engine() {
     eng.limbs_per_lane = eng.p_zkp_build_limbs_per_lane();
     eng.handle = h;
   });
-  return eng.handle ? &eng : nullptr;
+  return engs[which].handle ? &engs[which] : nullptr;
+}
+// the engine the call in hand runs on
+static void select_engine(zkp_ctx* c, int k) {
+  c->lat = c->eng[k]; c->lat_ctx = c->eng_ctx[k];
+  c->last_geometry = c->lat->limbs_per_lane;
 }
 
 // does this call (items independent modexp chains under mod_bits-bit moduli) go to the latency engine?
@@ -175,26 +192,42 @@ static const LatEngine* lat_engine() {
 // profiles/r05/size_sweep.jsonl, prove / verify ms): 48 proofs 43.9 / 43.5 against 49.3 / 44.2 on the n^2-sized throughput kernels, 64 proofs
 // 45.1 / 44.3 against 51.0 / 44.3, 96 proofs 60.7 / 59.7 against 64.9 / 61.6 on the throughput engine's base-n kernels, 128 proofs 76.7 / 74.5
 // against 66.7 / 61.7: the hand-over is at 96 proofs.
+// With the mid engine loaded (18 limbs per lane: 16 Enc per wavefront in base-n form, k_enc_basen<4>) the one-key Paillier calls are cut
+// three ways (same sweep, profiles/r05/size_sweep_w18.jsonl): up to 40 proofs the latency engine (32 proofs 33.1 / 29.5 ms against 40.0 / 38.3),
+// from there to 64 proofs — one wavefront per SIMD at 16 Enc each — the mid engine (64 proofs 41.4 / 38.5 against 45.9 / 44.4), the latency
+// engine again up to 96 (80 proofs 61.1 / 59.7 against 65.2 / 63.9), the throughput engine beyond — except 129 ... 192 proofs, where two mid
+// wavefronts per SIMD beat its second round of 32-Enc claims (160 proofs 90.7 / 67.7 against 111.7 / 66.1, 192: 93.2 / 89.8 against 113.6 / 111.2).
 static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits, bool one_key_paillier = false) {
   c->last_geometry = W;
-  if (!c->lat_ctx || c->geometry == W || items == 0) return false;
-  bool take = c->geometry == c->lat->limbs_per_lane;
-  if (!take && one_key_paillier && mod_bits == 4096 && c->lat->limbs_per_lane == 9 && c->enc_form != ZKP_ENC_FORM_N2)
-    take = items <= 3ull * 4 * (uint64_t)c->cus * 8;
-  if (!take) {
+  if (!c->eng_ctx[0] && !c->eng_ctx[1]) return false;
+  if (c->geometry == W || items == 0) return false;
+  if (c->geometry) {                                              // pinned to a secondary engine
+    const int k = engine_with(c, c->geometry);
+    if (k < 0) return false;
+    select_engine(c, k);
+    return true;
+  }
+  const uint64_t simds = 4 * (uint64_t)c->cus;
+  if (one_key_paillier && mod_bits == 4096 && c->enc_form != ZKP_ENC_FORM_N2) {
+    const int lat9 = engine_with(c, 9), mid18 = engine_with(c, 18);
+    if (mid18 >= 0 && ((items > 10 * simds && items <= 16 * simds) || (items > 32 * simds && items <= 48 * simds))) { select_engine(c, mid18); return true; }
+    if (lat9 >= 0 && items <= 3 * simds * 8) { select_engine(c, lat9); return true; }
+    if (lat9 >= 0) return false;
+  }
+  if (!c->eng_ctx[0]) return false;
+  {
     // automatic: the latency engine wins while its launch stays within a few wavefronts per SIMD — measured on MI355X
     // (tools/dev/sweep.py, both engines pinned): RangeProofNi n = 2048 (16 lanes per integer) 48 proofs = 3 waves per SIMD:
     // 56 ms against 62 ms, 64 proofs: 70 against 63; NiCorrectKeyProof (2048-bit moduli, 8 lanes) 4096 keys = 5.5 per SIMD:
     // 62 against 70 ms, 8192 keys: 101 against 96; CompositeDLogProof 16384 proofs = 4 per SIMD: 11 against 18 ms
     const uint64_t limbs = mod_bits <= 2048 ? 72 : mod_bits <= 4096 ? 144 : 288;
-    const uint64_t lanes = limbs / (uint64_t)c->lat->limbs_per_lane;
+    const uint64_t lanes = limbs / (uint64_t)c->eng[0]->limbs_per_lane;
     // (round 3, both engines with squarings where their product allows: RangeProofNi n = 2048 32 proofs 40.7 / 37.5 ms against 49.2 / 44.4,
     // 48 proofs 55.3 / 54.9 against 49.5 / 44.2 -> 2.5 waves per SIMD; NiCorrectKeyProof 4096 keys 56.9 against 59.0 ms, 8192 keys 90 against 81)
     const uint64_t half_waves_per_simd = mod_bits <= 2048 ? 12 : 5;
-    take = 2 * items <= (half_waves_per_simd * 4 * (uint64_t)c->cus * 64) / lanes;
+    if (2 * items <= (half_waves_per_simd * 4 * (uint64_t)c->cus * 64) / lanes) { select_engine(c, 0); return true; }
   }
-  if (take) c->last_geometry = c->lat->limbs_per_lane;
-  return take;
+  return false;
 }
 #define ZKP_ROUTE(c, items, mod_bits, fn, ...)                                              \
   if ((c) && route_latency((c), (items), (mod_bits))) return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__));
@@ -202,7 +235,7 @@ static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits, bool on
   if ((c) && route_latency((c), (items), (mod_bits), (one_key))) return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__));
 // (diagnostics: only when the caller PINNED the latency engine)
 #define ZKP_ROUTE_PINNED(c, fn, ...)                                                        \
-  if ((c) && (c)->lat_ctx && (c)->geometry == (c)->lat->limbs_per_lane) { (c)->last_geometry = (c)->geometry; return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__)); }
+  if ((c) && (c)->geometry && engine_with((c), (c)->geometry) >= 0) { select_engine((c), engine_with((c), (c)->geometry)); return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__)); }
 #else
 #define ZKP_ROUTE(c, items, mod_bits, fn, ...)
 #define ZKP_ROUTE_ENC(c, items, mod_bits, one_key, fn, ...)
@@ -693,11 +726,13 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
   if (hipMalloc((void**)&c->setup_flag, 64) != hipSuccess || hipHostMalloc((void**)&c->setup_flag_host, 64) != hipSuccess ||
       hipMemset(c->setup_flag, 0, 64) != hipSuccess) { (void)zkp_ctx_destroy(c); return ZKP_EDEVICE; }
 #ifndef ZKP_SECONDARY_ENGINE
-  if (const LatEngine* eng = lat_engine()) {
-    const int32_t st = eng->p_zkp_ctx_create_on_stream(device_id, (void*)c->stream, &c->lat_ctx);
-    if (st) { (void)zkp_ctx_destroy(c); return st; }
-    c->lat = eng;
-  }
+  for (int k = 0; k < 2; k++)
+    if (const LatEngine* eng = secondary_engine(k)) {
+      const int32_t st = eng->p_zkp_ctx_create_on_stream(device_id, (void*)c->stream, &c->eng_ctx[k]);
+      if (st) { (void)zkp_ctx_destroy(c); return st; }
+      c->eng[k] = eng;
+      if (!c->lat_ctx) { c->lat = eng; c->lat_ctx = c->eng_ctx[k]; }
+    }
   if (const char* g = std::getenv("ZKP_GEOMETRY")) {                        // testing aid: the same as zkp_ctx_set_geometry
     const int32_t st = zkp_ctx_set_geometry(c, std::atoi(g));
     if (st) { (void)zkp_ctx_destroy(c); return st; }
@@ -717,7 +752,7 @@ extern "C" int32_t zkp_ctx_create_on_stream(int32_t device_id, void* hip_stream,
 
 extern "C" int32_t zkp_ctx_set_geometry(zkp_ctx* c, int32_t limbs_per_lane) try {
   if (!c) return ZKP_EINVAL;
-  if (limbs_per_lane != 0 && limbs_per_lane != W && !(c->lat && limbs_per_lane == c->lat->limbs_per_lane)) {
+  if (limbs_per_lane != 0 && limbs_per_lane != W && engine_with(c, limbs_per_lane) < 0) {
     c->err = "zkp_ctx_set_geometry: no engine with " + std::to_string(limbs_per_lane) + " limbs per lane is loaded";
     return ZKP_EINVAL;
   }
@@ -725,13 +760,13 @@ extern "C" int32_t zkp_ctx_set_geometry(zkp_ctx* c, int32_t limbs_per_lane) try 
   return ZKP_OK;
 } ZKP_CATCH(c)
 extern "C" int32_t zkp_ctx_last_geometry(zkp_ctx* c) { return c ? c->last_geometry : 0; }
-extern "C" int32_t zkp_ctx_latency_limbs_per_lane(zkp_ctx* c) { return (c && c->lat) ? c->lat->limbs_per_lane : 0; }
+extern "C" int32_t zkp_ctx_latency_limbs_per_lane(zkp_ctx* c) { return (c && c->eng[0]) ? c->eng[0]->limbs_per_lane : 0; }
 
 extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   if (!c) return ZKP_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  if (c->lat_ctx) (void)c->lat->p_zkp_ctx_destroy(c->lat_ctx);
+  for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_ctx_destroy(c->eng_ctx[k]);
   for (DevBuf* b : {&c->consts, &c->consts2, &c->table, &c->bn_ncst, &c->bn_consts, &c->bn_table, &c->bn_expected, &c->bn_raw, &c->bn_flag, &c->bn_left}) if (b->p) (void)hipFree(b->p);
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -758,7 +793,8 @@ extern "C" int32_t zkp_ctx_release_staging(zkp_ctx* c) try {
   // the base-n form's per-launch areas (window tables of pairs: 1.4 GB under one key, 2.5 GB under per-proof keys; raw pairs; Mask-row
   // products) are sized by the largest launch so far and rebuilt on demand
   for (DevBuf* b : {&c->bn_table, &c->bn_raw, &c->bn_expected}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
-  if (c->lat_ctx) return lat_forward_plain(c, c->lat->p_zkp_ctx_release_staging(c->lat_ctx));
+  for (int k = 0; k < 2; k++)
+    if (c->eng_ctx[k]) { const int32_t st = c->eng[k]->p_zkp_ctx_release_staging(c->eng_ctx[k]); if (st) { c->err = c->eng[k]->p_zkp_last_error_string(c->eng_ctx[k]); return st; } }
   return ZKP_OK;
 } ZKP_CATCH(c)
 
@@ -850,18 +886,19 @@ extern "C" int32_t zkp_diag_set_enc_form(zkp_ctx* c, int32_t form) try {
   if (!c || form < ZKP_ENC_FORM_AUTO || form > ZKP_ENC_FORM_ALWAYS) return ZKP_EINVAL;
   c->enc_form = form;
 #ifndef ZKP_SECONDARY_ENGINE
-  if (c->lat_ctx) return lat_forward_plain(c, c->lat->p_zkp_diag_set_enc_form(c->lat_ctx, form));
+  for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_diag_set_enc_form(c->eng_ctx[k], form);
 #endif
   return ZKP_OK;
 } ZKP_CATCH(c)
 extern "C" int32_t zkp_diag_enc_form(zkp_ctx* c) { return c ? c->enc_form : -1; }
 extern "C" int32_t zkp_diag_last_host_blocks(zkp_ctx* c) { return c ? c->last_host_blocks : -1; }
+extern "C" int32_t zkp_diag_mid_limbs_per_lane(zkp_ctx* c) { return (c && c->eng[1]) ? c->eng[1]->limbs_per_lane : 0; }
 // the one-Enc-per-wavefront ladder of the latency engine (kernels_basen_r2l.hpp): 0 = never, 1 = the library's rule, 2 = whenever it can run
 extern "C" int32_t zkp_diag_set_r2l(zkp_ctx* c, int32_t mode) try {
   if (!c || mode < 0 || mode > 2) return ZKP_EINVAL;
   c->bn_r2l = mode;
 #ifndef ZKP_SECONDARY_ENGINE
-  if (c->lat_ctx) return lat_forward_plain(c, c->lat->p_zkp_diag_set_r2l(c->lat_ctx, mode));
+  for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_diag_set_r2l(c->eng_ctx[k], mode);
 #endif
   return ZKP_OK;
 } ZKP_CATCH(c)
@@ -879,7 +916,8 @@ extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) try {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->timing = enable != 0;
   c->ev_used = 0; c->timed_launches = 0; c->timed_modexps = 0; c->pinned_used = 0;
-  if (c->lat_ctx) return lat_forward_plain(c, c->lat->p_zkp_timing_reset(c->lat_ctx, enable));
+  for (int k = 0; k < 2; k++)
+    if (c->eng_ctx[k]) { const int32_t st = c->eng[k]->p_zkp_timing_reset(c->eng_ctx[k], enable); if (st) { c->err = c->eng[k]->p_zkp_last_error_string(c->eng_ctx[k]); return st; } }
   return ZKP_OK;
 } ZKP_CATCH(c)
 
@@ -894,12 +932,13 @@ extern "C" int32_t zkp_timing_get(zkp_ctx* c, double* ms, uint64_t* launches, ui
   }
   uint64_t extra = 0, lat_launches = 0, lat_modexps = 0;
   for (size_t i = 0; i < c->pinned_used; i++) extra += c->pinned_counts[i];
-  if (c->lat_ctx) {                                  // the twin ctx's share of the calls since the reset
-    double lat_ms = 0;
-    const int32_t st = lat_forward_plain(c, c->lat->p_zkp_timing_get(c->lat_ctx, &lat_ms, &lat_launches, &lat_modexps));
-    if (st) return st;
-    total += lat_ms;
-  }
+  for (int k = 0; k < 2; k++)
+    if (c->eng_ctx[k]) {                             // the twin contexts' share of the calls since the reset
+      double e_ms = 0; uint64_t e_launches = 0, e_modexps = 0;
+      const int32_t st = c->eng[k]->p_zkp_timing_get(c->eng_ctx[k], &e_ms, &e_launches, &e_modexps);
+      if (st) { c->err = c->eng[k]->p_zkp_last_error_string(c->eng_ctx[k]); return st; }
+      total += e_ms; lat_launches += e_launches; lat_modexps += e_modexps;
+    }
   if (ms) *ms = total;
   if (launches) *launches = c->timed_launches + lat_launches;
   if (modexps) *modexps = c->timed_modexps + extra + lat_modexps;
