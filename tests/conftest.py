@@ -27,6 +27,12 @@ def _gpu_present():
 def pytest_collection_modifyitems(config, items):
     """A plain `pytest` on a box without a GPU skips the gpu-marked tests instead of erroring in their fixtures.  When the gpu
     tests are asked for (`-m gpu`) nothing is skipped: without a gfx950 they fail loudly (there is no CPU fallback to hide behind)."""
+    # The two extra kernel families of round 5 — the mid engine (w18-basen) and the latency engine with its r2l ladder off (w9-pair) — run
+    # the files that are about the arithmetic; the files about documents, host glue and the other proofs keep the three families they had
+    # (the whole matrix would take the driver's GPU run from 10 to 19 minutes).
+    narrow = ("w18-basen", "w9-pair")
+    wide_files = ("test_gpu_l1", "test_golden", "test_gpu_range", "test_gpu_challenge", "test_gpu_correct_key", "test_gpu_dlog", "test_sigma_proofs", "test_verlin_proof", "test_gpu_soak")
+    items[:] = [it for it in items if not (any(f"[{n}" in it.nodeid or f"-{n}]" in it.nodeid or f"[{n}-" in it.nodeid for n in narrow) and not any(w in it.nodeid for w in wide_files))]
     if "gpu" in (config.getoption("-m") or "") or _gpu_present():
         return
     skip = pytest.mark.skip(reason="needs a gfx950 GPU (run with -m gpu on the GPU box)")

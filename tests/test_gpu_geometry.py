@@ -111,7 +111,7 @@ def test_ctx_on_a_caller_owned_stream():
         kw = 64
         nl = torch.from_numpy(H.L.int_to_limbs(n, kw).astype(np.int32)).to(dev)
         g = torch.Generator(device=dev); g.manual_seed(3)
-        for count, want in ((4, 9), (40000, 36)):      # Enc under one 2048-bit key: the latency engine takes up to 24576 (three wavefronts per SIMD at 8 Enc each, base-n form)
+        for count, want in ((4, 9), (60000, 36)):      # Enc under one 2048-bit key: the secondary engines take up to 49152 items (route_latency)
             m = torch.randint(-2**31, 2**31 - 1, (count, kw), dtype=torch.int32, device=dev, generator=g); m[:, -1] &= 0x3FFFFFFF
             r = torch.randint(-2**31, 2**31 - 1, (count, kw), dtype=torch.int32, device=dev, generator=g); r[:, -1] &= 0x3FFFFFFF
             torch.cuda.synchronize()
