@@ -164,7 +164,73 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], const uint32_t (&X)[R
   }
   R[0] += prev_lane<RW>((uint32_t)cy, gl);
 }
+// The same product with TWO quotient digits per trip through the broadcast (even RW).  A lone wavefront waits out the LDS crossbar once per
+// digit: 195 cycles per sub-step whether a lane holds 6 limbs or 9.  Lane 0 of a group can work out the NEXT digit by itself — its bottom two
+// columns are complete, and with M~ == -1 (mod 2^29) the carry out of the bottom column is (c0 >> 29) + q0, so
+//     q1 = low29( c1 + (c0 >> 29) + q0 (N_1 + 1) )
+// — one 32-bit multiply more on lane 0's chain, one broadcast latency less per pair of sub-steps (both digits go out together).  The digits,
+// and with them every value, are those of `product` (bigint29.hpp montmul2 does this under a 58-bit Orup multiple, which a 2048-bit n in
+// 2088 bits of capacity has no room for; this variant needs none).
+template <int RW>
+__device__ __forceinline__ void product2(uint32_t (&R)[RW], const uint32_t (&X)[RW], const uint32_t* ldsB, const uint32_t (&NT)[RW], uint64_t (&c)[RW],
+                                         uint64_t qmask, int gl, int lead4) {
+  static_assert((RW & 1) == 0, "pairs of sub-steps");
+  using GM = Geom<RW>;
+  const uint32_t n1p = NT[1] + 1;
+#pragma unroll 1
+  for (int s = 0; s < GM::RG; s++) {
+    uint32_t qd[4];
+    const uint32_t row_addr = lds_byte_address(ldsB + s * GM::RBLK);
+#pragma unroll
+    for (int t = 0; t < RW; t += 2) {
+      const int i0 = t % RW, i1 = (t + 1) % RW, i2 = (t + 2) % RW;
+      const uint32_t b0 = ldsB[s * GM::RBLK + t], b1 = ldsB[s * GM::RBLK + t + 1];
+      c[i0] += (uint64_t)X[0] * b0;
+      c[i1] += (uint64_t)X[1] * b0;
+      c[i1] += (uint64_t)X[0] * b1;
+      const uint32_t q0l = (uint32_t)c[i0] & LMASK;
+      const uint32_t q1l = ((uint32_t)c[i1] + (uint32_t)(c[i0] >> LB) + q0l * n1p) & LMASK;
+      const uint32_t q0 = lead_bcast<RW>(q0l, lead4);
+      const uint32_t q1 = lead_bcast<RW>(q1l, lead4);
+      qd[t & 3] = q0; qd[(t + 1) & 3] = q1;
+      if (((t + 1) & 3) == 3) q_write(qmask, row_addr + (t - 2) * 4, qd);
+      else if (t + 2 == RW) q_write2(qmask, row_addr + t * 4, q0, q1);
+#pragma unroll
+      for (int k = 2; k < RW; k++) c[(t + k) % RW] += (uint64_t)X[k] * b0;
+#pragma unroll
+      for (int k = 1; k < RW - 1; k++) c[(t + 1 + k) % RW] += (uint64_t)X[k] * b1;
+#pragma unroll
+      for (int k = 0; k < RW; k++) c[(t + k) % RW] += (uint64_t)NT[k] * q0;
+#pragma unroll
+      for (int k = 0; k < RW - 1; k++) c[(t + 1 + k) % RW] += (uint64_t)NT[k] * q1;
+      {
+        const uint64_t v = c[i0];
+        c[i1] += v >> LB;
+        c[i0] = (uint64_t)next_lane<RW>((uint32_t)v & LMASK);          // slot i0 is column t + RW from here on
+      }
+      c[i0] += (uint64_t)X[RW - 1] * b1;                                 // the top products of the second digit
+      c[i0] += (uint64_t)NT[RW - 1] * q1;
+      {
+        const uint64_t v = c[i1];
+        c[i2] += v >> LB;
+        c[i1] = (uint64_t)next_lane<RW>((uint32_t)v & LMASK);
+      }
+    }
+  }
+  uint64_t cy = 0;
+#pragma unroll
+  for (int k = 0; k < RW; k++) {
+    const uint64_t t = c[k] + cy;
+    R[k] = (uint32_t)t & LMASK;
+    cy = t >> LB;
+  }
+  R[0] += prev_lane<RW>((uint32_t)cy, gl);
+}
 }  // namespace r2l
+
+#ifndef ZKP_R2L_TWO_DIGITS
+#define ZKP_R2L_TWO_DIGITS 1
+#endif
 
 // One wavefront per workgroup, one Enc per claim.  bcst[OFF_OK] == 0 (a key the form does not take): return at once, the launch behind this
 // one — which claims from the same counter — does the work.
@@ -264,7 +330,8 @@ __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t*
         for (int i = 0; i < RW; i++) c[i] = (uint64_t)C3[i] + (uint64_t)((1u << LB) - Q[i]) * n1e;
       }
       wave_lds_fence();
-      product<RW>(R, X, area(ba), NT, c, qmask, gl, lead4);
+      if constexpr (ZKP_R2L_TWO_DIGITS && (RW & 1) == 0) product2<RW>(R, X, area(ba), NT, c, qmask, gl, lead4);
+      else product<RW>(R, X, area(ba), NT, c, qmask, gl, lead4);
       wave_lds_fence();
       blk_store<RW>(blk(d0), R);
       wave_lds_fence();
