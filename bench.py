@@ -721,15 +721,16 @@ def host_api_leg(B):
     pkg = os.path.join(ROOT, "zk-paillier_amd")
     try:
         os.makedirs(os.path.dirname(exe), exist_ok=True)
-        deps = [src, os.path.join(pkg, "host", "zkproofs.hpp"), os.path.join(pkg, "host", "bigint.hpp")]
+        deps = [src] + [os.path.join(pkg, "host", h) for h in ("zkproofs.hpp", "bigint.hpp", "staging.hpp")]
         if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", exe, "-L" + pkg, "-lzkp_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
         out = subprocess.run([exe, str(B)], capture_output=True, text=True, timeout=900)
         rec = json.loads(out.stdout.strip().splitlines()[-1])
     except Exception as e:                         # no compiler on the box, a build error: the leg is reported as missing, the line survives
         return {"error": f"{type(e).__name__}: {e}"}, True
-    rec["what"] = ("host/zkproofs.hpp RangeProofNi::{prove,verify}_batch, n=2048, fixture key: wall time of the whole call; host_share = 1 - gpu_call_ms / ms "
-                   "(gpu_call_ms = zkp_range_ni_{prove,verify}_batch with pageable host buffers, i.e. staging + PCIe + kernels)")
+    rec["what"] = ("host/zkproofs.hpp RangeProofNi::{prove,verify}_batch, n=2048, fixture key: wall time of the whole call, the SECOND call of each "
+                   "(steady state of a service: staging blocks come from the process-wide pool, host/staging.hpp; first_call_ms = into fresh memory); "
+                   "host_share = 1 - gpu_call_ms / ms (gpu_call_ms = zkp_range_ni_{prove,verify}_batch with pageable host buffers, i.e. staging + PCIe + kernels)")
     return rec, bool(rec.get("all_accepted")) and out.returncode == 0
 
 

@@ -26,23 +26,34 @@ int main(int argc, char** argv) {
   }
   const std::vector<BigInt> cts = Paillier::encrypt_with_chosen_randomness_batch(ek, mr);
   for (size_t b = 0; b < B; b++) { st[b].ciphertext = cts[b]; st[b].secret_x = xs[b]; st[b].secret_r = rs[b]; }
-  (void)RangeProofNi::prove_batch(ek, std::vector<RangeProofNi::Statement>(st.begin(), st.begin() + std::min<size_t>(B, 64)));     // warm-up: engine, staging blocks
+  (void)RangeProofNi::prove_batch(ek, std::vector<RangeProofNi::Statement>(st.begin(), st.begin() + std::min<size_t>(B, 64)));     // warm-up: engine, kernels
+  // Every call is made TWICE and the second one is reported — a service in steady state: the staging blocks of a batch come from the
+  // process-wide pool with their pages mapped (host/staging.hpp).  The first call's wall time is kept beside it (`first_call_ms`): what a
+  // batch costs into fresh memory, which depends on whether the box grants transparent huge pages.  $ZKP_HOST_POOL_MB=0: no pool.
   StopWatch sw;
   std::vector<RangeProofNi> proofs = RangeProofNi::prove_batch(ek, st);
+  const double prove_first_ms = sw.lap();
+  proofs.clear(); proofs.shrink_to_fit();
+  sw.lap();
+  proofs = RangeProofNi::prove_batch(ek, st);
   const double prove_ms = sw.lap();
   const HostTiming tp = last_host_timing();
   std::vector<const RangeProofNi*> ptr;
   for (auto& pr : proofs) ptr.push_back(&pr);
   sw.lap();
   std::vector<Result> res = RangeProofNi::verify_batch(ek, ptr);
+  const double verify_first_ms = sw.lap();
+  res = RangeProofNi::verify_batch(ek, ptr);
   const double verify_ms = sw.lap();
   const HostTiming tv = last_host_timing();
   size_t ok = 0;
   for (auto& r : res) ok += r.is_ok();
   std::printf("{\"proofs\": %zu, \"host_threads\": %u, \"all_accepted\": %s, "
-              "\"prove\": {\"ms\": %.1f, \"proofs_per_s\": %.1f, \"sample_and_flatten_ms\": %.1f, \"gpu_call_ms\": %.1f, \"rebuild_ms\": %.1f, \"host_share\": %.3f}, "
-              "\"verify\": {\"ms\": %.1f, \"verifies_per_s\": %.1f, \"classify_and_flatten_ms\": %.1f, \"gpu_call_ms\": %.1f, \"host_share\": %.3f}}\n",
-              B, tp.threads, ok == B ? "true" : "false", prove_ms, 1e3 * B / prove_ms, tp.sample_flatten_ms, tp.gpu_ms, tp.rebuild_ms, 1.0 - tp.gpu_ms / prove_ms,
-              verify_ms, 1e3 * B / verify_ms, tv.sample_flatten_ms, tv.gpu_ms, 1.0 - tv.gpu_ms / verify_ms);
+              "\"prove\": {\"ms\": %.1f, \"first_call_ms\": %.1f, \"proofs_per_s\": %.1f, \"sample_and_flatten_ms\": %.1f, \"gpu_call_ms\": %.1f, \"rebuild_ms\": %.1f, \"host_share\": %.3f}, "
+              "\"verify\": {\"ms\": %.1f, \"first_call_ms\": %.1f, \"verifies_per_s\": %.1f, \"classify_and_flatten_ms\": %.1f, \"gpu_call_ms\": %.1f, \"host_share\": %.3f}, "
+              "\"staging_pool\": {\"capacity_mb\": %zu, \"held_mb\": %zu, \"hits\": %zu, \"misses\": %zu}}\n",
+              B, tp.threads, ok == B ? "true" : "false", prove_ms, prove_first_ms, 1e3 * B / prove_ms, tp.sample_flatten_ms, tp.gpu_ms, tp.rebuild_ms, 1.0 - tp.gpu_ms / prove_ms,
+              verify_ms, verify_first_ms, 1e3 * B / verify_ms, tv.sample_flatten_ms, tv.gpu_ms, 1.0 - tv.gpu_ms / verify_ms,
+              StagingPool::instance().capacity() >> 20, StagingPool::instance().held() >> 20, StagingPool::instance().hits(), StagingPool::instance().misses());
   return ok == B ? 0 : 1;
 }

@@ -19,7 +19,7 @@ def build_exe():
         import __graft_entry__ as g
         g.build()
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
-    deps = [SRC, os.path.join(PKG, "host", "zkproofs.hpp"), os.path.join(PKG, "host", "bigint.hpp"), H.zkp.LIB_PATH]
+    deps = [SRC] + [os.path.join(PKG, "host", h) for h in ("zkproofs.hpp", "bigint.hpp", "staging.hpp")] + [H.zkp.LIB_PATH]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", SRC, "-o", EXE, "-L" + PKG, "-lzkp_hip",
                                "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
@@ -51,3 +51,14 @@ def test_host_bigint_against_gmp():
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I/opt/conda/include", src, gmp, "-o", exe])
     out = subprocess.run([exe, "8000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "bigint ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_staging_pool():
+    """host/staging.hpp: blocks of a batch call come back from the pool with their pages mapped, secret ones wiped; bounded; thread-safe
+    (tests/cpp/test_staging.cpp; no GPU, no library)"""
+    src = os.path.join(ROOT, "tests", "cpp", "test_staging.cpp")
+    exe = os.path.join(ROOT, "build", "test_staging")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "staging ok" in out.stdout, out.stdout + out.stderr

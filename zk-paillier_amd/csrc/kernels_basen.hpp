@@ -141,6 +141,91 @@ __device__ __forceinline__ void q_write2(uint64_t qmask, uint32_t addr /* LDS by
   } while (0)
 static_assert((W & 3) != 3, "the digit writes cover blocks of 4 k, 4 k + 1 or 4 k + 2 limbs");
 
+// ---- TWO quotient digits per trip through the broadcast (W = 9, the latency engine's 8- and 16-lane groups) — a measured variant, OFF.
+// Lane 0 of a group works out the next digit by itself: its bottom two columns are complete, and with M~ == -1 (mod 2^29) the carry out of
+// the bottom column is (c0 >> 29) + q0, so
+//     q1 = low29( c1 + (c0 >> 29) + q0 (N_1 + 1) )
+// — one 32-bit multiply more on lane 0's chain, one broadcast latency less per pair of sub-steps; same digits, same values as the one-digit
+// loops below (bigint29.hpp montmul2 / montsqr2 do this under a 58-bit Orup multiple, for which an n-sized integer of 2048 bits in 2088 has no
+// room; this form needs none).  It is what made the one-Enc-per-wavefront ladder 10 % faster (kernels_basen_r2l.hpp: product2), where a
+// sub-step is 12 multiply-adds.  Here a sub-step is 14 – 18 of them on 8 Enc at once and the broadcast is a smaller share: bit-exact
+// (tests/test_gpu_basen.py green with it), 32 proofs 33.1 / 31.1 -> 31.5 / 29.5 ms (one wavefront per SIMD), 96 proofs 61.0 / 60.0 ->
+// 62.7 / 62.4 (three) — profiles/r05/experiments/ab_two_quotient_digits_w9_basen.txt.  Not worth a second set of kernels.
+#ifndef ZKP_BN_TWO_DIGITS
+#define ZKP_BN_TWO_DIGITS 0
+#endif
+constexpr bool BN_TWO_DIGITS = ZKP_BN_TWO_DIGITS && W == 9;
+
+// digits of a pair (t, t + 1) / of the odd last sub-step into LDS
+#define ZKP_BN_QWRITE_PAIR(qmask, row_addr, t, qd)                                                                      \
+  do {                                                                                                                  \
+    if ((((t) + 1) & 3) == 3) q_write((qmask), (row_addr) + ((t) - 2) * 4, qd);                                         \
+  } while (0)
+
+template <int G, bool SQR>
+__device__ __forceinline__ void bn_core2(uint64_t (&c)[W], const uint32_t (&X)[W], uint32_t* ldsB, const uint32_t (&N)[W], uint64_t writes, int gl) {
+  const uint32_t n1p = N[1] + 1;
+  // c[col] += X[k] * (b | 2 b), or nothing: for a squaring the position pair (tt, k) decides at compile time (bigint29.hpp sqr_mult)
+#define ZKP_BN_P(tt, k, col, b1x, b2x) do { const int m_ = SQR ? sqr_mult((tt), (k)) : 1; if (m_ == 1) c[(col)] += (uint64_t)X[(k)] * (b1x); \
+                                            else if (m_ == 2) c[(col)] += (uint64_t)X[(k)] * (b2x); } while (0)
+#pragma unroll 1
+  for (int s = 0; s < G; s++) {
+    uint32_t qd[4];
+    const uint32_t row_addr = lds_byte_address(ldsB + s * BLK);
+#pragma unroll
+    for (int t = 0; t + 1 < W; t += 2) {
+      const int i0 = t % W, i1 = (t + 1) % W, i2 = (t + 2) % W;
+      const uint32_t b0 = ldsB[s * BLK + t], b1 = ldsB[s * BLK + t + 1];
+      const uint32_t b0d = b0 + b0, b1d = b1 + b1;
+      ZKP_BN_P(t, 0, i0, b0, b0d);                                         // the products of columns t and t + 1 first: they decide the digits
+      ZKP_BN_P(t, 1, i1, b0, b0d);
+      ZKP_BN_P(t + 1, 0, i1, b1, b1d);
+      const uint32_t q0l = (uint32_t)c[i0] & LMASK;
+      const uint32_t q1l = ((uint32_t)c[i1] + (uint32_t)(c[i0] >> LB) + q0l * n1p) & LMASK;
+      const uint32_t q0 = bcast0<G>(q0l);
+      const uint32_t q1 = bcast0<G>(q1l);
+      qd[t & 3] = q0; qd[(t + 1) & 3] = q1;
+      ZKP_BN_QWRITE_PAIR(writes, row_addr, t, qd);
+#pragma unroll
+      for (int k = 2; k < W; k++) ZKP_BN_P(t, k, (t + k) % W, b0, b0d);
+#pragma unroll
+      for (int k = 1; k < W - 1; k++) ZKP_BN_P(t + 1, k, (t + 1 + k) % W, b1, b1d);
+#pragma unroll
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q0;
+#pragma unroll
+      for (int k = 0; k < W - 1; k++) c[(t + 1 + k) % W] += (uint64_t)N[k] * q1;
+      {
+        const uint64_t v = c[i0];
+        c[i1] += v >> LB;
+        c[i0] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);        // slot i0 is column t + W from here on
+      }
+      ZKP_BN_P(t + 1, W - 1, i0, b1, b1d);                                 // the top products of the second digit
+      c[i0] += (uint64_t)N[W - 1] * q1;
+      {
+        const uint64_t v = c[i1];
+        c[i2] += v >> LB;
+        c[i1] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+      }
+    }
+    if constexpr (W & 1) {
+      constexpr int t = W - 1;
+      const uint32_t b = ldsB[s * BLK + t];
+      const uint32_t bd = b + b;
+#pragma unroll
+      for (int k = 0; k < W; k++) ZKP_BN_P(t, k, (t + k) % W, b, bd);
+      const uint32_t q = bcast0<G>((uint32_t)c[t] & LMASK);
+      qd[t & 3] = q;
+      ZKP_BN_QWRITE(writes, row_addr, t, qd);
+#pragma unroll
+      for (int k = 0; k < W; k++) c[(t + k) % W] += (uint64_t)N[k] * q;
+      const uint64_t v = c[t];
+      c[(t + 1) % W] += v >> LB;
+      c[t] = (uint64_t)from_next<G>((uint32_t)v & LMASK, gl);
+    }
+  }
+#undef ZKP_BN_P
+}
+
 // ---- the a side of a squaring: R = X * X / R' on M~ (bigint29.hpp montsqr, out of place), quotient digits into ldsB (see above)
 template <int G>
 __device__ __forceinline__ void bn_sqr_a(uint32_t (&R)[W], const uint32_t (&X)[W], uint32_t* ldsB, const uint32_t (&N)[W], const Bn<G>& g) {
@@ -150,6 +235,8 @@ __device__ __forceinline__ void bn_sqr_a(uint32_t (&R)[W], const uint32_t (&X)[W
   uint64_t c[W];
 #pragma unroll
   for (int k = 0; k < W; k++) c[k] = 0;
+  if constexpr (BN_TWO_DIGITS) bn_core2<G, true>(c, X, ldsB, N, writes, gl);
+  else
 #pragma unroll 1
   for (int s = 0; s < G; s++) {
     uint32_t qd[4];
@@ -225,6 +312,8 @@ __device__ __forceinline__ void bn_mul_impl(uint32_t (&R)[W], const uint32_t (&A
 #pragma unroll
     for (int k = 0; k < W; k++) c[k] = 0;
   }
+  if constexpr (BN_TWO_DIGITS) bn_core2<G, false>(c, A, ldsB, g.NT, writes, gl);
+  else
 #pragma unroll 1
   for (int s = 0; s < G; s++) {
     uint32_t qd[4];

@@ -176,11 +176,9 @@ __device__ __noinline__ WaveShaState hw_compress(WaveShaState st, int nblk, int 
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const uint32_t S1 = Sha256::xor3(Sha256::ror(e, 6), Sha256::ror(e, 11), Sha256::ror(e, 25));
-        const uint32_t ch = (e & f) ^ (~e & g);
-        const uint32_t t1 = hh + S1 + ch + kk[r];
+        const uint32_t t1 = hh + S1 + Sha256::ch(e, f, g) + kk[r];
         const uint32_t S0 = Sha256::xor3(Sha256::ror(a, 2), Sha256::ror(a, 13), Sha256::ror(a, 22));
-        const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
-        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + Sha256::maj(b, c, d);      // (b, c, d: a, b, c of this round, already shifted)
       }
     }
     st.h[0] += a; st.h[1] += b; st.h[2] += c; st.h[3] += d; st.h[4] += e; st.h[5] += f; st.h[6] += g; st.h[7] += hh;

@@ -31,6 +31,11 @@ struct Sha256 {
   __device__ __forceinline__ static uint32_t ror(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
   // a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96); the compiler alone emits two v_xor_b32
   __device__ __forceinline__ static uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+  // Maj and Ch as ONE v_bitop3_b32 each (truth tables 0xE8, 0xCA).  Written as (a & b) ^ (a & c) ^ (b & c) the compiler shares a & b with the
+  // next round's b & c and spends v_and + v_xor + v_bitop3 per round: 16.7 instructions per round of the serial chain instead of 14.7 —
+  // and a transcript hash on one wavefront IS that chain (k_range_hash_wave: 2052 blocks per proof, 4 cycles per instruction).
+  __device__ __forceinline__ static uint32_t maj(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+  __device__ __forceinline__ static uint32_t ch(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
 
   __device__ __forceinline__ void init(uint32_t* lds_buf, int lds_stride) {
     h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
@@ -61,11 +66,9 @@ struct Sha256 {
         w[i & 15] = wi;
       }
       const uint32_t S1 = xor3(ror(e, 6), ror(e, 11), ror(e, 25));
-      const uint32_t ch = (e & f) ^ (~e & g);
-      const uint32_t t1 = hh + S1 + ch + SHA_K[i] + wi;
+      const uint32_t t1 = hh + S1 + ch(e, f, g) + SHA_K[i] + wi;
       const uint32_t S0 = xor3(ror(a, 2), ror(a, 13), ror(a, 22));
-      const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
-      const uint32_t t2 = S0 + mj;
+      const uint32_t t2 = S0 + maj(a, b, c);
       hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;

@@ -40,6 +40,7 @@
 
 #include "../../include/zkp_hip.h"
 #include "bigint.hpp"
+#include "staging.hpp"
 
 namespace zkproofs {
 
@@ -112,29 +113,7 @@ template <class F> inline void parallel_for(size_t count, F body, unsigned max_t
   for (auto& x : th) x.join();
   if (first) std::rethrow_exception(first);
 }
-// staging memory that is written in full before it is read (by to_limbs, or by the GPU call): NOT value-initialised — a
-// std::vector would memset (and page-fault) 2 GB per 4096-proof call on one thread before the work starts.  Large buffers are 2 MB
-// aligned and marked for transparent huge pages: what such a buffer costs is its first touch (a quarter of a million 4 KB faults per
-// gigabyte — the D2H copy of a prove call took 125 ms longer into fresh memory than into touched memory, round 5), and a huge page is
-// one fault per 2 MB where the kernel grants it.
-template <class T> struct RawBuf {
-  T* p = nullptr;
-  explicit RawBuf(size_t n) {
-    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    if (bytes >= (size_t(4) << 20)) {
-      const size_t huge = size_t(2) << 20, rounded = (bytes + huge - 1) & ~(huge - 1);
-      p = static_cast<T*>(std::aligned_alloc(huge, rounded));
-      if (p) (void)madvise(p, rounded, MADV_HUGEPAGE);
-    } else p = static_cast<T*>(std::malloc(bytes));
-    if (!p) throw std::bad_alloc();
-  }
-  RawBuf(const RawBuf&) = delete;
-  RawBuf& operator=(const RawBuf&) = delete;
-  ~RawBuf() { std::free(p); }
-  T* data() { return p; }
-  T& operator[](size_t i) { return p[i]; }
-  const T& operator[](size_t i) const { return p[i]; }
-};
+// (RawBuf, StagingPool: host/staging.hpp)
 struct StopWatch {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   double lap() { const auto t1 = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1; return ms; }
@@ -309,8 +288,8 @@ class RangeProofNi {
     RawBuf<uint8_t> kind, jj;
     std::vector<uint8_t> status;
     ProveChunk(size_t lo_, size_t hi_, size_t kw, size_t EF)
-        : lo(lo_), hi(hi_), range((hi_ - lo_) * kw), ct((hi_ - lo_) * 2 * kw), x((hi_ - lo_) * kw), r((hi_ - lo_) * kw), w1((hi_ - lo_) * EF * kw), w2((hi_ - lo_) * EF * kw),
-          r1((hi_ - lo_) * EF * kw), r2((hi_ - lo_) * EF * kw), c1((hi_ - lo_) * EF * 2 * kw), c2((hi_ - lo_) * EF * 2 * kw), rw1((hi_ - lo_) * EF * kw), rr1((hi_ - lo_) * EF * kw),
+        : lo(lo_), hi(hi_), range((hi_ - lo_) * kw), ct((hi_ - lo_) * 2 * kw), x((hi_ - lo_) * kw, true), r((hi_ - lo_) * kw, true), w1((hi_ - lo_) * EF * kw, true),
+          w2((hi_ - lo_) * EF * kw, true), r1((hi_ - lo_) * EF * kw, true), r2((hi_ - lo_) * EF * kw, true) /* witnesses and nonces: wiped on release */, c1((hi_ - lo_) * EF * 2 * kw), c2((hi_ - lo_) * EF * 2 * kw), rw1((hi_ - lo_) * EF * kw), rr1((hi_ - lo_) * EF * kw),
           rw2((hi_ - lo_) * EF * kw), rr2((hi_ - lo_) * EF * kw), kind((hi_ - lo_) * EF), jj((hi_ - lo_) * EF), status(hi_ - lo_) {}
   };
   static std::vector<RangeProofNi> prove_batch(const EncryptionKey& ek, const std::vector<Statement>& st) {
