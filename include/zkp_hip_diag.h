@@ -60,6 +60,16 @@ int32_t zkp_diag_set_r2l(zkp_ctx* ctx, int32_t mode);
 int32_t zkp_diag_mid_limbs_per_lane(zkp_ctx* ctx);
 int32_t zkp_diag_r2l_last(zkp_ctx* ctx);
 
+/* The constants of the ONE key of a shared-key call are kept across calls: the set-up kernels compare the modulus they are handed with
+ * the one their record was computed from (a tag beside each constants buffer, on the device) and return at once when it is the same —
+ * 1 ms of a one-proof prove + verify.  The host side clears a tag whenever its buffer was reallocated or written by a launch of several
+ * keys; a rejected modulus never leaves a valid tag.  On by default; $ZKP_KEY_CACHE=0 at ctx create or zkp_diag_set_key_cache(ctx, 0)
+ * turn it off (every call computes, as before round 5).  zkp_diag_key_cache_state: out[3] = {tag valid, the last set-up launch into
+ * the buffer returned early, set-ups that computed so far} for buffer `which` (0 = n^2 / modexp constants, 1 = the second set (mod n),
+ * 2 = the n-sized record behind the base-n form, 3 = the base-n record) of the engine the most recent routed call ran on. */
+int32_t zkp_diag_set_key_cache(zkp_ctx* ctx, int32_t on);
+int32_t zkp_diag_key_cache_state(zkp_ctx* ctx, int32_t which, uint32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

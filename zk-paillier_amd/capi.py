@@ -50,6 +50,8 @@ DIAG_EXPORTS = {
     "zkp_diag_set_r2l": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_r2l_last": (C.c_int32, [C.c_void_p]),
     "zkp_diag_mid_limbs_per_lane": (C.c_int32, [C.c_void_p]),
+    "zkp_diag_set_key_cache": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "zkp_diag_key_cache_state": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]),
 }
 ENC_FORM_AUTO, ENC_FORM_N2, ENC_FORM_SHARED, ENC_FORM_ALWAYS = 0, 1, 2, 3
 ENC_FORMS = {"auto": ENC_FORM_AUTO, "n2": ENC_FORM_N2, "shared": ENC_FORM_SHARED, "basen": ENC_FORM_ALWAYS, "always": ENC_FORM_ALWAYS}
@@ -317,6 +319,16 @@ class Context:
     def mid_limbs_per_lane(self) -> int:
         """limbs per lane of the mid engine (libzkp_hip_mid.so), 0 when it is not loaded"""
         return self.lib.zkp_diag_mid_limbs_per_lane(self.h)
+
+    def set_key_cache(self, on: bool):
+        """keep the constants of the one key of a shared-key call across calls (include/zkp_hip_diag.h); on by default"""
+        self.check(self.lib.zkp_diag_set_key_cache(self.h, 1 if on else 0))
+
+    def key_cache_state(self, which: int):
+        """(valid, last set-up launch returned early, set-ups computed so far) of constants buffer `which` on the engine that ran last"""
+        out = (C.c_uint32 * 3)()
+        self.check(self.lib.zkp_diag_key_cache_state(self.h, which, out))
+        return bool(out[0]), bool(out[1]), int(out[2])
 
     def r2l_last(self) -> bool:
         return self.lib.zkp_diag_r2l_last(self.h) == 1

@@ -32,6 +32,10 @@ using namespace zkp;
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  // constants buffers only (run_setup): the tag of the ONE key whose record the buffer holds (kernels_modexp.hpp), and what tells the host
+  // that the record is no longer that key's — `gen` moves with every reallocation and every launch of several keys into the buffer
+  uint32_t* tag = nullptr;
+  uint64_t gen = 0, tag_gen = 0;
 };
 
 // staging blocks kept by the ctx between calls (host-pointer mode): a call takes the best-fitting cached block or
@@ -64,6 +68,7 @@ struct zkp_ctx {
   std::vector<hipEvent_t> ev_pipe;
   bool copy_busy = false;        // copies enqueued on `copy` that nothing has waited for yet
   int last_host_blocks = 0;      // proof blocks of the most recent RangeProofNi host-pointer call (1: the plain path)
+  int key_cache = 1;             // keep the constants of the ONE key of a shared-key call across calls (setup_tag below); $ZKP_KEY_CACHE=0 at zkp_ctx_create or zkp_diag_set_key_cache turn it off
   int host_chunks = -1;          // $ZKP_HOST_CHUNKS at zkp_ctx_create: unset (-1) or 1 = a host-pointer call is one block, N = N equal blocks, 0 = uneven blocks (host_blocks)
   std::string err;
   DevBuf consts, consts2, table, scratch[48];
@@ -119,7 +124,7 @@ static int32_t zkp_caught(zkp_ctx* c, int32_t st, const char* what) noexcept {
   X(zkp_zero_proof_prove_batch) X(zkp_zero_proof_verify_batch) X(zkp_ciphertext_proof_prove_batch)                               \
   X(zkp_ciphertext_proof_verify_batch) X(zkp_verlin_proof_prove_batch) X(zkp_verlin_proof_verify_batch)                          \
   X(zkp_mul_proof_prove_batch) X(zkp_mul_proof_verify_batch) X(zkp_correct_message_prove_batch) X(zkp_correct_message_verify_batch)           \
-  X(zkp_diag_basen) X(zkp_diag_basen_last) X(zkp_diag_set_enc_form) X(zkp_diag_set_r2l) X(zkp_diag_r2l_last)
+  X(zkp_diag_basen) X(zkp_diag_basen_last) X(zkp_diag_set_enc_form) X(zkp_diag_set_r2l) X(zkp_diag_r2l_last) X(zkp_diag_set_key_cache) X(zkp_diag_key_cache_state)
 
 struct LatEngine {
   void* handle = nullptr;
@@ -246,10 +251,14 @@ static int32_t ensure(zkp_ctx* c, DevBuf& b, size_t bytes) {
   if (b.cap >= bytes) return ZKP_OK;
   if (b.p) HIPCHK(c, hipFree(b.p));
   b.p = nullptr; b.cap = 0;
+  b.gen++;
   HIPCHK(c, hipMalloc(&b.p, bytes));
   b.cap = bytes;
   return ZKP_OK;
 }
+// the tag of a constants buffer for a launch of `count` keys into it: the device pointer to hand to the kernel (count == 1 and the cache is
+// on), nullptr otherwise; cleared on the stream when the buffer has changed hands since the tag was written
+static int32_t setup_tag(zkp_ctx* c, DevBuf& b, uint64_t count, uint32_t** out);
 
 // ---- staging of host buffers --------------------------------------------------------------
 struct Stage {
@@ -461,13 +470,33 @@ template <int G, class K> static int resident_blocks(zkp_ctx* c, K kernel) {
   return per_cu * c->cus;
 }
 
+static int32_t setup_tag(zkp_ctx* c, DevBuf& b, uint64_t count, uint32_t** out) {
+  *out = nullptr;
+  if (count != 1 || !c->key_cache) {                          // several keys (or the cache is off): whatever single-key record the buffer held is gone
+    b.gen++;
+    return ZKP_OK;
+  }
+  if (!b.tag) {
+    HIPCHK(c, hipMalloc((void**)&b.tag, SETUP_TAG_WORDS * sizeof(uint32_t)));
+    HIPCHK(c, hipMemsetAsync(b.tag, 0, SETUP_TAG_WORDS * sizeof(uint32_t), c->stream));
+    b.tag_gen = b.gen;
+  } else if (b.tag_gen != b.gen) {
+    HIPCHK(c, hipMemsetAsync(b.tag, 0, 4, c->stream));
+    b.tag_gen = b.gen;
+  }
+  *out = b.tag;
+  return ZKP_OK;
+}
+
 template <int G> static int32_t run_setup(zkp_ctx* c, const uint32_t* src, uint64_t stride, int src_words, int square, uint64_t count, DevBuf& buf) {
   using CL = ConstLayout<G>;
   using LL = LdsLayoutFull<G>;
   int32_t st = ensure(c, buf, count * CL::WORDS * sizeof(uint32_t));
   if (st) return st;
   const unsigned blocks = (unsigned)((count + LL::GROUPS_PER_BLOCK - 1) / LL::GROUPS_PER_BLOCK);
-  hipLaunchKernelGGL(k_setup<G>, dim3(blocks), dim3(LL::THREADS), LL::BYTES_PER_BLOCK, c->stream, src, stride, src_words, square, count, (uint32_t*)buf.p, c->setup_flag);
+  uint32_t* tag = nullptr;
+  if ((st = setup_tag(c, buf, count, &tag))) return st;
+  hipLaunchKernelGGL(k_setup<G>, dim3(blocks), dim3(LL::THREADS), LL::BYTES_PER_BLOCK, c->stream, src, stride, src_words, square, count, (uint32_t*)buf.p, c->setup_flag, tag);
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
 }
@@ -550,8 +579,8 @@ extern template __global__ void zkp::k_enc_basen_keys<BN_GA>(EncArgs, const uint
 extern template __global__ void zkp::k_enc_basen_keys<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 extern template __global__ void zkp::k_basen_finish<BN_GA>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*);
 extern template __global__ void zkp::k_basen_finish<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*);
-extern template __global__ void zkp::k_setup_basen<BN_GA>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
-extern template __global__ void zkp::k_setup_basen<BN_GB>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
+extern template __global__ void zkp::k_setup_basen<BN_GA>(const uint32_t*, uint32_t*, uint64_t, uint32_t*, const uint32_t*, uint32_t*);
+extern template __global__ void zkp::k_setup_basen<BN_GB>(const uint32_t*, uint32_t*, uint64_t, uint32_t*, const uint32_t*, uint32_t*);
 extern template __global__ void zkp::k_expected<2 * BN_GA>(EncArgs, uint32_t*, const uint32_t*);
 extern template __global__ void zkp::k_expected<2 * BN_GB>(EncArgs, uint32_t*, const uint32_t*);
 extern template __global__ void zkp::k_diag_basen<BN_GA>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
@@ -583,8 +612,10 @@ template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uin
   if ((st = ensure(c, c->bn_flag, 64))) return st;
   HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->bn_flag.p, 1, 2, c->stream));      // word 0: every key of the batch qualified (cleared by k_setup_basen); word 1: the constant 1
   constexpr unsigned GPB = 64 / G;
+  uint32_t* tag = nullptr;
+  if ((st = setup_tag(c, c->bn_consts, nkeys, &tag))) return st;
   hipLaunchKernelGGL(k_setup_basen<G>, dim3((unsigned)((nkeys + GPB - 1) / GPB)), dim3(64), GPB * BN_SETUP_LDS_WORDS * sizeof(uint32_t), c->stream,
-                     (const uint32_t*)c->bn_ncst.p, (uint32_t*)c->bn_consts.p, nkeys, (uint32_t*)c->bn_flag.p);
+                     (const uint32_t*)c->bn_ncst.p, (uint32_t*)c->bn_consts.p, nkeys, (uint32_t*)c->bn_flag.p, tag ? (const uint32_t*)c->bn_ncst.tag : nullptr, tag);
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
 }
@@ -717,6 +748,7 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
   c->enc_form = enc_form_from_env();
 #endif
   if (const char* hc = std::getenv("ZKP_HOST_CHUNKS")) c->host_chunks = std::atoi(hc);
+  if (const char* kc = std::getenv("ZKP_KEY_CACHE")) c->key_cache = std::atoi(kc) != 0;
   if (const char* rl = std::getenv("ZKP_R2L")) c->bn_r2l = std::atoi(rl);
   if (const char* rl = std::getenv("ZKP_R2L_LANES")) c->bn_r2l_lanes = std::atoi(rl) == 8 ? 8 : 12;
   c->owns_stream = own_stream;
@@ -767,7 +799,7 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_ctx_destroy(c->eng_ctx[k]);
-  for (DevBuf* b : {&c->consts, &c->consts2, &c->table, &c->bn_ncst, &c->bn_consts, &c->bn_table, &c->bn_expected, &c->bn_raw, &c->bn_flag, &c->bn_left}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&c->consts, &c->consts2, &c->table, &c->bn_ncst, &c->bn_consts, &c->bn_table, &c->bn_expected, &c->bn_raw, &c->bn_flag, &c->bn_left}) { if (b->p) (void)hipFree(b->p); if (b->tag) (void)hipFree(b->tag); }
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
@@ -900,6 +932,33 @@ extern "C" int32_t zkp_diag_set_r2l(zkp_ctx* c, int32_t mode) try {
 #ifndef ZKP_SECONDARY_ENGINE
   for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_diag_set_r2l(c->eng_ctx[k], mode);
 #endif
+  return ZKP_OK;
+} ZKP_CATCH(c)
+// the per-key constants kept across calls (setup_tag): on / off for this ctx and its secondary engines
+extern "C" int32_t zkp_diag_set_key_cache(zkp_ctx* c, int32_t on) try {
+  if (!c) return ZKP_EINVAL;
+  c->key_cache = on != 0;
+#ifndef ZKP_SECONDARY_ENGINE
+  for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_diag_set_key_cache(c->eng_ctx[k], on);
+#endif
+  return ZKP_OK;
+} ZKP_CATCH(c)
+// the tag header of one constants buffer of the engine the most recent routed call ran on (which: 0 = n^2 / modexp constants, 1 = the
+// second set (mod n), 2 = the n-sized record behind the base-n form, 3 = the base-n record): out[0] = 1 valid, out[1] = 1 when the last
+// set-up launch into it returned early, out[2] = its epoch (set-ups that computed).  All zero when the buffer has no tag.  Synchronises.
+extern "C" int32_t zkp_diag_key_cache_state(zkp_ctx* c, int32_t which, uint32_t* out) try {
+  if (!c || !out || which < 0 || which > 3) return ZKP_EINVAL;
+#ifndef ZKP_SECONDARY_ENGINE
+  if (c->lat_ctx && c->last_geometry == c->lat->limbs_per_lane) return lat_forward_plain(c, c->lat->p_zkp_diag_key_cache_state(c->lat_ctx, which, out));
+#endif
+  out[0] = out[1] = out[2] = 0;
+  DevBuf* b = which == 0 ? &c->consts : which == 1 ? &c->consts2 : which == 2 ? &c->bn_ncst : &c->bn_consts;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!b->tag || b->tag_gen != b->gen) return ZKP_OK;
+  uint32_t head[SETUP_TAG_HEAD];
+  HIPCHK(c, hipMemcpy(head, b->tag, sizeof(head), hipMemcpyDeviceToHost));
+  out[0] = head[0] == SETUP_TAG_MAGIC; out[1] = head[4]; out[2] = head[5];
   return ZKP_OK;
 } ZKP_CATCH(c)
 // did the most recent Paillier launch of this ctx run on it?

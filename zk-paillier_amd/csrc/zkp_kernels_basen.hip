@@ -13,8 +13,8 @@ template __global__ void k_enc_basen_keys<BN_GA>(EncArgs, const uint32_t*, const
 template __global__ void k_enc_basen_keys<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 template __global__ void k_basen_finish<BN_GA>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*);
 template __global__ void k_basen_finish<BN_GB>(EncArgs, const uint32_t*, const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*);
-template __global__ void k_setup_basen<BN_GA>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
-template __global__ void k_setup_basen<BN_GB>(const uint32_t*, uint32_t*, uint64_t, uint32_t*);
+template __global__ void k_setup_basen<BN_GA>(const uint32_t*, uint32_t*, uint64_t, uint32_t*, const uint32_t*, uint32_t*);
+template __global__ void k_setup_basen<BN_GB>(const uint32_t*, uint32_t*, uint64_t, uint32_t*, const uint32_t*, uint32_t*);
 template __global__ void k_expected<2 * BN_GA>(EncArgs, uint32_t*, const uint32_t*);
 template __global__ void k_expected<2 * BN_GB>(EncArgs, uint32_t*, const uint32_t*);
 template __global__ void k_diag_basen<BN_GA>(const uint32_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
