@@ -862,7 +862,15 @@ def other_configs(env):
             rec0["latency_engine_pair_ladder_on_n2"] = one_proof()
         finally:
             ctx.set_r2l(1); ctx.set_geometry(lpl)
-        ok = ok and rec0["accepted"] and rec0["on_the_throughput_engine"]["accepted"] and rec0["latency_engine_pair_ladder_on_n2"]["accepted"]
+        # the headline figure of this leg is a call under a key the ctx has seen (the key's constants are kept across calls: the set-up kernels
+        # return early); the same call with that switched off = every call of a process that never repeats a key
+        ctx.set_geometry(0); ctx.set_key_cache(False)
+        try:
+            rec0["without_the_key_constants_cache"] = one_proof()
+        finally:
+            ctx.set_key_cache(True); ctx.set_geometry(lpl)
+        rec0["key_constants"] = "kept across calls (zkp_diag_set_key_cache; DESIGN.md section 3 item 13): prove_ms / verify_ms are calls under a key the ctx has seen"
+        ok = ok and rec0["accepted"] and rec0["on_the_throughput_engine"]["accepted"] and rec0["latency_engine_pair_ladder_on_n2"]["accepted"] and rec0["without_the_key_constants_cache"]["accepted"]
         other["configs[0] one RangeProofNi, n=2048, host buffers (GPU latency, best of reps)"] = rec0
 
     # ---- configs[3]: 65536 NiCorrectKeyProof verifies, n = 2048, 65536 distinct (pseudo-)moduli cut into `world` blocks of keys:
