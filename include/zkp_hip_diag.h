@@ -67,6 +67,13 @@ int32_t zkp_diag_r2l_last(zkp_ctx* ctx);
  * turn it off (every call computes, as before round 5).  zkp_diag_key_cache_state: out[3] = {tag valid, the last set-up launch into
  * the buffer returned early, set-ups that computed so far} for buffer `which` (0 = n^2 / modexp constants, 1 = the second set (mod n),
  * 2 = the n-sized record behind the base-n form, 3 = the base-n record) of the engine the most recent routed call ran on. */
+/* A RangeProofNi prove / verify call of 65 ... 96 proofs under one 2048-bit key (items between one and one and a half wavefronts per SIMD of
+ * the mid engine) runs as TWO concurrent calls: the first 64 proofs on the mid engine on the ctx's stream, the rest on a second ctx of the
+ * latency engine with a stream of its own (58 -> 41 ... 53 ms; csrc/zkp_api_proofs.inc: range_split_run).  Needs both secondary engines and
+ * the automatic geometry / Enc form.  On by default; $ZKP_SPLIT=0 at ctx create or zkp_diag_set_split(ctx, 0) turn it off.
+ * zkp_diag_last_split: the proofs of the most recent RangeProofNi call that went to the latency engine beside the mid engine (0: not split). */
+int32_t zkp_diag_set_split(zkp_ctx* ctx, int32_t on);
+int32_t zkp_diag_last_split(zkp_ctx* ctx);
 int32_t zkp_diag_set_key_cache(zkp_ctx* ctx, int32_t on);
 int32_t zkp_diag_key_cache_state(zkp_ctx* ctx, int32_t which, uint32_t* out);
 

@@ -5,6 +5,9 @@ A RangeProofNi call at n = 2048 under one key is served by one of these kernel f
     (k_enc_basen_r2l) up to 8 proofs, the window ladder on the n^2-sized product up to 16, 8 Enc per wavefront in base-n form
     (k_enc_basen<8>) from there on — except
   * 41 ... 64 and 129 ... 192 proofs: the mid engine (18 limbs per lane, libzkp_hip_mid.so), 16 Enc per wavefront in base-n form,
+  * 65 ... 96 proofs: TWO concurrent calls — up to 64 proofs on the mid engine, at least 16 on a second ctx of the latency engine —,
+    and 17 ... 20 proofs: 16 on the latency engine's window ladder, the rest beside them on its one-Enc-per-wavefront ladder
+    (csrc/zkp_api_proofs.inc: range_split_plan / range_split_run; zkp_diag_last_split),
   * the throughput engine's base-n kernels (k_enc_basen<2>, 32 Enc per wavefront) beyond,
   * its n^2-sized kernels (k_enc<4, .>) for keys the form does not take and for launches pinned to that engine that leave SIMDs idle.
 The parity suites pin each family in turn (tests/conftest.py: ctx); this file lets the library choose, says which family it expects for
@@ -43,6 +46,8 @@ def expected_family(c, items):
     (route_latency with one_key_paillier, launch_basen of either engine)"""
     lat, mid = c.latency_limbs_per_lane(), c.mid_limbs_per_lane()
     simds = 4 * compute_units()
+    if lat == 9 and mid == 18 and (16 * simds < items <= 24 * simds or 4 * simds < items <= 5 * simds):
+        return "split"                                         # two concurrent calls (expected_tail below)
     if mid == 18 and (10 * simds < items <= 16 * simds or 32 * simds < items <= 48 * simds):
         return "mid-basen"                                     # 16 Enc per wavefront: one (two) wavefronts per SIMD of the mid engine
     if lat == 9 and items <= 3 * simds * 8:                    # the latency engine: up to three wavefronts per SIMD at 8 Enc per wavefront
@@ -52,7 +57,18 @@ def expected_family(c, items):
     return "base-n" if items > simds * 16 else "n2"
 
 
+def expected_tail(B):
+    """proofs of a split call that run on the second latency-engine ctx (csrc/zkp_api_proofs.inc: range_split_plan; 256 Enc per proof)"""
+    simds = 4 * compute_units()
+    full, least = 16 * simds // 256, 4 * simds // 256
+    if B * 256 <= 5 * simds:
+        return B - least                                       # 17 ... 20 proofs: 16 on the window ladder, the rest on the one-Enc-per-wavefront ladder
+    return B - full if B - full >= least else least            # 65 ... 96: 64 on the mid engine | at least 16 on the latency engine
+
+
 def family_that_ran(c):
+    if c.last_split() > 0:
+        return "split"
     g = c.last_geometry()
     if g == 18:
         lanes, ok = c.diag_basen_last()
@@ -75,7 +91,7 @@ def sub_batch(pb, idx, n_bits):
     return s
 
 
-@pytest.mark.parametrize("B", [4, 12, 32, 64, 96, 128, 160, 300])
+@pytest.mark.parametrize("B", [4, 12, 18, 32, 64, 65, 80, 96, 128, 160, 300])
 def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     n_bits, kw = 2048, 64
     n = H.fixture_key()[2]
@@ -90,6 +106,8 @@ def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     actx.range_ni_prove(pb.struct(), wt.struct(), None, None, status, device=False)
     want = expected_family(actx, 2 * 128 * B)
     assert family_that_ran(actx) == want, (B, family_that_ran(actx), want)
+    if want == "split":
+        assert actx.last_split() == expected_tail(B)
     assert not status.any()
     # the prove transcripts of a sample of the batch, byte for byte against the oracle
     idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1} & set(range(B)))
@@ -180,3 +198,50 @@ def test_the_environment_is_read_once_at_ctx_create(actx):
         c2.close()
     finally:
         os.environ.pop("ZKP_BASEN", None)
+
+
+def test_split_call_device_resident_and_switched_off(actx, oracle):
+    """a call the library cuts in two (80 proofs: 64 on the mid engine, 16 beside them on the latency engine) with DEVICE-resident arrays —
+    the two streams are ordered against the ctx's stream by events, not by the host —, and the same call with the cut switched off:
+    the same bytes; then an invalid argument inside the tail comes back as the call's error"""
+    import torch
+    if expected_family(actx, 2 * 128 * 80) != "split":
+        pytest.skip("the split rule needs both secondary engines")
+    n_bits, B = 2048, 80
+    n = H.fixture_key()[2]
+    cases = H.build_range_case(b"routing-split", [n], n_bits, B)
+    oracle.set_threads(min(16, oracle.max_threads()))
+    pb_h, wt_h = H.fill_batch(cases, n_bits, True, oracle)
+    dev = torch.device("cuda", 0)
+    actx.set_geometry(0); actx.set_enc_form("auto"); actx.set_split(True)
+    try:
+        pb_d, wt_d = pb_h.to(dev), wt_h.to(dev)
+        st_d = torch.full((B,), 9, dtype=torch.uint8, device=dev)
+        actx.range_ni_prove(pb_d.struct(), wt_d.struct(), None, None, st_d, device=True)
+        assert actx.last_split() == 16
+        v_d = torch.full((B,), 9, dtype=torch.uint8, device=dev)
+        actx.range_ni_verify(pb_d.struct(), v_d, device=True)          # (reads what the prove call wrote: ordered by the events)
+        assert actx.last_split() == 16
+        actx.synchronize()
+        assert not st_d.cpu().numpy().any() and bool(v_d.cpu().numpy().all())
+        got = pb_d.to(None)
+        actx.set_split(False)
+        pb_1 = zkp.RangeBatch(n_bits, B, 128, shared_key=True)
+        pb_1.n[:] = pb_h.n; pb_1.range[:] = pb_h.range; pb_1.ciphertext[:] = pb_h.ciphertext
+        actx.range_ni_prove(pb_1.struct(), wt_h.struct(), None, None, None, device=False)
+        assert actx.last_split() == 0 and family_that_ran(actx) == "lat-basen"
+        for f in FIELDS:
+            assert np.array_equal(getattr(got, f), getattr(pb_1, f)), f
+        oracle.range_ni_prove(pb_h.struct(), wt_h.struct(), None, None, None)
+        for f in FIELDS:
+            assert np.array_equal(getattr(pb_h, f), getattr(pb_1, f)), f
+        # tampered proofs on both sides of the cut, host arrays
+        actx.set_split(True)
+        pb_1.resp_r1[3, 7, 0] ^= 1; pb_1.c2[70, 5, 9] ^= 4; pb_1.resp_w1[79, 100, 1] ^= 2
+        v = np.full(B, 9, np.uint8)
+        actx.range_ni_verify(pb_1.struct(), v, device=False)
+        assert actx.last_split() == 16
+        expect = np.ones(B, np.uint8); expect[[3, 70, 79]] = 0
+        assert np.array_equal(v, expect)
+    finally:
+        actx.set_split(True); actx.set_geometry(0); actx.set_enc_form("auto")

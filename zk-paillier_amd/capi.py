@@ -50,6 +50,8 @@ DIAG_EXPORTS = {
     "zkp_diag_set_r2l": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_r2l_last": (C.c_int32, [C.c_void_p]),
     "zkp_diag_mid_limbs_per_lane": (C.c_int32, [C.c_void_p]),
+    "zkp_diag_set_split": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "zkp_diag_last_split": (C.c_int32, [C.c_void_p]),
     "zkp_diag_set_key_cache": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_key_cache_state": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]),
 }
@@ -319,6 +321,14 @@ class Context:
     def mid_limbs_per_lane(self) -> int:
         """limbs per lane of the mid engine (libzkp_hip_mid.so), 0 when it is not loaded"""
         return self.lib.zkp_diag_mid_limbs_per_lane(self.h)
+
+    def set_split(self, on: bool):
+        """calls of 65 ... 96 proofs under one 2048-bit key as two concurrent calls on the mid and the latency engine (on by default)"""
+        self.check(self.lib.zkp_diag_set_split(self.h, 1 if on else 0))
+
+    def last_split(self) -> int:
+        """proofs of the most recent RangeProofNi call that ran on the latency engine beside the mid engine (0: the call was not split)"""
+        return self.lib.zkp_diag_last_split(self.h)
 
     def set_key_cache(self, on: bool):
         """keep the constants of the one key of a shared-key call across calls (include/zkp_hip_diag.h); on by default"""

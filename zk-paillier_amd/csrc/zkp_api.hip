@@ -9,8 +9,10 @@
 #include <cstdlib>
 #include <new>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/zkp_hip.h"
@@ -68,6 +70,14 @@ struct zkp_ctx {
   std::vector<hipEvent_t> ev_pipe;
   bool copy_busy = false;        // copies enqueued on `copy` that nothing has waited for yet
   int last_host_blocks = 0;      // proof blocks of the most recent RangeProofNi host-pointer call (1: the plain path)
+  // A RangeProofNi call of 65 ... 96 proofs under one 2048-bit key runs as TWO concurrent calls (range_split in zkp_api_proofs.inc): one
+  // wavefront per SIMD of the mid engine (64 proofs) on this ctx's stream, the rest on a second ctx of the latency engine with a stream of
+  // its own — created on first use.  $ZKP_SPLIT=0 at zkp_ctx_create / zkp_diag_set_split turn it off.
+  zkp_ctx* split_ctx = nullptr;
+  hipStream_t split_stream = nullptr;
+  hipEvent_t ev_split[2] = {nullptr, nullptr};
+  int split_calls = 1;
+  int last_split = 0;            // proofs the most recent RangeProofNi call sent to the latency engine beside the mid engine (0: it was not split)
   int key_cache = 1;             // keep the constants of the ONE key of a shared-key call across calls (setup_tag below); $ZKP_KEY_CACHE=0 at zkp_ctx_create or zkp_diag_set_key_cache turn it off
   int host_chunks = -1;          // $ZKP_HOST_CHUNKS at zkp_ctx_create: unset (-1) or 1 = a host-pointer call is one block, N = N equal blocks, 0 = uneven blocks (host_blocks)
   std::string err;
@@ -749,6 +759,7 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
 #endif
   if (const char* hc = std::getenv("ZKP_HOST_CHUNKS")) c->host_chunks = std::atoi(hc);
   if (const char* kc = std::getenv("ZKP_KEY_CACHE")) c->key_cache = std::atoi(kc) != 0;
+  if (const char* sp = std::getenv("ZKP_SPLIT")) c->split_calls = std::atoi(sp) != 0;
   if (const char* rl = std::getenv("ZKP_R2L")) c->bn_r2l = std::atoi(rl);
   if (const char* rl = std::getenv("ZKP_R2L_LANES")) c->bn_r2l_lanes = std::atoi(rl) == 8 ? 8 : 12;
   c->owns_stream = own_stream;
@@ -798,6 +809,9 @@ extern "C" int32_t zkp_ctx_destroy(zkp_ctx* c) try {
   if (!c) return ZKP_EINVAL;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->split_ctx) { (void)hipStreamSynchronize(c->split_stream); (void)c->eng[0]->p_zkp_ctx_destroy(c->split_ctx); }
+  if (c->split_stream) (void)hipStreamDestroy(c->split_stream);
+  for (hipEvent_t e : c->ev_split) if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_ctx_destroy(c->eng_ctx[k]);
   for (DevBuf* b : {&c->consts, &c->consts2, &c->table, &c->bn_ncst, &c->bn_consts, &c->bn_table, &c->bn_expected, &c->bn_raw, &c->bn_flag, &c->bn_left}) { if (b->p) (void)hipFree(b->p); if (b->tag) (void)hipFree(b->tag); }
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
@@ -825,6 +839,7 @@ extern "C" int32_t zkp_ctx_release_staging(zkp_ctx* c) try {
   // the base-n form's per-launch areas (window tables of pairs: 1.4 GB under one key, 2.5 GB under per-proof keys; raw pairs; Mask-row
   // products) are sized by the largest launch so far and rebuilt on demand
   for (DevBuf* b : {&c->bn_table, &c->bn_raw, &c->bn_expected}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+  if (c->split_ctx) (void)c->eng[0]->p_zkp_ctx_release_staging(c->split_ctx);
   for (int k = 0; k < 2; k++)
     if (c->eng_ctx[k]) { const int32_t st = c->eng[k]->p_zkp_ctx_release_staging(c->eng_ctx[k]); if (st) { c->err = c->eng[k]->p_zkp_last_error_string(c->eng_ctx[k]); return st; } }
   return ZKP_OK;
@@ -961,6 +976,10 @@ extern "C" int32_t zkp_diag_key_cache_state(zkp_ctx* c, int32_t which, uint32_t*
   out[0] = head[0] == SETUP_TAG_MAGIC; out[1] = head[4]; out[2] = head[5];
   return ZKP_OK;
 } ZKP_CATCH(c)
+// calls of 65 ... 96 proofs as two concurrent calls on two engines (range_split): on / off; how many proofs of the most recent
+// RangeProofNi call went to the latency engine beside the mid engine (0: the call was not split)
+extern "C" int32_t zkp_diag_set_split(zkp_ctx* c, int32_t on) { if (!c) return ZKP_EINVAL; c->split_calls = on != 0; return ZKP_OK; }
+extern "C" int32_t zkp_diag_last_split(zkp_ctx* c) { return c ? c->last_split : -1; }
 // did the most recent Paillier launch of this ctx run on it?
 extern "C" int32_t zkp_diag_r2l_last(zkp_ctx* c) {
   if (!c) return -1;
