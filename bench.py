@@ -844,7 +844,9 @@ def other_configs(env):
                 t2 = time.perf_counter()
                 rec = {"prove_ms": 1e3 * (t1 - t0), "verify_ms": 1e3 * (t2 - t1), "prove_plus_verify_ms": 1e3 * (t2 - t0), "accepted": bool(v1[0] == 1),
                        "limbs_per_lane": ctx.last_geometry(),
-                       "enc_kernel": ("k_enc_basen_r2l (one Enc per wavefront: the base-n exponentiation as a right-to-left ladder pipelined over five lane groups, 2052 slots of 72 sub-steps)"
+                       "enc_kernel": (("k_enc_basen_r2l5 (FIVE wavefronts per Enc, one per role of the right-to-left base-n ladder: 36 lanes x 2 limbs per n-sized integer, quotient digits wave-uniform in "
+                                       "scalar registers; 2052 slots of 72 sub-steps, two workgroup barriers per slot)" if ctx.r2l_lanes_last() == 36 else
+                                       "k_enc_basen_r2l (one Enc per wavefront: the base-n exponentiation as a right-to-left ladder pipelined over five lane groups, 2052 slots of 72 sub-steps)")
                                       if ctx.r2l_last() else ("k_enc<16, false, true> (pair ladder on the n^2-sized product: 2058 products of 144 sub-steps)" if ctx.last_geometry() == 9 else "k_enc<4, true>"))}
                 if best is None or rec["prove_plus_verify_ms"] < best["prove_plus_verify_ms"]:
                     best = rec
@@ -857,6 +859,11 @@ def other_configs(env):
         finally:
             ctx.set_geometry(lpl)                # the batch legs are pinned to the throughput engine
         rec0["on_the_throughput_engine"] = one_proof()
+        ctx.set_geometry(0); ctx.set_r2l_lanes(12)      # the one-wavefront-per-Enc form of the same ladder (what served this shape before the five-wavefront kernel)
+        try:
+            rec0["latency_engine_one_wavefront_per_enc"] = one_proof()
+        finally:
+            ctx.set_r2l_lanes(0); ctx.set_geometry(lpl)
         ctx.set_geometry(0); ctx.set_r2l(0)     # the kernel that served this shape until round 5, for comparison
         try:
             rec0["latency_engine_pair_ladder_on_n2"] = one_proof()
@@ -870,7 +877,7 @@ def other_configs(env):
         finally:
             ctx.set_key_cache(True); ctx.set_geometry(lpl)
         rec0["key_constants"] = "kept across calls (zkp_diag_set_key_cache; DESIGN.md section 3 item 13): prove_ms / verify_ms are calls under a key the ctx has seen"
-        ok = ok and rec0["accepted"] and rec0["on_the_throughput_engine"]["accepted"] and rec0["latency_engine_pair_ladder_on_n2"]["accepted"] and rec0["without_the_key_constants_cache"]["accepted"]
+        ok = ok and rec0["accepted"] and rec0["on_the_throughput_engine"]["accepted"] and rec0["latency_engine_one_wavefront_per_enc"]["accepted"] and rec0["latency_engine_pair_ladder_on_n2"]["accepted"] and rec0["without_the_key_constants_cache"]["accepted"]
         other["configs[0] one RangeProofNi, n=2048, host buffers (GPU latency, best of reps)"] = rec0
 
     # ---- configs[3]: 65536 NiCorrectKeyProof verifies, n = 2048, 65536 distinct (pseudo-)moduli cut into `world` blocks of keys:

@@ -223,7 +223,7 @@ def test_range_proofs_under_per_proof_keys_with_keys_outside_the_form(oracle):
         c.close()
 
 
-@pytest.mark.parametrize("lanes", [12, 8], ids=["12-lanes-x-6-limbs", "8-lanes-x-9-limbs"])
+@pytest.mark.parametrize("lanes", [12, 8, 36], ids=["12-lanes-x-6-limbs", "8-lanes-x-9-limbs", "five-wavefronts-of-36-lanes-x-2-limbs"])
 def test_one_enc_per_wavefront_ladder_of_the_latency_engine(lanes):
     """csrc/kernels_basen_r2l.hpp: the base-n exponentiation as a right-to-left ladder pipelined over five lane groups, the latency engine's
     kernel for calls of a few proofs under one 2048-bit key (tests/test_basen_r2l_model.py states the pipeline on values): Enc against
@@ -242,7 +242,7 @@ def test_one_enc_per_wavefront_ladder_of_the_latency_engine(lanes):
         c.set_geometry(9)
         for trial, n in enumerate((odd_modulus(rnd, 2048), odd_modulus(rnd, 2047), H.fixture_key()[2], odd_modulus(rnd, 1200))):
             nn = n * n
-            count = 37 if trial else 300                          # one launch of more than a wavefront per SIMD-quarter, then small ones
+            count = 37 if trial else (1030 if lanes == 36 else 300)      # one launch of more than a wavefront per SIMD-quarter (five wavefronts per Enc: more items than workgroups), then small ones
             ms = [rnd.randrange(n) for _ in range(count)]
             rs = [rnd.getrandbits(n_bits) for _ in range(count)]
             ms[0], rs[0] = 0, 1
@@ -259,6 +259,7 @@ def test_one_enc_per_wavefront_ladder_of_the_latency_engine(lanes):
                 out = np.zeros((count, 2 * kw), np.uint32)
                 c.paillier_enc(n_bits, count, nw, 0, mw, rw, out)
                 assert c.last_geometry() == 9 and c.r2l_last() == (mode == 2), (trial, mode)
+                assert c.r2l_lanes_last() == (lanes if mode == 2 else 0), (trial, mode, c.r2l_lanes_last())
                 outs.append(out)
             assert np.array_equal(outs[0], outs[1])
             for i in range(count):

@@ -91,7 +91,7 @@ def sub_batch(pb, idx, n_bits):
     return s
 
 
-@pytest.mark.parametrize("B", [4, 12, 18, 32, 64, 65, 80, 96, 128, 160, 300])
+@pytest.mark.parametrize("B", [1, 2, 4, 12, 18, 32, 64, 65, 80, 96, 128, 160, 300])
 def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     n_bits, kw = 2048, 64
     n = H.fixture_key()[2]
@@ -108,6 +108,8 @@ def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     assert family_that_ran(actx) == want, (B, family_that_ran(actx), want)
     if want == "split":
         assert actx.last_split() == expected_tail(B)
+    if want == "lat-r2l":                                    # one Enc per compute unit: five wavefronts per Enc (k_enc_basen_r2l5); beyond: one wavefront per Enc
+        assert actx.r2l_lanes_last() == (36 if 2 * 128 * B <= compute_units() else 12), (B, actx.r2l_lanes_last())
     assert not status.any()
     # the prove transcripts of a sample of the batch, byte for byte against the oracle
     idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1} & set(range(B)))

@@ -49,6 +49,8 @@ DIAG_EXPORTS = {
     "zkp_diag_last_host_blocks": (C.c_int32, [C.c_void_p]),
     "zkp_diag_set_r2l": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_r2l_last": (C.c_int32, [C.c_void_p]),
+    "zkp_diag_set_r2l_lanes": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "zkp_diag_r2l_lanes_last": (C.c_int32, [C.c_void_p]),
     "zkp_diag_mid_limbs_per_lane": (C.c_int32, [C.c_void_p]),
     "zkp_diag_set_split": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_last_split": (C.c_int32, [C.c_void_p]),
@@ -342,6 +344,14 @@ class Context:
 
     def r2l_last(self) -> bool:
         return self.lib.zkp_diag_r2l_last(self.h) == 1
+
+    def set_r2l_lanes(self, lanes: int):
+        """lane geometry of that ladder: 0 = the library's rule, 36 = five wavefronts per Enc (36 lanes x 2 limbs each), 12 / 8 = one wavefront"""
+        self.check(self.lib.zkp_diag_set_r2l_lanes(self.h, lanes))
+
+    def r2l_lanes_last(self) -> int:
+        """geometry of the most recent launch of the ladder (0: the most recent Paillier launch was not one)"""
+        return self.lib.zkp_diag_r2l_lanes_last(self.h)
 
     def last_host_blocks(self) -> int:
         """proof blocks of the most recent RangeProofNi prove / verify call on host arrays (1: not cut)"""

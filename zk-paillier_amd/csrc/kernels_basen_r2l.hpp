@@ -28,6 +28,7 @@
 // Replaces, like k_enc: kzen-paillier EncryptWithChosenRandomness at range_proof.rs:165-169,179-183,280-291,330-334 — for the call shape
 // of the reference's own benchmark, ONE RangeProofNi proof (benches/all.rs:55-71).
 #pragma once
+#include <utility>
 #include "kernels_basen.hpp"
 
 namespace zkp {
@@ -372,6 +373,277 @@ __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t*
         add<RW>(R, R, U, gl);
         limbs_global_store<RW>(raw + item * E + L, R, gl);
       }
+    }
+  }
+}
+
+
+// ---- the same ladder with FIVE wavefronts per Enc: one role per wavefront, 36 lanes x 2 limbs per n-sized integer ------------------------
+// One proof is 192 - 256 Enc and the chip has 1024 SIMDs: the one-wavefront kernel above leaves three quarters of them idle, and what
+// bounds it is the instruction count of a lone wavefront's chain (an issue slot every 4 cycles, a multiply-add every 8): 24 multiply-adds
+// and ~17 other instructions per pair of sub-steps plus one trip through the LDS crossbar for the two quotient digits.  Here every role
+// (A, B, C, D, E of the header) is a wavefront of its own in a workgroup of five:
+//   * 2 limbs per lane — 8 multiply-adds per pair of sub-steps instead of 24;
+//   * ONE lane group per wavefront, so the quotient digits are WAVE-UNIFORM: lane 0's columns go through v_readfirstlane, the second digit
+//     is worked out on the scalar unit, and the multiply-adds take the digits as SGPR operands — no trip through the LDS crossbar;
+//   * the staged operand's limbs are broadcast reads of one address (two rows per ds_read_b128, fetched one iteration ahead);
+//   * the digits of a sub-step pair are parked in lane s of a register pair (v_writelane) and leave as one 8-byte store per lane after
+//     the product — the layout B and D read them in.
+// The roles meet at two workgroup barriers per slot: one between the products and the stores that overwrite what a neighbour's product
+// read (B's result over the b_k that D staged, A's over the digits B started from ...), one between the stores and the next slot's loads.
+// E's sum q_k = D + E, which needs D's result of the SAME slot, is taken at the start of the next slot (E keeps its product in registers).
+// Values, digits and the raw pair are those of k_enc_basen_r2l (tests/test_basen_r2l_model.py states them): same BnConst record, same
+// k_basen_finish behind it.  320 threads, 11 KB of LDS; lanes 36 - 63 of every wavefront hold zeros (the top lane's neighbour).
+// (timing probes of tools/dev/r2l5_variants.sh, never on in a shipped build: a product over a fraction of the rows, a slot without its barriers —
+// both compute garbage; the difference to the real kernel is what a row pair and what a barrier costs)
+#ifndef ZKP_R2L5_FOLD
+#define ZKP_R2L5_FOLD 1      /* v_and_b32_dpp and the shifted-in limb as a multiply-add's addend: A/B switch (profiles/r05/r2l5/) */
+#endif
+#ifndef ZKP_R2L5_REGS
+#define ZKP_R2L5_REGS 1      /* per-role constants in registers, one exponent-bit read per slot: A/B switch */
+#endif
+#ifndef ZKP_R2L5_DEV_ROW_DIVISOR
+#define ZKP_R2L5_DEV_ROW_DIVISOR 1
+#endif
+#ifndef ZKP_R2L5_DEV_NO_BARRIERS
+#define ZKP_R2L5_DEV_NO_BARRIERS 0
+#endif
+namespace r2l5 {
+using namespace r2l;
+__device__ __forceinline__ void slot_barrier() {
+  if constexpr (ZKP_R2L5_DEV_NO_BARRIERS) wave_lds_fence(); else __syncthreads();
+}
+constexpr int RW = 2, RG = LIMBS / RW, AW = LIMBS, WAVES = 5;
+constexpr int NEXP = NAREAS;                 // one more area: the exponent's words (the key), read bit by bit
+constexpr int LDS_WORDS = (NAREAS + 1) * AW + 8;
+
+__device__ __forceinline__ void ld2(uint32_t (&v)[RW], const uint32_t* area, int gl, bool on) {
+  if (on) { const uint2 t = *reinterpret_cast<const uint2*>(area + RW * gl); v[0] = t.x; v[1] = t.y; }
+  else { v[0] = 0; v[1] = 0; }
+}
+__device__ __forceinline__ void st2(uint32_t* area, const uint32_t (&v)[RW], int gl, bool on) {
+  if (on) *reinterpret_cast<uint2*>(area + RW * gl) = make_uint2(v[0], v[1]);
+}
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// R = (X * B + c + q M~) / R' with B staged limb-linear at ldsB; the digits of row s (sub-steps 2 s, 2 s + 1) land in lane s of Qd when CAPTURE
+template <bool CAPTURE>
+__device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], const uint32_t (&X)[RW], const uint32_t* ldsB, const uint32_t (&NT)[RW],
+                                        const uint64_t (&cin)[RW], uint32_t n1p, int gl) {
+  uint64_t c0 = cin[0], c1 = cin[1];
+  const uint32_t X0 = X[0], X1 = X[1], N0 = NT[0], N1 = NT[1];
+  uint32_t qa = 0, qb = 0;
+#if ZKP_R2L5_FOLD
+  uint32_t lm;
+  asm("v_mov_b32 %0, 0x1fffffff" : "=v"(lm));
+#endif
+  uint4 nx = *reinterpret_cast<const uint4*>(ldsB);
+  auto trip = [&](uint32_t b0, uint32_t b1, auto rowc) {
+    constexpr int row = decltype(rowc)::value;
+    c0 += (uint64_t)X0 * b0;
+    c1 += (uint64_t)X1 * b0;
+    c1 += (uint64_t)X0 * b1;
+    // M~ == -1 (mod 2^29): the first digit is lane 0's bottom limb, the second follows from its bottom two columns (product2 above)
+    const uint32_t q0 = uni((uint32_t)c0) & LMASK;
+    const uint32_t t = uni((uint32_t)c1 + (uint32_t)(c0 >> LB));
+    const uint32_t q1 = (t + q0 * n1p) & LMASK;
+    if constexpr (CAPTURE) {
+      // (lane `row` of the pair takes the two digits: one SGPR operand and an inline-constant lane select each)
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(qa) : "s"(q0), "n"(row));
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(qb) : "s"(q1), "n"(row));
+    }
+    c0 += (uint64_t)N0 * q0;
+    c1 += (uint64_t)N1 * q0;
+    c1 += (uint64_t)N0 * q1;
+    // a lone wavefront pays for every instruction it issues: the limb mask is applied AFTER the DPP move, from a register the compiler cannot
+    // see through, so that (move, and) become one v_and_b32_dpp; the limb that arrives is the addend of the column's first multiply-add
+    {
+      const uint64_t v = c0;
+      c1 += v >> LB;
+#if ZKP_R2L5_FOLD
+      const uint64_t in = (uint64_t)(next_lane<RW>((uint32_t)v) & lm);
+      uint64_t sink;
+      asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(c0), "=s"(sink) : "v"(X1), "v"(b1), "v"(in));
+#else
+      c0 = (uint64_t)next_lane<RW>((uint32_t)v & LMASK);
+      c0 += (uint64_t)X1 * b1;
+#endif
+    }
+    c0 += (uint64_t)N1 * q1;
+    {
+      const uint64_t v = c1;
+      c0 += v >> LB;
+#if ZKP_R2L5_FOLD
+      c1 = (uint64_t)(next_lane<RW>((uint32_t)v) & lm);
+#else
+      c1 = (uint64_t)next_lane<RW>((uint32_t)v & LMASK);
+#endif
+    }
+  };
+  // 18 pairs of rows, fully unrolled (the lane selects are immediates; ~1100 instructions per variant)
+  static_for<RG / 2 / ZKP_R2L5_DEV_ROW_DIVISOR>([&](auto ic) {
+    constexpr int s = 2 * decltype(ic)::value;
+    const uint4 cur = nx;
+    if constexpr (s + 2 < RG) nx = *reinterpret_cast<const uint4*>(ldsB + RW * (s + 2));
+    trip(cur.x, cur.y, std::integral_constant<int, s>{});
+    trip(cur.z, cur.w, std::integral_constant<int, s + 1>{});
+  });
+  uint64_t t0 = c0;
+  R[0] = (uint32_t)t0 & LMASK;
+  t0 = c1 + (t0 >> LB);
+  R[1] = (uint32_t)t0 & LMASK;
+  R[0] += prev_lane<RW>((uint32_t)(t0 >> LB), gl);
+  Qd[0] = qa; Qd[1] = qb;
+}
+}  // namespace r2l5
+
+__global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_t* __restrict__ bcst, uint32_t* __restrict__ raw) {
+  using namespace r2l5;
+  using BC = BnConst<8>;
+  constexpr int L = LIMBS, E = 2 * L;
+  if (!bcst[BC::OFF_OK]) return;
+  __shared__ __align__(16) uint32_t lds[LDS_WORDS];
+  __shared__ unsigned long long claim;
+  const int tid = threadIdx.x, lane = tid & 63, gl = lane;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool on = lane < RG;
+  auto area = [&](int i) -> uint32_t* { return lds + i * AW; };
+  const int kw = a.n_bits / 32;
+  const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
+  uint32_t NT[RW];
+  NT[0] = on ? bcst[BC::OFF_MT + RW * gl] : 0u;
+  NT[1] = on ? bcst[BC::OFF_MT + RW * gl + 1] : 0u;
+  const uint32_t n1 = bcst[BC::OFF_NI];
+  const uint32_t n1p = uni(NT[1]) + 1;
+  for (int w = tid; w < AW; w += 64 * WAVES) {
+    area(C3A)[w] = bcst[BC::OFF_C3 + w];
+    area(ONEA)[w] = bcst[BC::OFF_R1A + w];
+    area(ONEB)[w] = bcst[BC::OFF_R1B + w];
+    area(ZERO)[w] = 0;
+    area(INT1)[w] = w == 0 ? 1u : 0u;
+    area(NEXP)[w] = w < kw ? a.n[w] : 0u;
+  }
+  __syncthreads();
+  int t_bits = 0;
+  for (int w = kw - 1; w >= 0; w--) {
+    const uint32_t v = uni(area(NEXP)[w]);
+    if (v) { t_bits = w * 32 + (32 - __clz(v)); break; }
+  }
+  auto nbit = [&](int k) -> bool { return k >= 0 && k < t_bits && ((uni(area(NEXP)[k >> 5]) >> (k & 31)) & 1u); };
+  uint32_t C3r[RW], ONEr[RW];                          // C3 (B's and D's initial columns) and the Montgomery one (A hands it to C at a clear bit)
+  ld2(C3r, area(C3A), gl, on);
+  ld2(ONEr, area(ONEA), gl, on);
+  for (;;) {
+    __syncthreads();                                   // (the previous item's areas are free)
+    if (tid == 0) claim = atomicAdd(a.work_counter, 1ull);
+    __syncthreads();
+    const unsigned long long base = claim;
+    const uint64_t item = ((uint64_t)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
+    if (item >= count) break;
+    const BnItem it = bn_item(a, item, nullptr);
+    // ---- the item's r and m as limbs: r -> DA1 (B's multiplier of slot 0) and RL (A's register operand of slot -1); m -> MM
+    for (int w = tid; w < AW; w += 64 * WAVES) {
+      area(WBUF)[w] = (w < it.rw) ? it.pr[w] : 0u;
+      area(DUM0)[w] = (it.pm && w < it.mw) ? it.pm[w] : 0u;
+    }
+    __syncthreads();
+    if (tid < L) {
+      const int bit = tid * LB, w0 = bit >> 5, off = bit & 31;
+      const uint64_t xr = (uint64_t)area(WBUF)[w0] | ((uint64_t)area(WBUF)[w0 + 1] << 32);
+      const uint64_t xm = (uint64_t)area(DUM0)[w0] | ((uint64_t)area(DUM0)[w0 + 1] << 32);
+      const uint32_t lr = (uint32_t)(xr >> off) & LMASK, lm = (uint32_t)(xm >> off) & LMASK;
+      area(DA1)[tid] = lr; area(RL)[tid] = lr; area(MM)[tid] = lm;
+      area(SA1)[tid] = bcst[BC::OFF_RRA + tid];      // slot -1: A multiplies r by RR's a part (parity of -1: 1)
+      area(SB)[tid] = bcst[BC::OFF_RRB + tid];       // slot  0: B multiplies r by RR's b part
+    }
+    __syncthreads();
+    uint32_t Es[RW] = {0, 0};                          // E's product of the previous slot, until D's result of that slot can be added
+    bool pend = false;
+    bool b_prev = false, b_cur = false, b_next = nbit(0);      // bits k - 1, k, k + 1 of the exponent: one LDS read per slot, issued ahead of the product
+#pragma unroll 1
+    for (int k = -1; k <= t_bits + 2; k++) {
+      const int par = k & 1, prev = par ^ 1;
+#if ZKP_R2L5_REGS
+      const bool bit_prev = b_prev, bit_next = b_next;
+      b_prev = b_cur; b_cur = b_next; b_next = nbit(k + 2);
+#else
+      const bool bit_prev = nbit(k - 1), bit_next = nbit(k + 1);
+#endif
+      const bool fin1 = k == t_bits + 1, fin2 = k == t_bits + 2;
+      bool act = false, capture = false;
+      int xa = ZERO, ba = ZERO, qa = -1, d0 = -1;
+      if (role == 0) { act = k <= t_bits - 2; capture = true; xa = k < 0 ? (int)RL : SA0 + par; ba = SA0 + par; d0 = SA0 + prev; }
+      else if (role == 1) { act = k >= 0 && k <= t_bits - 1; xa = DA0 + prev; ba = SB; qa = SA0 + prev; d0 = SB; }
+      else if (role == 2) { act = (k >= 1 && k <= t_bits - 1) || fin1; capture = true; xa = fin1 ? (int)INT1 : PC0 + par; ba = fin1 ? (int)PX : SC0 + par; d0 = fin1 ? -1 : PC0 + prev; }
+      else if (role == 3) { act = (k >= 2 && k <= t_bits) || fin2; xa = fin2 ? (int)INT1 : PC0 + prev; ba = fin2 ? (int)QQ : (bit_prev ? (int)SB : (int)ONEB); qa = fin2 ? (int)PX : SC0 + prev; d0 = RD; }
+      else { act = (k >= 2 && k <= t_bits) || fin1; xa = fin1 ? (int)MM : (int)QQ; ba = fin1 ? (int)SE0 + (t_bits & 1) : (bit_prev ? SE0 + prev : (int)ONEA); d0 = fin1 ? (int)UU : -1; }
+      uint32_t X[RW], R[RW] = {0, 0}, Qd[RW] = {0, 0};
+      if (role == 4 && pend) {                         // q_(k-1) = D + E of the previous slot (RD is D's until the stores of this slot)
+        uint32_t D[RW];
+        ld2(D, area(RD), gl, on);
+        add<RW>(Es, Es, D, gl);
+        st2(area(QQ), Es, gl, on);
+        pend = false;
+      }
+      if (act) {
+        if (role == 4 && !fin1 && k > 2) { X[0] = on ? Es[0] : 0u; X[1] = on ? Es[1] : 0u; }
+        else ld2(X, area(xa), gl, on);
+        uint64_t c[RW];
+        {
+          uint32_t Q[RW], C3[RW];
+          ld2(Q, area(qa < 0 ? (int)ZERO : qa), gl, on);
+#if ZKP_R2L5_REGS
+          C3[0] = qa < 0 ? 0u : C3r[0]; C3[1] = qa < 0 ? 0u : C3r[1];
+#else
+          ld2(C3, area(qa < 0 ? (int)ZERO : (int)C3A), gl, on);
+#endif
+          const uint32_t n1e = (qa < 0 || !on) ? 0u : n1;
+#pragma unroll
+          for (int i = 0; i < RW; i++) c[i] = (uint64_t)C3[i] + (uint64_t)((1u << LB) - Q[i]) * n1e;
+        }
+        if (capture) product<true>(R, Qd, X, area(ba), NT, c, n1p, gl);
+        else product<false>(R, Qd, X, area(ba), NT, c, n1p, gl);
+      }
+      slot_barrier();                                  // every product of the slot has read what it reads
+      if (act) {
+        if (capture) st2(area(ba), Qd, gl, on);        // the digits over the staged operand, where B / D look for them one slot later
+        if (d0 >= 0) st2(area(d0), R, gl, on);
+        if (role == 0) {
+          st2(area(SE0 + prev), R, gl, on);
+          uint32_t T[RW];
+          if (bit_next) { T[0] = R[0]; T[1] = R[1]; }
+#if ZKP_R2L5_REGS
+          else { T[0] = ONEr[0]; T[1] = ONEr[1]; }
+#else
+          else ld2(T, area(ONEA), gl, on);
+#endif
+          st2(area(SC0 + prev), T, gl, on);            // C's multiplier of the next slot: a_(k+1), or the Montgomery one
+          if (k < 0) st2(area(PC0 + par), R, gl, on);  // the accumulator starts as s_0: p_1 = a_0 (n is odd), read by C in slot 1
+          T[0] = R[0]; T[1] = R[1];
+          dbl<RW>(T, gl);
+          st2(area(DA0 + prev), T, gl, on);
+        }
+        if (role == 1 && k == 0) st2(area(QQ), R, gl, on);          // q_1 = b_0
+        if (role == 2) {
+          if (fin1) { if (on) { raw[item * E + RW * gl] = R[0]; raw[item * E + RW * gl + 1] = R[1]; } }
+          else st2(area(PX), R, gl, on);
+        }
+        if (role == 3 && fin2) {
+          uint32_t U[RW];
+          ld2(U, area(UU), gl, on);
+          add<RW>(R, R, U, gl);
+          if (on) { raw[item * E + L + RW * gl] = R[0]; raw[item * E + L + RW * gl + 1] = R[1]; }
+        }
+        if (role == 4 && !fin1) { Es[0] = R[0]; Es[1] = R[1]; pend = true; }
+      }
+      if (role == 2 && k == t_bits) {                  // p_t once more, for E's product by m in the next slot (C stages PX itself there)
+        uint32_t T[RW];
+        ld2(T, area(PX), gl, on);
+        st2(area(SE0 + (t_bits & 1)), T, gl, on);
+      }
+      slot_barrier();                                  // ... and every store of the slot is in place
     }
   }
 }

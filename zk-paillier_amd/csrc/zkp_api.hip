@@ -24,6 +24,10 @@
 #if ZKP_W == 36 || ZKP_W == 18 || ZKP_W == 9
 #define ZKP_HAS_BASEN 1
 #include "kernels_basen.hpp"
+#ifndef ZKP_R2L5_ITEMS_PER_CU
+#define ZKP_R2L5_ITEMS_PER_CU 1ull      /* launches of up to this many Enc per compute unit take five wavefronts per Enc (k_enc_basen_r2l5): one proof 14.4 / 10.4 -> 12.4 / 8.3 ms;
+                                           two proofs (two workgroups per CU) 16.1 / 12.0 against 15.4 / 11.3 on one wavefront per Enc (profiles/r05/r2l5/) */
+#endif
 #include "kernels_basen_r2l.hpp"      // (W = 9 only: one Enc per wavefront, the five-group right-to-left ladder of calls of a few proofs)          // the Paillier kernels in base-n form: 2 / 4 lanes per n-sized integer in the throughput engine (W = 36), 8 / 16 in the latency engine (W = 9)
 #else
 #define ZKP_HAS_BASEN 0
@@ -88,7 +92,9 @@ struct zkp_ctx {
   int bn_last_g = 0;                   // lanes per n-sized integer of the most recent base-n launch (0: none yet)
   bool bn_last_per_key = false;        // ... and whether it ran under per-proof keys
   bool bn_last_r2l = false;            // ... and whether it was the one-Enc-per-wavefront ladder of the latency engine (kernels_basen_r2l.hpp)
-  int bn_r2l_lanes = 12;               // ... its lane geometry: 12 lanes x 6 limbs per n-sized integer, or 8 x 9 ($ZKP_R2L_LANES at ctx create)
+  int bn_r2l_lanes = 0;                // ... its lane geometry: 0 = the library's rule (five wavefronts of 36 lanes x 2 limbs per Enc while every Enc finds a CU's worth of
+                                       // SIMDs, else one wavefront of five groups of 12 lanes x 6 limbs); 36 / 12 / 8 (x 9 limbs) pin one ($ZKP_R2L_LANES at ctx create, zkp_diag_set_r2l_lanes)
+  int bn_last_r2l_lanes = 0;           // ... and the geometry the most recent such launch ran on
   int bn_r2l = 1;                      // that ladder: 0 = never, 1 = the library's rule (launches of up to two wavefronts per SIMD), 2 = whenever it can run (tests); $ZKP_R2L at ctx create
   DevBuf bn_flag;                      // device word: every key of the last batched base-n set-up qualified   // base-n form (kernels_basen.hpp): set-up record of n, its base-n constants, window tables, Mask-row products
   // timing of the dominant kernels
@@ -134,7 +140,7 @@ static int32_t zkp_caught(zkp_ctx* c, int32_t st, const char* what) noexcept {
   X(zkp_zero_proof_prove_batch) X(zkp_zero_proof_verify_batch) X(zkp_ciphertext_proof_prove_batch)                               \
   X(zkp_ciphertext_proof_verify_batch) X(zkp_verlin_proof_prove_batch) X(zkp_verlin_proof_verify_batch)                          \
   X(zkp_mul_proof_prove_batch) X(zkp_mul_proof_verify_batch) X(zkp_correct_message_prove_batch) X(zkp_correct_message_verify_batch)           \
-  X(zkp_diag_basen) X(zkp_diag_basen_last) X(zkp_diag_set_enc_form) X(zkp_diag_set_r2l) X(zkp_diag_r2l_last) X(zkp_diag_set_key_cache) X(zkp_diag_key_cache_state)
+  X(zkp_diag_basen) X(zkp_diag_basen_last) X(zkp_diag_set_enc_form) X(zkp_diag_set_r2l) X(zkp_diag_r2l_last) X(zkp_diag_set_r2l_lanes) X(zkp_diag_r2l_lanes_last) X(zkp_diag_set_key_cache) X(zkp_diag_key_cache_state)
 
 struct LatEngine {
   void* handle = nullptr;
@@ -703,8 +709,13 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
     if (r2l_launch) {
       if constexpr (G == 8) {
         const unsigned waves = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(a.count, 8ull * 4 * (uint64_t)c->cus));
-        // five groups of 12 lanes x 6 limbs (the default), or of 8 lanes x 9 limbs ($ZKP_R2L_LANES=8: A/B runs)
-        if (c->bn_r2l_lanes == 8) hipLaunchKernelGGL(k_enc_basen_r2l<9>, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
+        // five wavefronts per Enc (36 lanes x 2 limbs each, k_enc_basen_r2l5) while the launch leaves a CU to every Enc: one proof;
+        // one wavefront of five groups of 12 lanes x 6 limbs beyond; 8 lanes x 9 limbs only when pinned (A/B runs)
+        const int lanes = c->bn_r2l_lanes ? c->bn_r2l_lanes : (a.count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus ? 36 : 12);
+        c->bn_last_r2l_lanes = lanes;
+        if (lanes == 36) hipLaunchKernelGGL(k_enc_basen_r2l5, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(a.count, 4ull * (uint64_t)c->cus))), dim3(320), 0, c->stream, a,
+                                            (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
+        else if (lanes == 8) hipLaunchKernelGGL(k_enc_basen_r2l<9>, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
         else hipLaunchKernelGGL(k_enc_basen_r2l<6>, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
       }
     } else
@@ -761,7 +772,7 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
   if (const char* kc = std::getenv("ZKP_KEY_CACHE")) c->key_cache = std::atoi(kc) != 0;
   if (const char* sp = std::getenv("ZKP_SPLIT")) c->split_calls = std::atoi(sp) != 0;
   if (const char* rl = std::getenv("ZKP_R2L")) c->bn_r2l = std::atoi(rl);
-  if (const char* rl = std::getenv("ZKP_R2L_LANES")) c->bn_r2l_lanes = std::atoi(rl) == 8 ? 8 : 12;
+  if (const char* rl = std::getenv("ZKP_R2L_LANES")) { const int v = std::atoi(rl); c->bn_r2l_lanes = (v == 8 || v == 12 || v == 36) ? v : 0; }
   c->owns_stream = own_stream;
   c->stream = stream;
   if (own_stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKP_EDEVICE; }
@@ -949,6 +960,22 @@ extern "C" int32_t zkp_diag_set_r2l(zkp_ctx* c, int32_t mode) try {
 #endif
   return ZKP_OK;
 } ZKP_CATCH(c)
+// ... and its lane geometry: 0 = the library's rule, 36 = five wavefronts per Enc, 12 / 8 = one wavefront of five 12- / 8-lane groups
+extern "C" int32_t zkp_diag_set_r2l_lanes(zkp_ctx* c, int32_t lanes) try {
+  if (!c || (lanes != 0 && lanes != 8 && lanes != 12 && lanes != 36)) return ZKP_EINVAL;
+  c->bn_r2l_lanes = lanes;
+#ifndef ZKP_SECONDARY_ENGINE
+  for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_diag_set_r2l_lanes(c->eng_ctx[k], lanes);
+#endif
+  return ZKP_OK;
+} ZKP_CATCH(c)
+extern "C" int32_t zkp_diag_r2l_lanes_last(zkp_ctx* c) {
+  if (!c) return -1;
+#ifndef ZKP_SECONDARY_ENGINE
+  if (c->lat_ctx && c->last_geometry == c->lat->limbs_per_lane) return c->lat->p_zkp_diag_r2l_lanes_last(c->lat_ctx);
+#endif
+  return (c->bn_last_g && c->bn_last_r2l) ? c->bn_last_r2l_lanes : 0;
+}
 // the per-key constants kept across calls (setup_tag): on / off for this ctx and its secondary engines
 extern "C" int32_t zkp_diag_set_key_cache(zkp_ctx* c, int32_t on) try {
   if (!c) return ZKP_EINVAL;
