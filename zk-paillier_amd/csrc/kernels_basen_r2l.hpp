@@ -399,6 +399,9 @@ __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t*
 #ifndef ZKP_R2L5_FOLD
 #define ZKP_R2L5_FOLD 1      /* v_and_b32_dpp and the shifted-in limb as a multiply-add's addend: A/B switch (profiles/r05/r2l5/) */
 #endif
+#ifndef ZKP_R2L5_VALU_DIGITS
+#define ZKP_R2L5_VALU_DIGITS 1      /* the quotient digits' arithmetic on the vector side (no scalar instruction between v_readfirstlane and its multiply-add): A/B switch */
+#endif
 #ifndef ZKP_R2L5_REGS
 #define ZKP_R2L5_REGS 1      /* per-role constants in registers, one exponent-bit read per slot: A/B switch */
 #endif
@@ -439,6 +442,10 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
   uint32_t lm;
   asm("v_mov_b32 %0, 0x1fffffff" : "=v"(lm));
 #endif
+#if ZKP_R2L5_VALU_DIGITS
+  uint32_t vmask;                                      // (a register the compiler cannot see through: it would move the mask behind the v_readfirstlane, onto the scalar unit)
+  asm("v_mov_b32 %0, 0x1fffffff" : "=v"(vmask));
+#endif
   uint4 nx = *reinterpret_cast<const uint4*>(ldsB);
   auto trip = [&](uint32_t b0, uint32_t b1, auto rowc) {
     constexpr int row = decltype(rowc)::value;
@@ -446,9 +453,17 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
     c1 += (uint64_t)X1 * b0;
     c1 += (uint64_t)X0 * b1;
     // M~ == -1 (mod 2^29): the first digit is lane 0's bottom limb, the second follows from its bottom two columns (product2 above)
+#if ZKP_R2L5_VALU_DIGITS
+    // all of the digit arithmetic on the vector side, one v_readfirstlane per digit and nothing scalar in between: a scalar instruction between
+    // a v_readfirstlane and the multiply-add that takes its result costs a lone wavefront 7 ns (csrc/microbench/lone_wave_hops.hip)
+    const uint32_t q0v = (uint32_t)c0 & vmask;
+    const uint32_t q0 = uni(q0v);
+    const uint32_t q1 = uni(((uint32_t)(c1 + (uint64_t)q0v * n1p) + (uint32_t)(c0 >> LB)) & vmask);
+#else
     const uint32_t q0 = uni((uint32_t)c0) & LMASK;
     const uint32_t t = uni((uint32_t)c1 + (uint32_t)(c0 >> LB));
     const uint32_t q1 = (t + q0 * n1p) & LMASK;
+#endif
     if constexpr (CAPTURE) {
       // (lane `row` of the pair takes the two digits: one SGPR operand and an inline-constant lane select each)
       asm("v_writelane_b32 %0, %1, %2" : "+v"(qa) : "s"(q0), "n"(row));
