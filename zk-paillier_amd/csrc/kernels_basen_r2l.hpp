@@ -402,6 +402,9 @@ __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t*
 #ifndef ZKP_R2L5_VALU_DIGITS
 #define ZKP_R2L5_VALU_DIGITS 1      /* the quotient digits' arithmetic on the vector side (no scalar instruction between v_readfirstlane and its multiply-add): A/B switch */
 #endif
+#ifndef ZKP_R2L5_ROLE_LOOPS
+#define ZKP_R2L5_ROLE_LOOPS 1      /* the slot loop instantiated per role: A/B switch */
+#endif
 #ifndef ZKP_R2L5_REGS
 #define ZKP_R2L5_REGS 1      /* per-role constants in registers, one exponent-bit read per slot: A/B switch */
 #endif
@@ -522,7 +525,7 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
   __shared__ __align__(16) uint32_t lds[LDS_WORDS];
   __shared__ unsigned long long claim;
   const int tid = threadIdx.x, lane = tid & 63, gl = lane;
-  const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role_rt = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool on = lane < RG;
   auto area = [&](int i) -> uint32_t* { return lds + i * AW; };
   const int kw = a.n_bits / 32;
@@ -574,6 +577,14 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
       area(SB)[tid] = bcst[BC::OFF_RRB + tid];       // slot  0: B multiplies r by RR's b part
     }
     __syncthreads();
+    // the slots, once per role: the compiler sees which areas a role reads and writes and which product (with or without digit capture) it runs
+    // (one loop for all five — the role a run-time value — spent ~0.2 us per slot on selecting them: ZKP_R2L5_ROLE_LOOPS=0, profiles/r05/r2l5/)
+    auto slots = [&](auto rolec) {
+#if ZKP_R2L5_ROLE_LOOPS
+    constexpr int role = decltype(rolec)::value;
+#else
+    const int role = role_rt;
+#endif
     uint32_t Es[RW] = {0, 0};                          // E's product of the previous slot, until D's result of that slot can be added
     bool pend = false;
     bool b_prev = false, b_cur = false, b_next = nbit(0);      // bits k - 1, k, k + 1 of the exponent: one LDS read per slot, issued ahead of the product
@@ -660,6 +671,18 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
       }
       slot_barrier();                                  // ... and every store of the slot is in place
     }
+    };
+#if ZKP_R2L5_ROLE_LOOPS
+    switch (role_rt) {
+      case 0: slots(std::integral_constant<int, 0>{}); break;
+      case 1: slots(std::integral_constant<int, 1>{}); break;
+      case 2: slots(std::integral_constant<int, 2>{}); break;
+      case 3: slots(std::integral_constant<int, 3>{}); break;
+      default: slots(std::integral_constant<int, 4>{}); break;
+    }
+#else
+    slots(std::integral_constant<int, -1>{});
+#endif
   }
 }
 
