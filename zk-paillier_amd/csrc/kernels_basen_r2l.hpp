@@ -402,6 +402,9 @@ __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t*
 #ifndef ZKP_R2L5_VALU_DIGITS
 #define ZKP_R2L5_VALU_DIGITS 1      /* the quotient digits' arithmetic on the vector side (no scalar instruction between v_readfirstlane and its multiply-add): A/B switch */
 #endif
+#ifndef ZKP_R2L5_ASM_MADS
+#define ZKP_R2L5_ASM_MADS 1      /* every multiply-add as the instruction on its own accumulator (needs FOLD and VALU_DIGITS): A/B switch */
+#endif
 #ifndef ZKP_R2L5_ROLE_LOOPS
 #define ZKP_R2L5_ROLE_LOOPS 1      /* the slot loop instantiated per role: A/B switch */
 #endif
@@ -450,6 +453,42 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
   asm("v_mov_b32 %0, 0x1fffffff" : "=v"(vmask));
 #endif
   uint4 nx = *reinterpret_cast<const uint4*>(ldsB);
+#if ZKP_R2L5_ASM_MADS
+  // Every multiply-add written as the instruction on ITS accumulator: left to itself the compiler opens side sums (v_mad ... , 0) to shorten
+  // dependency chains and merges them with two more 64-bit adds per pair of sub-steps — a lone wavefront is bound by what it gets issued,
+  // not by those chains (a dependent multiply-add costs it the 4.8 ns an independent one does).
+  auto madv = [](uint64_t& c, uint32_t a, uint32_t b) { uint64_t sink; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(c), "=s"(sink) : "v"(a), "v"(b)); };
+  auto mads = [](uint64_t& c, uint32_t a, uint32_t q) { uint64_t sink; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(c), "=s"(sink) : "v"(a), "s"(q)); };
+  // (a column that opens — the limb shifted in from the neighbour lane, upper word zero — is the ADDEND of its first multiply-add: no copy)
+  auto mad3 = [](uint32_t a, uint32_t b, uint64_t in) { uint64_t c, sink; asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(c), "=s"(sink) : "v"(a), "v"(b), "v"(in)); return c; };
+  auto trip = [&](uint32_t b0, uint32_t b1, auto rowc) {
+    constexpr int row = decltype(rowc)::value;
+    madv(c0, X0, b0);
+    c1 = mad3(X1, b0, c1);
+    madv(c1, X0, b1);
+    const uint32_t q0v = (uint32_t)c0 & vmask;
+    const uint32_t q0 = uni(q0v);
+    const uint32_t q1 = uni(((uint32_t)c1 + q0v * n1p + (uint32_t)(c0 >> LB)) & vmask);
+    if constexpr (CAPTURE) {
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(qa) : "s"(q0), "n"(row));
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(qb) : "s"(q1), "n"(row));
+    }
+    mads(c0, N0, q0);
+    mads(c1, N1, q0);
+    mads(c1, N0, q1);
+    {
+      const uint64_t v = c0;
+      c1 += v >> LB;
+      c0 = mad3(X1, b1, (uint64_t)(next_lane<RW>((uint32_t)v) & lm));
+    }
+    mads(c0, N1, q1);
+    {
+      const uint64_t v = c1;
+      c0 += v >> LB;
+      c1 = (uint64_t)(next_lane<RW>((uint32_t)v) & lm);
+    }
+  };
+#else
   auto trip = [&](uint32_t b0, uint32_t b1, auto rowc) {
     constexpr int row = decltype(rowc)::value;
     c0 += (uint64_t)X0 * b0;
@@ -500,6 +539,7 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
 #endif
     }
   };
+#endif
   // 18 pairs of rows, fully unrolled (the lane selects are immediates; ~1100 instructions per variant)
   static_for<RG / 2 / ZKP_R2L5_DEV_ROW_DIVISOR>([&](auto ic) {
     constexpr int s = 2 * decltype(ic)::value;
