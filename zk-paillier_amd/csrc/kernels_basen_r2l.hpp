@@ -405,6 +405,9 @@ __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t*
 #ifndef ZKP_R2L5_ASM_MADS
 #define ZKP_R2L5_ASM_MADS 1      /* every multiply-add as the instruction on its own accumulator (needs FOLD and VALU_DIGITS): A/B switch */
 #endif
+#ifndef ZKP_R2L5_ONE_DIGIT
+#define ZKP_R2L5_ONE_DIGIT 1      /* one quotient digit per sub-step (18 instead of 21 instructions per pair): A/B switch */
+#endif
 #ifndef ZKP_R2L5_ROLE_LOOPS
 #define ZKP_R2L5_ROLE_LOOPS 1      /* the slot loop instantiated per role: A/B switch */
 #endif
@@ -540,6 +543,39 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
     }
   };
 #endif
+#if ZKP_R2L5_ONE_DIGIT && ZKP_R2L5_ASM_MADS
+  // One quotient digit per sub-step after all: the two-digit form exists to save a trip through the LDS crossbar, and here a digit is a
+  // v_readfirstlane away.  Taken one at a time the second digit needs no arithmetic of its own — it is the low limb of the next bottom
+  // column once the first digit's carry is in — 18 instead of 21 instructions per pair of sub-steps for a wavefront that is bound by
+  // what it gets issued.  Same digits, same values (`product` above).  The window of a lane: `bot` (column t) and the column that opens
+  // with the limb shifted in from the neighbour lane, `in` — the addend of its first multiply-add.
+  uint64_t bot = c0, in = c1;
+  auto step = [&](uint32_t b, auto tc) {
+    constexpr int t = decltype(tc)::value;
+    madv(bot, X0, b);
+    uint64_t top = mad3(X1, b, in);
+    const uint32_t q = uni((uint32_t)bot & vmask);
+    if constexpr (CAPTURE) {
+      if constexpr ((t & 1) == 0) asm("v_writelane_b32 %0, %1, %2" : "+v"(qa) : "s"(q), "n"(t / 2));
+      else asm("v_writelane_b32 %0, %1, %2" : "+v"(qb) : "s"(q), "n"(t / 2));
+    }
+    mads(bot, N0, q);
+    mads(top, N1, q);
+    top += bot >> LB;
+    in = (uint64_t)(next_lane<RW>((uint32_t)bot) & lm);
+    bot = top;
+  };
+  static_for<RG / 2 / ZKP_R2L5_DEV_ROW_DIVISOR>([&](auto ic) {
+    constexpr int s = 2 * decltype(ic)::value;
+    const uint4 cur = nx;
+    if constexpr (s + 2 < RG) nx = *reinterpret_cast<const uint4*>(ldsB + RW * (s + 2));
+    step(cur.x, std::integral_constant<int, 2 * s>{});
+    step(cur.y, std::integral_constant<int, 2 * s + 1>{});
+    step(cur.z, std::integral_constant<int, 2 * s + 2>{});
+    step(cur.w, std::integral_constant<int, 2 * s + 3>{});
+  });
+  c0 = bot; c1 = in;
+#else
   // 18 pairs of rows, fully unrolled (the lane selects are immediates; ~1100 instructions per variant)
   static_for<RG / 2 / ZKP_R2L5_DEV_ROW_DIVISOR>([&](auto ic) {
     constexpr int s = 2 * decltype(ic)::value;
@@ -548,6 +584,7 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
     trip(cur.x, cur.y, std::integral_constant<int, s>{});
     trip(cur.z, cur.w, std::integral_constant<int, s + 1>{});
   });
+#endif
   uint64_t t0 = c0;
   R[0] = (uint32_t)t0 & LMASK;
   t0 = c1 + (t0 >> LB);
