@@ -425,16 +425,19 @@ using namespace r2l;
 __device__ __forceinline__ void slot_barrier() {
   if constexpr (ZKP_R2L5_DEV_NO_BARRIERS) wave_lds_fence(); else __syncthreads();
 }
-constexpr int RW = 2, RG = LIMBS / RW, AW = LIMBS, WAVES = 5;
+// An area is the 72 limbs of an integer, limb-linear, plus 8 words that stay ZERO: lanes 36 - 63 of a wavefront hold zeros (the top lane's
+// neighbour must), and instead of masking them out of every load and store — an execution-mask region each, ~0.1 us per slot — they all
+// read and write word 72 of the same area: they load zeros, compute zeros, store zeros (`lw`, the lane's word offset; carries between
+// lanes take such a lane for lane 0 of a group: `gle`).
+constexpr int RW = 2, RG = LIMBS / RW, AW = LIMBS + 8, WAVES = 5;
 constexpr int NEXP = NAREAS;                 // one more area: the exponent's words (the key), read bit by bit
 constexpr int LDS_WORDS = (NAREAS + 1) * AW + 8;
 
-__device__ __forceinline__ void ld2(uint32_t (&v)[RW], const uint32_t* area, int gl, bool on) {
-  if (on) { const uint2 t = *reinterpret_cast<const uint2*>(area + RW * gl); v[0] = t.x; v[1] = t.y; }
-  else { v[0] = 0; v[1] = 0; }
+__device__ __forceinline__ void ld2(uint32_t (&v)[RW], const uint32_t* area, int lw) {
+  const uint2 t = *reinterpret_cast<const uint2*>(area + lw); v[0] = t.x; v[1] = t.y;
 }
-__device__ __forceinline__ void st2(uint32_t* area, const uint32_t (&v)[RW], int gl, bool on) {
-  if (on) *reinterpret_cast<uint2*>(area + RW * gl) = make_uint2(v[0], v[1]);
+__device__ __forceinline__ void st2(uint32_t* area, const uint32_t (&v)[RW], int lw) {
+  *reinterpret_cast<uint2*>(area + lw) = make_uint2(v[0], v[1]);
 }
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
@@ -604,6 +607,7 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
   const int tid = threadIdx.x, lane = tid & 63, gl = lane;
   const int role_rt = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool on = lane < RG;
+  const int lw = on ? RW * gl : LIMBS, gle = on ? gl : 0;
   auto area = [&](int i) -> uint32_t* { return lds + i * AW; };
   const int kw = a.n_bits / 32;
   const uint64_t count = a.count_ptr ? (uint64_t)*a.count_ptr : a.count;
@@ -612,7 +616,9 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
   NT[1] = on ? bcst[BC::OFF_MT + RW * gl + 1] : 0u;
   const uint32_t n1 = bcst[BC::OFF_NI];
   const uint32_t n1p = uni(NT[1]) + 1;
-  for (int w = tid; w < AW; w += 64 * WAVES) {
+  for (int w = tid; w < LDS_WORDS; w += 64 * WAVES) lds[w] = 0;
+  __syncthreads();
+  for (int w = tid; w < LIMBS; w += 64 * WAVES) {
     area(C3A)[w] = bcst[BC::OFF_C3 + w];
     area(ONEA)[w] = bcst[BC::OFF_R1A + w];
     area(ONEB)[w] = bcst[BC::OFF_R1B + w];
@@ -626,10 +632,17 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
     const uint32_t v = uni(area(NEXP)[w]);
     if (v) { t_bits = w * 32 + (32 - __clz(v)); break; }
   }
-  auto nbit = [&](int k) -> bool { return k >= 0 && k < t_bits && ((uni(area(NEXP)[k >> 5]) >> (k & 31)) & 1u); };
+  // bit k of the exponent out of a 32-bit window in a scalar register (one LDS read every 32 slots)
+  int ew_at = -1;
+  uint32_t ew = 0;
+  auto nbit = [&](int k) -> bool {
+    if (k < 0 || k >= t_bits) return false;
+    if ((k >> 5) != ew_at) { ew_at = k >> 5; ew = uni(area(NEXP)[ew_at]); }
+    return ((ew >> (k & 31)) & 1u) != 0;
+  };
   uint32_t C3r[RW], ONEr[RW];                          // C3 (B's and D's initial columns) and the Montgomery one (A hands it to C at a clear bit)
-  ld2(C3r, area(C3A), gl, on);
-  ld2(ONEr, area(ONEA), gl, on);
+  ld2(C3r, area(C3A), lw);
+  ld2(ONEr, area(ONEA), lw);
   for (;;) {
     __syncthreads();                                   // (the previous item's areas are free)
     if (tid == 0) claim = atomicAdd(a.work_counter, 1ull);
@@ -639,7 +652,7 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
     if (item >= count) break;
     const BnItem it = bn_item(a, item, nullptr);
     // ---- the item's r and m as limbs: r -> DA1 (B's multiplier of slot 0) and RL (A's register operand of slot -1); m -> MM
-    for (int w = tid; w < AW; w += 64 * WAVES) {
+    for (int w = tid; w < LIMBS; w += 64 * WAVES) {
       area(WBUF)[w] = (w < it.rw) ? it.pr[w] : 0u;
       area(DUM0)[w] = (it.pm && w < it.mw) ? it.pm[w] : 0u;
     }
@@ -685,66 +698,66 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
       uint32_t X[RW], R[RW] = {0, 0}, Qd[RW] = {0, 0};
       if (role == 4 && pend) {                         // q_(k-1) = D + E of the previous slot (RD is D's until the stores of this slot)
         uint32_t D[RW];
-        ld2(D, area(RD), gl, on);
-        add<RW>(Es, Es, D, gl);
-        st2(area(QQ), Es, gl, on);
+        ld2(D, area(RD), lw);
+        add<RW>(Es, Es, D, gle);
+        st2(area(QQ), Es, lw);
         pend = false;
       }
       if (act) {
-        if (role == 4 && !fin1 && k > 2) { X[0] = on ? Es[0] : 0u; X[1] = on ? Es[1] : 0u; }
-        else ld2(X, area(xa), gl, on);
+        if (role == 4 && !fin1 && k > 2) { X[0] = Es[0]; X[1] = Es[1]; }
+        else ld2(X, area(xa), lw);
         uint64_t c[RW];
         {
           uint32_t Q[RW], C3[RW];
-          ld2(Q, area(qa < 0 ? (int)ZERO : qa), gl, on);
+          ld2(Q, area(qa < 0 ? (int)ZERO : qa), lw);
 #if ZKP_R2L5_REGS
           C3[0] = qa < 0 ? 0u : C3r[0]; C3[1] = qa < 0 ? 0u : C3r[1];
 #else
-          ld2(C3, area(qa < 0 ? (int)ZERO : (int)C3A), gl, on);
+          ld2(C3, area(qa < 0 ? (int)ZERO : (int)C3A), lw);
 #endif
           const uint32_t n1e = (qa < 0 || !on) ? 0u : n1;
 #pragma unroll
           for (int i = 0; i < RW; i++) c[i] = (uint64_t)C3[i] + (uint64_t)((1u << LB) - Q[i]) * n1e;
         }
-        if (capture) product<true>(R, Qd, X, area(ba), NT, c, n1p, gl);
-        else product<false>(R, Qd, X, area(ba), NT, c, n1p, gl);
+        if (capture) product<true>(R, Qd, X, area(ba), NT, c, n1p, gle);
+        else product<false>(R, Qd, X, area(ba), NT, c, n1p, gle);
       }
       slot_barrier();                                  // every product of the slot has read what it reads
       if (act) {
-        if (capture) st2(area(ba), Qd, gl, on);        // the digits over the staged operand, where B / D look for them one slot later
-        if (d0 >= 0) st2(area(d0), R, gl, on);
+        if (capture) st2(area(ba), Qd, lw);        // the digits over the staged operand, where B / D look for them one slot later
+        if (d0 >= 0) st2(area(d0), R, lw);
         if (role == 0) {
-          st2(area(SE0 + prev), R, gl, on);
+          st2(area(SE0 + prev), R, lw);
           uint32_t T[RW];
           if (bit_next) { T[0] = R[0]; T[1] = R[1]; }
 #if ZKP_R2L5_REGS
           else { T[0] = ONEr[0]; T[1] = ONEr[1]; }
 #else
-          else ld2(T, area(ONEA), gl, on);
+          else ld2(T, area(ONEA), lw);
 #endif
-          st2(area(SC0 + prev), T, gl, on);            // C's multiplier of the next slot: a_(k+1), or the Montgomery one
-          if (k < 0) st2(area(PC0 + par), R, gl, on);  // the accumulator starts as s_0: p_1 = a_0 (n is odd), read by C in slot 1
+          st2(area(SC0 + prev), T, lw);            // C's multiplier of the next slot: a_(k+1), or the Montgomery one
+          if (k < 0) st2(area(PC0 + par), R, lw);  // the accumulator starts as s_0: p_1 = a_0 (n is odd), read by C in slot 1
           T[0] = R[0]; T[1] = R[1];
-          dbl<RW>(T, gl);
-          st2(area(DA0 + prev), T, gl, on);
+          dbl<RW>(T, gle);
+          st2(area(DA0 + prev), T, lw);
         }
-        if (role == 1 && k == 0) st2(area(QQ), R, gl, on);          // q_1 = b_0
+        if (role == 1 && k == 0) st2(area(QQ), R, lw);          // q_1 = b_0
         if (role == 2) {
           if (fin1) { if (on) { raw[item * E + RW * gl] = R[0]; raw[item * E + RW * gl + 1] = R[1]; } }
-          else st2(area(PX), R, gl, on);
+          else st2(area(PX), R, lw);
         }
         if (role == 3 && fin2) {
           uint32_t U[RW];
-          ld2(U, area(UU), gl, on);
-          add<RW>(R, R, U, gl);
+          ld2(U, area(UU), lw);
+          add<RW>(R, R, U, gle);
           if (on) { raw[item * E + L + RW * gl] = R[0]; raw[item * E + L + RW * gl + 1] = R[1]; }
         }
         if (role == 4 && !fin1) { Es[0] = R[0]; Es[1] = R[1]; pend = true; }
       }
       if (role == 2 && k == t_bits) {                  // p_t once more, for E's product by m in the next slot (C stages PX itself there)
         uint32_t T[RW];
-        ld2(T, area(PX), gl, on);
-        st2(area(SE0 + (t_bits & 1)), T, gl, on);
+        ld2(T, area(PX), lw);
+        st2(area(SE0 + (t_bits & 1)), T, lw);
       }
       slot_barrier();                                  // ... and every store of the slot is in place
     }
