@@ -21,5 +21,8 @@ json.dump({"kernel": "k_enc_basen<2>", "launch_ms_in_dispatch_order": rows,
           open("gpurun_out/${ROUND}_kernel_trace_k_enc_basen2_launches_$TAG.json", "w"), indent=1)
 PY
 find gpurun_out/prof_${ROUND}_$TAG -name "*kernel_trace.csv" -delete
-ROUND=$ROUND bash profiles/collect_all.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
-tail -6 gpurun_out/pmc_$TAG.log
+# (SKIP_PMC=1: the counter passes are left out — when the kernels they measure have not changed since the last collection)
+if [ -z "$SKIP_PMC" ]; then
+  ROUND=$ROUND bash profiles/collect_all.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
+  tail -6 gpurun_out/pmc_$TAG.log
+fi
