@@ -408,6 +408,9 @@ __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t*
 #ifndef ZKP_R2L5_ONE_DIGIT
 #define ZKP_R2L5_ONE_DIGIT 1      /* one quotient digit per sub-step (18 instead of 21 instructions per pair): A/B switch */
 #endif
+#ifndef ZKP_R2L5_PIN_ORDER
+#define ZKP_R2L5_PIN_ORDER 0      /* the instruction order of a sub-step pinned by hand (no consumer straight behind an asm producer, the DPP read third after its source): measured 4.6 % SLOWER than the scheduler's own order (profiles/r05/r2l5/ab_pinned_order.jsonl) — off */
+#endif
 #ifndef ZKP_R2L5_ROLE_LOOPS
 #define ZKP_R2L5_ROLE_LOOPS 1      /* the slot loop instantiated per role: A/B switch */
 #endif
@@ -462,7 +465,7 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
 #if ZKP_R2L5_ASM_MADS
   // Every multiply-add written as the instruction on ITS accumulator: left to itself the compiler opens side sums (v_mad ... , 0) to shorten
   // dependency chains and merges them with two more 64-bit adds per pair of sub-steps — a lone wavefront is bound by what it gets issued,
-  // not by those chains (a dependent multiply-add costs it the 4.8 ns an independent one does).
+  // not by those chains (a dependent multiply-add costs it the 2.1 ns an independent one does).
   auto madv = [](uint64_t& c, uint32_t a, uint32_t b) { uint64_t sink; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(c), "=s"(sink) : "v"(a), "v"(b)); };
   auto mads = [](uint64_t& c, uint32_t a, uint32_t q) { uint64_t sink; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(c), "=s"(sink) : "v"(a), "s"(q)); };
   // (a column that opens — the limb shifted in from the neighbour lane, upper word zero — is the ADDEND of its first multiply-add: no copy)
@@ -503,7 +506,7 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
     // M~ == -1 (mod 2^29): the first digit is lane 0's bottom limb, the second follows from its bottom two columns (product2 above)
 #if ZKP_R2L5_VALU_DIGITS
     // all of the digit arithmetic on the vector side, one v_readfirstlane per digit and nothing scalar in between: a scalar instruction between
-    // a v_readfirstlane and the multiply-add that takes its result costs a lone wavefront 7 ns (csrc/microbench/lone_wave_hops.hip)
+    // a v_readfirstlane and the multiply-add that takes its result costs a lone wavefront 7 - 8 ns (csrc/microbench/lone_wave_hops.hip)
     const uint32_t q0v = (uint32_t)c0 & vmask;
     const uint32_t q0 = uni(q0v);
     const uint32_t q1 = uni(((uint32_t)(c1 + (uint64_t)q0v * n1p) + (uint32_t)(c0 >> LB)) & vmask);
@@ -553,8 +556,32 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
   // what it gets issued.  Same digits, same values (`product` above).  The window of a lane: `bot` (column t) and the column that opens
   // with the limb shifted in from the neighbour lane, `in` — the addend of its first multiply-add.
   uint64_t bot = c0, in = c1;
+  // (ZKP_R2L5_PIN_ORDER, an experiment that stays off: a scheduling barrier behind every statement and an order in which no consumer follows
+  // an asm producer directly and the DPP read comes third after its source — the hazards that cost 5.5 s_nop per pair of sub-steps.  The
+  // wait states stay (asm statements do not count as such, v_readfirstlane wants one after its source, an SGPR two before a vector
+  // instruction reads it) and the scheduler's own order is 4.6 % faster.)
+  auto pin = [] { if constexpr (ZKP_R2L5_PIN_ORDER) __builtin_amdgcn_sched_barrier(0); };
   auto step = [&](uint32_t b, auto tc) {
     constexpr int t = decltype(tc)::value;
+#if ZKP_R2L5_PIN_ORDER
+    // (only the multiply-add that OPENS a column is written as the instruction — its addend is what the compiler would turn into a side
+    // sum —; it also fills the slot between the mask and the v_readfirstlane, which wants one instruction between it and its source)
+    bot += (uint64_t)X0 * b; pin();
+    const uint32_t qv = (uint32_t)bot & vmask; pin();
+    uint64_t top = mad3(X1, b, in); pin();
+    const uint32_t q = uni(qv); pin();
+    if constexpr (CAPTURE) {
+      if constexpr ((t & 1) == 0) asm("v_writelane_b32 %0, %1, %2" : "+v"(qa) : "s"(q), "n"(t / 2));
+      else asm("v_writelane_b32 %0, %1, %2" : "+v"(qb) : "s"(q), "n"(t / 2));
+      pin();
+    }
+    bot += (uint64_t)N0 * q; pin();
+    top += (uint64_t)N1 * q; pin();
+    const uint64_t cy = bot >> LB; pin();
+    in = (uint64_t)(next_lane<RW>((uint32_t)bot) & lm); pin();
+    top += cy; pin();
+    bot = top;
+#else
     madv(bot, X0, b);
     uint64_t top = mad3(X1, b, in);
     const uint32_t q = uni((uint32_t)bot & vmask);
@@ -567,6 +594,7 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
     top += bot >> LB;
     in = (uint64_t)(next_lane<RW>((uint32_t)bot) & lm);
     bot = top;
+#endif
   };
   static_for<RG / 2 / ZKP_R2L5_DEV_ROW_DIVISOR>([&](auto ic) {
     constexpr int s = 2 * decltype(ic)::value;
@@ -696,7 +724,7 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
       else if (role == 3) { act = (k >= 2 && k <= t_bits) || fin2; xa = fin2 ? (int)INT1 : PC0 + prev; ba = fin2 ? (int)QQ : (bit_prev ? (int)SB : (int)ONEB); qa = fin2 ? (int)PX : SC0 + prev; d0 = RD; }
       else { act = (k >= 2 && k <= t_bits) || fin1; xa = fin1 ? (int)MM : (int)QQ; ba = fin1 ? (int)SE0 + (t_bits & 1) : (bit_prev ? SE0 + prev : (int)ONEA); d0 = fin1 ? (int)UU : -1; }
       uint32_t X[RW], R[RW] = {0, 0}, Qd[RW] = {0, 0};
-      if (role == 4 && pend) {                         // q_(k-1) = D + E of the previous slot (RD is D's until the stores of this slot)
+      if (role == 4 && pend) {    // q_(k-1) = D + E of the previous slot (RD is D's until the stores of this slot)
         uint32_t D[RW];
         ld2(D, area(RD), lw);
         add<RW>(Es, Es, D, gle);
@@ -754,7 +782,7 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
         }
         if (role == 4 && !fin1) { Es[0] = R[0]; Es[1] = R[1]; pend = true; }
       }
-      if (role == 2 && k == t_bits) {                  // p_t once more, for E's product by m in the next slot (C stages PX itself there)
+      if (role == 2 && k == t_bits) {   // p_t once more, for E's product by m in the next slot (C stages PX itself there)
         uint32_t T[RW];
         ld2(T, area(PX), lw);
         st2(area(SE0 + (t_bits & 1)), T, lw);

@@ -22,8 +22,10 @@
                  : "=&v"(r) : "v"(a + threadIdx.x), "v"(b ^ threadIdx.x), "s"(iters) : CLOBBER);                          \
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                                                      \
   }
-#define X4(B) B B B B
-#define X8(B) X4(B) X4(B)
+#define Y4(B) B B B B
+#define Y8(B) Y4(B) Y4(B)
+#define X4(B) Y8(Y4(B))      /* 32 copies per loop iteration: the three scalar instructions of the loop are < 3 % of it */
+#define X8(B) Y8(Y8(B))      /* 64 copies */
 #define MADC "v_mad_u64_u32 v[10:11], vcc, v2, v3, v[10:11]\n"
 #define MADS "v_mad_u64_u32 v[10:11], vcc, v2, s21, v[10:11]\n"
 
@@ -63,19 +65,19 @@ int main(int argc, char** argv) {
   const int blocks = p.multiProcessorCount * per_cu;
   uint32_t* d; CHECK(hipMalloc(&d, (size_t)blocks * 64 * 4));
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  const int iters = argc > 3 ? atoi(argv[3]) : 1 << 19;
+  const int iters = argc > 3 ? atoi(argv[3]) : 1 << 16;
   struct { const char* name; void (*k)(uint32_t*, uint32_t, uint32_t, int); int units; const char* unit; } ks[] = {
-    {"8 dependent v_mad_u64_u32", k_mad_dep, 8, "multiply-add"}, {"8 v_mad_u64_u32 on two chains", k_mad_indep, 8, "multiply-add"},
-    {"8 dependent v_add_u32", k_add_dep, 8, "add"}, {"8 v_add_u32 on two chains", k_add_indep, 8, "add"}, {"16 v_add_u32 on four chains", k_add_indep4, 16, "add"},
-    {"8 dependent s_add_u32", k_salu_dep, 8, "s_add"},
-    {"4 x (multiply-add, independent add)", k_mad_add_mix, 4, "group"}, {"4 x (multiply-add, two independent adds)", k_mad_add2_mix, 4, "group"},
-    {"4 x (mad -> readfirstlane -> s_and -> mad with the SGPR)", k_hop_rfl_sand, 4, "group of 2 mads + hop"},
-    {"4 x (mad -> v_and -> readfirstlane -> mad with the SGPR)", k_hop_vand_rfl, 4, "group of 2 mads + hop"},
-    {"4 x (mad -> readfirstlane, mad', s_and, mad'' -> mad with the SGPR)", k_hop_rfl_sand_fill, 4, "group of 4 mads + hop"},
-    {"8 x (readfirstlane -> v_add reading the SGPR)", k_rfl_valu, 8, "pair"}, {"8 x (readfirstlane -> s_add -> v_add)", k_rfl_salu_valu, 8, "triple"},
-    {"8 x (readfirstlane -> s_mul, s_add, s_and -> v_add)", k_rfl_salu3_valu, 8, "group of 5"},
-    {"8 x (v_lshrrev_b64 -> v_lshl_add_u64)", k_carry, 8, "pair"}, {"8 x (v_add -> s_nop 1 -> v_and_b32_dpp)", k_and_dpp, 8, "pair"},
-    {"8 x (ds_bpermute -> wait -> v_add)", k_bpermute, 8, "pair"}, {"8 dependent v_mul_lo_u32", k_mul_lo_dep, 8, "multiply"}};
+    {"8 dependent v_mad_u64_u32", k_mad_dep, 64, "multiply-add"}, {"8 v_mad_u64_u32 on two chains", k_mad_indep, 64, "multiply-add"},
+    {"8 dependent v_add_u32", k_add_dep, 64, "add"}, {"8 v_add_u32 on two chains", k_add_indep, 64, "add"}, {"16 v_add_u32 on four chains", k_add_indep4, 128, "add"},
+    {"8 dependent s_add_u32", k_salu_dep, 64, "s_add"},
+    {"4 x (multiply-add, independent add)", k_mad_add_mix, 32, "group"}, {"4 x (multiply-add, two independent adds)", k_mad_add2_mix, 32, "group"},
+    {"4 x (mad -> readfirstlane -> s_and -> mad with the SGPR)", k_hop_rfl_sand, 32, "group of 2 mads + hop"},
+    {"4 x (mad -> v_and -> readfirstlane -> mad with the SGPR)", k_hop_vand_rfl, 32, "group of 2 mads + hop"},
+    {"4 x (mad -> readfirstlane, mad', s_and, mad'' -> mad with the SGPR)", k_hop_rfl_sand_fill, 32, "group of 4 mads + hop"},
+    {"8 x (readfirstlane -> v_add reading the SGPR)", k_rfl_valu, 64, "pair"}, {"8 x (readfirstlane -> s_add -> v_add)", k_rfl_salu_valu, 64, "triple"},
+    {"8 x (readfirstlane -> s_mul, s_add, s_and -> v_add)", k_rfl_salu3_valu, 64, "group of 5"},
+    {"8 x (v_lshrrev_b64 -> v_lshl_add_u64)", k_carry, 64, "pair"}, {"8 x (v_add -> s_nop 1 -> v_and_b32_dpp)", k_and_dpp, 64, "pair"},
+    {"8 x (ds_bpermute -> wait -> v_add)", k_bpermute, 64, "pair"}, {"8 dependent v_mul_lo_u32", k_mul_lo_dep, 64, "multiply"}};
   for (auto& k : ks) {
     float best = 1e9f;
     for (int rep = 0; rep < 3; rep++) {
