@@ -55,8 +55,8 @@ int32_t zkp_diag_last_host_blocks(zkp_ctx* ctx);
  * launch of the ctx ran on it. */
 int32_t zkp_diag_set_r2l(zkp_ctx* ctx, int32_t mode);
 /* The lane geometry of that ladder.  0 = the library's rule (the default): FIVE wavefronts per Enc — one per role, 36 lanes x 2 limbs per
- * n-sized integer, the quotient digits wave-uniform in scalar registers (k_enc_basen_r2l5) — while the launch has at most two Enc
- * per compute unit (one or two proofs), one wavefront of five groups of 12 lanes x 6 limbs beyond; 36 / 12 pin one of the two,
+ * n-sized integer, the quotient digits wave-uniform in scalar registers (k_enc_basen_r2l5) — while the launch leaves every Enc a
+ * compute unit of its own (one proof), one wavefront of five groups of 12 lanes x 6 limbs beyond; 36 / 12 pin one of the two,
  * 8 the 8-lane x 9-limb variant of the one-wavefront kernel (A/B runs).  $ZKP_R2L_LANES presets it at ctx create.
  * zkp_diag_r2l_lanes_last: the geometry of the most recent launch of the ladder (0: the most recent Paillier launch was not one). */
 int32_t zkp_diag_set_r2l_lanes(zkp_ctx* ctx, int32_t lanes);

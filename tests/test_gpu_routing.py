@@ -108,8 +108,8 @@ def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     assert family_that_ran(actx) == want, (B, family_that_ran(actx), want)
     if want == "split":
         assert actx.last_split() == expected_tail(B)
-    if want == "lat-r2l":                                    # up to two Enc per compute unit: five wavefronts per Enc (k_enc_basen_r2l5); beyond: one wavefront per Enc
-        assert actx.r2l_lanes_last() == (36 if 2 * 128 * B <= 2 * compute_units() else 12), (B, actx.r2l_lanes_last())
+    if want == "lat-r2l":                                    # one Enc per compute unit: five wavefronts per Enc (k_enc_basen_r2l5); beyond: one wavefront per Enc
+        assert actx.r2l_lanes_last() == (36 if 2 * 128 * B <= compute_units() else 12), (B, actx.r2l_lanes_last())
     assert not status.any()
     # the prove transcripts of a sample of the batch, byte for byte against the oracle
     idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1} & set(range(B)))

@@ -35,6 +35,10 @@ namespace zkp {
 
 #if ZKP_W == 9
 
+#ifndef ZKP_R2L_UNROLL_ROWS
+#define ZKP_R2L_UNROLL_ROWS 12      /* all of them: one 1024-Enc launch 10.70 (one row per iteration) -> 9.82 (3) -> 9.70 (4) -> 9.47 ms (profiles/r05/r2l5/ab_row_loop_unrolled_one_wavefront_kernel.jsonl) */
+#endif
+
 namespace r2l {
 // LDS areas of a wavefront (word offsets / AW)
 enum Area {
@@ -178,7 +182,9 @@ __device__ __forceinline__ void product2(uint32_t (&R)[RW], const uint32_t (&X)[
   static_assert((RW & 1) == 0, "pairs of sub-steps");
   using GM = Geom<RW>;
   const uint32_t n1p = NT[1] + 1;
-#pragma unroll 1
+  // (the rows of the staged operand: a taken branch costs a lone wavefront ~20 ns — csrc/microbench/lone_wave_hops.hip —, twelve of them 5 % of a
+  // product of 12 lanes x 6 limbs; ZKP_R2L_UNROLL_ROWS copies per loop iteration: A/B switch)
+#pragma unroll ZKP_R2L_UNROLL_ROWS
   for (int s = 0; s < GM::RG; s++) {
     uint32_t qd[4];
     const uint32_t row_addr = lds_byte_address(ldsB + s * GM::RBLK);

@@ -25,8 +25,9 @@
 #define ZKP_HAS_BASEN 1
 #include "kernels_basen.hpp"
 #ifndef ZKP_R2L5_ITEMS_PER_CU
-#define ZKP_R2L5_ITEMS_PER_CU 2ull      /* launches of up to this many Enc per compute unit take five wavefronts per Enc (k_enc_basen_r2l5): one proof 14.45 / 10.37 -> 10.23 / 5.98 ms,
-                                           two proofs (two workgroups per CU) 15.5 / 11.3 -> 13.9 / 9.7; three: 17.9 / 13.7 against 15.4 / 11.4 on one wavefront per Enc (profiles/r05/r2l5/) */
+#define ZKP_R2L5_ITEMS_PER_CU 1ull      /* launches of up to this many Enc per compute unit take five wavefronts per Enc (k_enc_basen_r2l5): one proof 13.3 / 9.3 -> 10.2 / 6.0 ms;
+                                           two proofs (two workgroups per CU) 13.8 / 9.6 against 13.9 / 9.7 on one wavefront per Enc, but the verify time is bimodal there (9.6 or 12.4 ms:
+                                           a transcript-hash wavefront that shares its SIMD with three others); three: 17.7 / 13.4 against 13.9 / 9.9 (profiles/r05/r2l5/) */
 #endif
 #include "kernels_basen_r2l.hpp"      // (W = 9 only: one Enc per wavefront, the five-group right-to-left ladder of calls of a few proofs)          // the Paillier kernels in base-n form: 2 / 4 lanes per n-sized integer in the throughput engine (W = 36), 8 / 16 in the latency engine (W = 9)
 #else
@@ -709,7 +710,7 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
     if (r2l_launch) {
       if constexpr (G == 8) {
         const unsigned waves = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(a.count, 8ull * 4 * (uint64_t)c->cus));
-        // five wavefronts per Enc (36 lanes x 2 limbs each, k_enc_basen_r2l5) while the launch has at most two Enc per CU: one or two proofs;
+        // five wavefronts per Enc (36 lanes x 2 limbs each, k_enc_basen_r2l5) while the launch leaves a CU to every Enc: one proof;
         // one wavefront of five groups of 12 lanes x 6 limbs beyond; 8 lanes x 9 limbs only when pinned (A/B runs)
         const int lanes = c->bn_r2l_lanes ? c->bn_r2l_lanes : (a.count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus ? 36 : 12);
         c->bn_last_r2l_lanes = lanes;
