@@ -24,6 +24,21 @@
 #pragma once
 #include "kernels_modexp.hpp"
 
+// rows of the staged operand per iteration of a product body's loop (A/B switch: a taken branch costs a LONE wavefront ~20 ns, csrc/microbench/lone_wave_hops.hip;
+// the throughput engine's bodies are three to a kernel and at the instruction cache's limit: one row per iteration there)
+// Latency engine (W = 9, calls of 21 ... 40 proofs at one to three wavefronts per SIMD): all rows — one 8192-Enc launch of k_enc_basen<8> (one wavefront per
+// SIMD) 27.28 -> 25.29 (2 rows) -> 24.21 (4) -> 23.29 ms (8), two wavefronts per SIMD 37.5 -> 35.8 (profiles/r05/r2l5/ab_row_loops_of_the_w9_base_n_kernels.jsonl)
+// (as _Pragma: a macro inside `#pragma unroll` survives -save-temps unexpanded and fails in the second pass)
+#define ZKP_UNROLL_STR(x) #x
+#define ZKP_UNROLL_(n) _Pragma(ZKP_UNROLL_STR(unroll n))
+#define ZKP_UNROLL(n) ZKP_UNROLL_(n)
+#ifndef ZKP_BN_ROW_UNROLL
+#if ZKP_W == 9
+#define ZKP_BN_ROW_UNROLL 8
+#else
+#define ZKP_BN_ROW_UNROLL 1
+#endif
+#endif
 namespace zkp {
 
 // ---- per-key constants (uint32 words in global memory), geometry G = lanes per n-sized integer
@@ -168,7 +183,7 @@ __device__ __forceinline__ void bn_core2(uint64_t (&c)[W], const uint32_t (&X)[W
   // c[col] += X[k] * (b | 2 b), or nothing: for a squaring the position pair (tt, k) decides at compile time (bigint29.hpp sqr_mult)
 #define ZKP_BN_P(tt, k, col, b1x, b2x) do { const int m_ = SQR ? sqr_mult((tt), (k)) : 1; if (m_ == 1) c[(col)] += (uint64_t)X[(k)] * (b1x); \
                                             else if (m_ == 2) c[(col)] += (uint64_t)X[(k)] * (b2x); } while (0)
-#pragma unroll 1
+ZKP_UNROLL(ZKP_BN_ROW_UNROLL)
   for (int s = 0; s < G; s++) {
     uint32_t qd[4];
     const uint32_t row_addr = lds_byte_address(ldsB + s * BLK);
@@ -237,7 +252,7 @@ __device__ __forceinline__ void bn_sqr_a(uint32_t (&R)[W], const uint32_t (&X)[W
   for (int k = 0; k < W; k++) c[k] = 0;
   if constexpr (BN_TWO_DIGITS) bn_core2<G, true>(c, X, ldsB, N, writes, gl);
   else
-#pragma unroll 1
+ZKP_UNROLL(ZKP_BN_ROW_UNROLL)
   for (int s = 0; s < G; s++) {
     uint32_t qd[4];
     const uint32_t row_addr = lds_byte_address(ldsB + s * BLK);
@@ -314,7 +329,7 @@ __device__ __forceinline__ void bn_mul_impl(uint32_t (&R)[W], const uint32_t (&A
   }
   if constexpr (BN_TWO_DIGITS) bn_core2<G, false>(c, A, ldsB, g.NT, writes, gl);
   else
-#pragma unroll 1
+ZKP_UNROLL(ZKP_BN_ROW_UNROLL)
   for (int s = 0; s < G; s++) {
     uint32_t qd[4];
     const uint32_t row_addr = lds_byte_address(ldsB + s * BLK);

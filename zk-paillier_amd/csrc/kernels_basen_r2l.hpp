@@ -184,7 +184,7 @@ __device__ __forceinline__ void product2(uint32_t (&R)[RW], const uint32_t (&X)[
   const uint32_t n1p = NT[1] + 1;
   // (the rows of the staged operand: a taken branch costs a lone wavefront ~20 ns — csrc/microbench/lone_wave_hops.hip —, twelve of them 5 % of a
   // product of 12 lanes x 6 limbs; ZKP_R2L_UNROLL_ROWS copies per loop iteration: A/B switch)
-#pragma unroll ZKP_R2L_UNROLL_ROWS
+  ZKP_UNROLL(ZKP_R2L_UNROLL_ROWS)
   for (int s = 0; s < GM::RG; s++) {
     uint32_t qd[4];
     const uint32_t row_addr = lds_byte_address(ldsB + s * GM::RBLK);
