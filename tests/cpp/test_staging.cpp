@@ -69,6 +69,23 @@ int main() {
   for (auto& x : th) x.join();
   CHECK(pool.held() <= pool.capacity());
   CHECK(pool.hits() > 100);
+  // wipe_now: the owner wipes a secret block on its own thread, ahead of a background release (host/zkproofs.hpp wipe_secrets)
+  {
+    RawBuf<uint32_t> s2(N, true);
+    for (size_t i = 0; i < N; i += 512) s2[i] = 0x5ec2e7u;
+    s2.wipe_now();
+    bool zero = true;
+    for (size_t i = 0; i < N; i += 512) zero &= s2[i] == 0;
+    CHECK(zero && !s2.secret && s2.pooled());
+    RawBuf<uint32_t> tiny2(8, true);
+    CHECK(!tiny2.pooled());
+  }
+  // trim: a long-running service gives the parked blocks back
+  CHECK(pool.held() > 0);
+  pool.trim();
+  CHECK(pool.held() == 0);
+  { RawBuf<uint32_t> again(N); again[0] = 3; }
+  CHECK(pool.held() == (size_t(8) << 20));                   // ... and the pool refills on demand
   std::printf(fails ? "staging FAILED\n" : "staging ok (hits %zu, misses %zu)\n", pool.hits(), pool.misses());
   return fails != 0;
 }

@@ -284,6 +284,10 @@ __device__ __forceinline__ void powm_fixed(const Grp<G, LL>& g, uint32_t (&X)[W]
 //     ~ t + t/7 + 33 products.
 constexpr uint8_t OP_END = 0xFF, OP_ZERO = 0xFE, OP_FIRST = 0x80, OP_MUL = 0x40, OP_TAB = 0x20, OP_SQ0 = 0x60;
 constexpr int SCHED_BYTES_PER_EXP_BIT = 2, SCHED_EXTRA_BYTES = 128;
+// behind the plain script lies its COMPACT form (kernels_basen.hpp, the engine's path): a run of squarings is ONE byte 1 .. 31 (its length;
+// longer runs take several), every other byte is the plain script's
+__host__ __device__ constexpr size_t sched_compact_offset(int exp_bits) { return (size_t)exp_bits * SCHED_BYTES_PER_EXP_BIT + SCHED_EXTRA_BYTES; }
+__host__ __device__ constexpr size_t sched_buffer_bytes(int exp_bits) { return 2 * sched_compact_offset(exp_bits); }
 
 #ifndef ZKP_TEMPLATE_KERNELS_ONLY
 __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int exp_bits, uint8_t* __restrict__ ops) {
@@ -291,7 +295,8 @@ __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int e
   auto bit = [&](int i) -> int { return (int)((exp_words[i >> 5] >> (i & 31)) & 1u); };
   int n = 0, i = exp_bits - 1;
   while (i >= 0 && !bit(i)) i--;
-  if (i < 0) { ops[0] = OP_ZERO; ops[1] = OP_END; return; }
+  uint8_t* compact = ops + sched_compact_offset(exp_bits);
+  if (i < 0) { ops[0] = OP_ZERO; ops[1] = OP_END; compact[0] = OP_ZERO; compact[1] = OP_END; return; }
   ops[n++] = OP_SQ0;
   for (int e = 1; e < TABS; e++) ops[n++] = (uint8_t)(OP_TAB | e);
   bool started = false;
@@ -309,6 +314,13 @@ __global__ void k_sliding_schedule(const uint32_t* __restrict__ exp_words, int e
     i = l - 1;
   }
   ops[n] = OP_END;
+  int m = 0, run = 0;
+  for (int j = 0; j <= n; j++) {
+    if (ops[j] == 0 && run < 31) { run++; continue; }
+    if (run) compact[m++] = (uint8_t)run;
+    run = ops[j] == 0 ? 1 : 0;
+    if (ops[j]) compact[m++] = ops[j];
+  }
 }
 #endif
 

@@ -533,7 +533,7 @@ static int32_t read_setup_flag(zkp_ctx* c, bool* any_bad) {
 // sliding-window schedule for a launch-uniform exponent (device resident, ctx scratch slot 15)
 static int32_t build_schedule(zkp_ctx* c, const uint32_t* exp_words, uint32_t exp_bits, const uint8_t** out) {
   DevBuf& b = c->scratch[15];
-  int32_t st = ensure(c, b, (size_t)exp_bits * SCHED_BYTES_PER_EXP_BIT + SCHED_EXTRA_BYTES);
+  int32_t st = ensure(c, b, sched_buffer_bytes((int)exp_bits));
   if (st) return st;
   hipLaunchKernelGGL(k_sliding_schedule, dim3(1), dim3(64), 0, c->stream, exp_words, (int)exp_bits, (uint8_t*)b.p);
   HIPCHK(c, hipGetLastError());
@@ -1024,6 +1024,8 @@ extern "C" int32_t zkp_timing_reset(zkp_ctx* c, int32_t enable) try {
   c->ev_used = 0; c->timed_launches = 0; c->timed_modexps = 0; c->pinned_used = 0;
   for (int k = 0; k < 2; k++)
     if (c->eng_ctx[k]) { const int32_t st = c->eng[k]->p_zkp_timing_reset(c->eng_ctx[k], enable); if (st) { c->err = c->eng[k]->p_zkp_last_error_string(c->eng_ctx[k]); return st; } }
+  // (the tail of a split call — csrc/zkp_api_proofs.inc range_split_run — runs on a second ctx of the latency engine: its share counts too)
+  if (c->split_ctx) { const int32_t st = c->eng[0]->p_zkp_timing_reset(c->split_ctx, enable); if (st) { c->err = c->eng[0]->p_zkp_last_error_string(c->split_ctx); return st; } }
   return ZKP_OK;
 } ZKP_CATCH(c)
 
@@ -1045,6 +1047,12 @@ extern "C" int32_t zkp_timing_get(zkp_ctx* c, double* ms, uint64_t* launches, ui
       if (st) { c->err = c->eng[k]->p_zkp_last_error_string(c->eng_ctx[k]); return st; }
       total += e_ms; lat_launches += e_launches; lat_modexps += e_modexps;
     }
+  if (c->split_ctx) {
+    double e_ms = 0; uint64_t e_launches = 0, e_modexps = 0;
+    const int32_t st = c->eng[0]->p_zkp_timing_get(c->split_ctx, &e_ms, &e_launches, &e_modexps);
+    if (st) { c->err = c->eng[0]->p_zkp_last_error_string(c->split_ctx); return st; }
+    total += e_ms; lat_launches += e_launches; lat_modexps += e_modexps;
+  }
   if (ms) *ms = total;
   if (launches) *launches = c->timed_launches + lat_launches;
   if (modexps) *modexps = c->timed_modexps + extra + lat_modexps;

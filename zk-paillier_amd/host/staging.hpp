@@ -67,6 +67,16 @@ class StagingPool {
     }
     for (Block& b : out) std::free(b.p);
   }
+  // give everything that is parked back to the OS (a long-running service after a burst of large batches; the pool refills on demand)
+  void trim() {
+    std::list<Block> out;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      out.swap(blocks_);
+      held_ = 0;
+    }
+    for (Block& b : out) std::free(b.p);
+  }
   size_t capacity() { std::lock_guard<std::mutex> g(mu_); return cap_; }
   size_t held() { std::lock_guard<std::mutex> g(mu_); return held_; }
   size_t hits() { std::lock_guard<std::mutex> g(mu_); return hits_; }
@@ -103,6 +113,13 @@ template <class T> struct RawBuf {
   }
   RawBuf(const RawBuf&) = delete;
   RawBuf& operator=(const RawBuf&) = delete;
+  // a secret block is wiped where its owner decides (wipe_now: on the calling thread, before the block is handed to a background
+  // release) or, at the latest, here
+  void wipe_now() {
+    if (secret && p) wipe_bytes(p, bytes);
+    secret = false;
+  }
+  bool pooled() const { return block != 0; }
   ~RawBuf() {
     if (secret) wipe_bytes(p, bytes);
     if (block) StagingPool::instance().give(p, block);

@@ -270,16 +270,20 @@ class RangeProofNi {
   // THE GPU WORKS (`prealloc`: every BigInt of every proof at its full capacity, on a few helper threads under the blocking call), and
   // after the call `fill` only copies limbs into memory that is already there, on all threads.  ZKP_HOST_PIPELINE=N (N > 1) still cuts
   // the batch into N calls — the next chunk's sampling and the previous chunk's fill then run under a call as well.
-  // chunks of a pipelined batch call: ZKP_HOST_PIPELINE = 0 / 1 (one call) or N (up to N chunks of >= 1024 proofs); default `dflt`
+  // chunks of a pipelined batch call, the same in prove_batch and verify_batch: ZKP_HOST_PIPELINE = 0 / 1 (one call) or N (up to N
+  // chunks of >= 1024 proofs); default `dflt`.  (verify_batch alone also knows ZKP_HOST_PIPELINE=uneven: a quarter, then the rest.)
   static size_t pipeline_chunks(size_t B, size_t dflt) {
     const char* pe = std::getenv("ZKP_HOST_PIPELINE");
     size_t want = dflt;
     if (pe && pe[0] >= '0' && pe[0] <= '9') want = std::max<size_t>(1, (size_t)std::atoi(pe));
     return std::max<size_t>(1, std::min<size_t>(want, B / 1024));
   }
-  // the staging buffers of a finished call (2.2 GB at B = 4096) go back to the OS on a thread of their own: unmapping them is tens of
-  // milliseconds that the caller need not wait for
-  template <class Chunks> static void release_later(Chunks&& chunks) {
+  // The staging buffers of a finished LARGE call (2.2 GB at B = 4096) go back to the pool / the OS on a thread of their own: unmapping
+  // them is tens of milliseconds that the caller need not wait for.  Small calls (nothing pooled: a single proof is a batch of one) free
+  // theirs inline — no thread per call.  Secret blocks are wiped by the CALLER before this (wipe_secrets below), never only in the
+  // background: a process that exits right after the call must not leave witnesses behind.
+  template <class Chunks> static void release_later(Chunks&& chunks, bool large) {
+    if (!large) { chunks.clear(); return; }
     try { std::thread([held = std::move(chunks)]() mutable { held.clear(); }).detach(); } catch (...) {}     // (no thread: freed here, by `chunks` going out of scope)
   }
   struct ProveChunk {
@@ -287,6 +291,8 @@ class RangeProofNi {
     RawBuf<uint32_t> range, ct, x, r, w1, w2, r1, r2, c1, c2, rw1, rr1, rw2, rr2;
     RawBuf<uint8_t> kind, jj;
     std::vector<uint8_t> status;
+    void wipe_secrets() { for (RawBuf<uint32_t>* b : {&x, &r, &w1, &w2, &r1, &r2}) b->wipe_now(); }
+    bool large() const { return c1.pooled(); }
     ProveChunk(size_t lo_, size_t hi_, size_t kw, size_t EF)
         : lo(lo_), hi(hi_), range((hi_ - lo_) * kw), ct((hi_ - lo_) * 2 * kw), x((hi_ - lo_) * kw, true), r((hi_ - lo_) * kw, true), w1((hi_ - lo_) * EF * kw, true),
           w2((hi_ - lo_) * EF * kw, true), r1((hi_ - lo_) * EF * kw, true), r2((hi_ - lo_) * EF * kw, true) /* witnesses and nonces: wiped on release */, c1((hi_ - lo_) * EF * 2 * kw), c2((hi_ - lo_) * EF * 2 * kw), rw1((hi_ - lo_) * EF * kw), rr1((hi_ - lo_) * EF * kw),
@@ -395,7 +401,9 @@ class RangeProofNi {
     sw.lap();
     fill(*ch[chunks - 1], ~0u);
     tm.rebuild_ms = sw.lap();
-    release_later(std::move(ch));
+    bool large = false;
+    for (auto& c : ch) { c->wipe_secrets(); large = large || c->large(); }      // witnesses and nonces: gone before this call returns
+    release_later(std::move(ch), large);
     return out;
   }
   static RangeProofNi prove(const EncryptionKey& ek, const BigInt& range, const BigInt& ciphertext, const BigInt& secret_x, const BigInt& secret_r) {
@@ -451,7 +459,7 @@ class RangeProofNi {
     std::vector<Result> out(B, Result(false));
     if (!fast.empty()) {
       // ONE GPU call by default.  The batch CAN run as a pipeline of chunks (ZKP_HOST_PIPELINE=N: while the GPU verifies chunk k, a helper
-      // thread flattens chunk k + 1; ZKP_HOST_PIPELINE=0: a quarter, then the rest), but what a chunk hides is small — flattening 0.78 GB of
+      // thread flattens chunk k + 1; ZKP_HOST_PIPELINE=uneven: a quarter, then the rest; 0 and 1: one call, as in prove_batch), but what a chunk hides is small — flattening 0.78 GB of
       // received proofs takes 13 ms on 16 threads now that the staging memory is huge-page backed (95 ms in round 4: first-touch faults) —
       // and every extra launch has a tail of its own.  B = 4096, one box, round 5: one call 3025 verifies/s, a quarter + the rest 2940,
       // 2 / 4 equal chunks 2938 / 2650.
@@ -468,7 +476,7 @@ class RangeProofNi {
       RawBuf<uint32_t> n(kw);
       ek.n.to_limbs(n.data(), kw);
       const char* pipe_env = std::getenv("ZKP_HOST_PIPELINE");
-      const bool uneven = pipe_env && pipe_env[0] == '0' && F >= 2048;
+      const bool uneven = pipe_env && pipe_env[0] == 'u' && F >= 2048;
       const size_t chunks = uneven ? 2 : pipeline_chunks(F, 1);
       auto flatten = [&](VerifyChunk& c, unsigned max_threads) {
         parallel_for(c.hi - c.lo, [&](size_t k) {
@@ -524,7 +532,9 @@ class RangeProofNi {
           out[fast[f]] = v == ZKP_VERDICT_MALFORMED ? Result::panicked("RangeProofNi::verify: malformed proof (the reference would panic)") : Result(v == ZKP_VERDICT_ACCEPT);
         }
       }
-      release_later(std::move(ch));
+      bool large = false;
+      for (auto& c : ch) large = large || c->c1.pooled();
+      release_later(std::move(ch), large);
       sw.lap();
     }
     if (!general.empty()) {
