@@ -339,22 +339,81 @@ def make_steps(engine, pb, wt, verdict, world, counts=None, gather="all"):
         bufs["c1"] = shard.GatherBuffers(pb.c1, world, counts)
         bufs["c2"] = shard.GatherBuffers(pb.c2, world, counts)
     out["recv_bytes"] = {"prove": sum(bufs[k].nbytes for k in ("c1", "c2") if k in bufs), "verify": bufs["verdict"].nbytes}
+    # per call, on this rank's host clock: seconds of compute (the engine's call until its stream is drained) and of the gather behind it
+    # (which ends when the slowest rank has delivered: it holds the wait for stragglers as well as the exchange)
+    phases = {"prove": [], "verify": []}
+    out["phases"] = phases            # (the step functions keep their own reference: callers may pop or clear `out`)
 
     def prove_step():
+        t0 = time.perf_counter()
         engine.prove(pb, wt)
         engine.before_collective()
+        t1 = time.perf_counter()
         if gather == "all":
             out["c1"] = shard.all_gather_slabs(pb.c1, world, counts, bufs["c1"])
             out["c2"] = shard.all_gather_slabs(pb.c2, world, counts, bufs["c2"])
         engine.after_collective()
+        phases["prove"].append((t1 - t0, time.perf_counter() - t1))
 
     def verify_step():
+        t0 = time.perf_counter()
         engine.verify(pb, verdict)
         engine.before_collective()
+        t1 = time.perf_counter()
         out["verdict"] = shard.all_gather_slabs(verdict, world, counts, bufs["verdict"])
         engine.after_collective()
+        phases["verify"].append((t1 - t0, time.perf_counter() - t1))
 
     return prove_step, verify_step, out
+
+
+def rccl_block(backend, world, gpus):
+    """what the process group really was: the backend's name, how many distinct ranks and distinct boards answered the all-gather of the
+    per-rank identities (`gpus`) — a line whose ranks_seen is not its n_gpus is not an N-GPU measurement, whatever its header says"""
+    return {"backend": backend, "world_size": world, "ranks_seen": len({g_["rank"] for g_ in gpus if g_}),
+            "distinct_boards_seen": len({g_.get("unique_id") or g_.get("pci_bus") or g_["rank"] for g_ in gpus if g_}),
+            "unique_ids": [g_.get("unique_id") for g_ in gpus if g_]}
+
+
+def phase_means(phases, steps):
+    """mean compute / gather milliseconds over the last `steps` calls (the timed ones) of a step function of make_steps"""
+    last = phases[-steps:] if steps else []
+    if not last:
+        return None
+    return {"compute_ms": 1e3 * sum(c for c, _ in last) / len(last), "gather_ms": 1e3 * sum(g for _, g in last) / len(last), "steps": len(last)}
+
+
+def scaling_leg(kind, args, engine, synth, shard, torch, dev, ctx, sync, timed, n, n_bits, world, rank):
+    """ONE scaling mode measured from scratch — inputs, a prove leg (which makes the proofs), a verify leg — exactly as the headline legs do
+    it: `weak` = --batch proofs on every rank, `strong` = --batch proofs IN ALL, cut into one block of proof indices per rank (BASELINE.json's
+    wording: "batch=4096, 1/2/4/8 GPU").  -> the entry of `scaling_values` and whether every verdict was right."""
+    if kind == "strong":
+        lo, hi = shard.shard_range(args.batch, world, rank)
+        B, total, counts = hi - lo, args.batch, block_counts(args.batch, world)
+    else:
+        B, total, counts = args.batch, args.batch * world, None
+    pb, wt = synth.synth_range_inputs(n, n_bits, B, seed=4321 + rank, device=dev)
+    sync()
+    ctx.paillier_enc(n_bits, B, pb.n, 0, wt.x, wt.r, pb.ciphertext)
+    sync()
+    verdict = torch.zeros(B, dtype=torch.uint8, device=dev)
+    prove_step, verify_step, got = make_steps(engine, pb, wt, verdict, world, counts, args.gather)
+    dtp, _, _, _ = timed(prove_step, args.steps, args.warmup)
+    tampered = torch.arange(0, B, 64, device=dev)
+    pb.resp_r1[tampered, 0, 0] ^= 1
+    expect = torch.ones(B, dtype=torch.uint8, device=dev)
+    expect[tampered] = 0
+    sync()
+    dtv, kms, launches, _ = timed(verify_step, args.steps, args.warmup)
+    sync()
+    my_lo = sum(counts[:rank]) if counts and len(set(counts)) > 1 else rank * B
+    ok = bool(torch.equal(verdict, expect)) and got["verdict"].shape[0] == total and bool(torch.equal(got["verdict"][my_lo:my_lo + B], expect))
+    out = {"proofs_total": total, "proofs_per_rank": B, "verifies_per_s": total * args.steps / dtv, "proofs_per_s": total * args.steps / dtp,
+           "verify_ms_per_step": 1e3 * dtv / args.steps, "prove_ms_per_step": 1e3 * dtp / args.steps,
+           "verify_phases_rank0": phase_means(got["phases"]["verify"], args.steps), "prove_phases_rank0": phase_means(got["phases"]["prove"], args.steps),
+           "verify_kernel_ms_per_launch_rank0": kms / max(launches, 1)}
+    got.clear()
+    return out, ok
 
 
 def make_correct_key_step(engine, n_bits, n, sigma, salt, verdict, world, counts=None):
@@ -550,6 +609,7 @@ def main():
     verdict = torch.zeros(B, dtype=torch.uint8, device=dev)
     prove_step, verify_step, gathered = make_steps(engine, pb, wt, verdict, world, counts, args.gather)
     recv_bytes = gathered.pop("recv_bytes")
+    phases = gathered.pop("phases")
 
     # ---- prove leg (also produces the proofs the verify leg consumes)
     prove = None
@@ -560,7 +620,7 @@ def main():
             dt, kms, launches, modexps = timed(prove_step, args.steps, args.warmup)
         prove = {"value": B_total * args.steps / dt, "unit": "proofs/s", "ms_per_step": 1e3 * dt / args.steps, "clock": clk_p.summary(),
                  "gather": args.gather, "gather_recv_bytes_per_rank_per_step": recv_bytes["prove"],
-                 "enc_kernel_ms_per_launch": kms / max(launches, 1), "launches": launches,
+                 "enc_kernel_ms_per_launch": kms / max(launches, 1), "launches": launches, "phases_rank0": phase_means(phases["prove"], args.steps),
                  "achieved_limb_mac_per_s": None, "frac": None, "_kms": kms, "_modexps": modexps}
     # tamper every 64th proof (one bit of resp_r1 in row 0): those must be rejected, all others accepted
     tampered = torch.arange(0, B, 64, device=dev)
@@ -595,7 +655,27 @@ def main():
     else:
         roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc<{144 // lpl}, true> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer; sliding-window ladder, squarings at 3/4 of a product)", clk.summary(), executed_lane_mads_per_enc(n, n_bits, True))
     ms_per_step = 1e3 * dt / args.steps
+    verify_phases = phase_means(phases["verify"], args.steps)
+    # energy of the dominant kernel (the board sits at its power cap on it: joules per Enc is what a change has to lower)
+    cs = clk.summary() or {}
+    if cs.get("mean_power_w") and kms and modexps:
+        roofline["mean_power_w"] = cs["mean_power_w"]
+        roofline["joules_per_enc"] = cs["mean_power_w"] * (kms * 1e-3) / modexps
+        roofline["picojoules_per_executed_lane_mad"] = 1e12 * roofline["joules_per_enc"] / roofline["executed_lane_mads_per_enc"] if roofline.get("executed_lane_mads_per_enc") else None
+        roofline["energy_note"] = "board power (sysfs hwmon power1_input, sampled every 50 ms over the timed verify steps) x the HIP-event time of the Enc launches / Enc count"
     gathered.clear()
+    # ---- BOTH scaling modes in one line (BASELINE.json reads "batch=4096, 1/2/4/8 GPU": the strong one; `value` stays the mode --scaling names)
+    this_mode = {"proofs_total": B_total, "proofs_per_rank": B, "verifies_per_s": value, "proofs_per_s": prove["value"] if prove else None,
+                 "verify_ms_per_step": ms_per_step, "prove_ms_per_step": prove["ms_per_step"] if prove else None,
+                 "verify_phases_rank0": verify_phases, "prove_phases_rank0": prove["phases_rank0"] if prove else None,
+                 "verify_kernel_ms_per_launch_rank0": kms / max(launches, 1)}
+    scaling_values = {args.scaling: this_mode}
+    other_mode = "strong" if args.scaling == "weak" else "weak"
+    if world == 1:
+        scaling_values[other_mode] = dict(this_mode, note="one GPU: the two modes are the same run")
+    elif not args.no_prove_leg:
+        scaling_values[other_mode], same = scaling_leg(other_mode, args, engine, synth, shard, torch, dev, ctx, sync, timed, n, n_bits, world, rank)
+        ok = ok and same
 
     cpu = pcie = other = None
     if rank == 0 and world == 1:
@@ -635,6 +715,7 @@ def main():
     else:
         gpus = [mine]
     ok = bool(okt.item())
+    rccl = rccl_block(dist.get_backend(), world, gpus)
 
     if rank == 0:
         per = "per GPU" if args.scaling == "weak" else f"in all, cut into {world} blocks"
@@ -648,7 +729,7 @@ def main():
                           "parallelism": f"proof-index sharding x{world}, one RCCL all-gather per step of verdicts (verify)" + (" and c1/c2 slabs (prove)" if args.gather == "all" else "; --gather verdicts: a prove step exchanges nothing") + " via zk-paillier_amd/shard.py (receive buffers allocated once, outside the timed steps)",
                           "gather": args.gather, "gather_recv_bytes_per_rank_per_step": recv_bytes,
                           "proofs_per_rank": B, "proofs_total": B_total},
-               "gpus": gpus,
+               "gpus": gpus, "rccl": rccl, "scaling_values": scaling_values, "phases_rank0": {"verify": verify_phases, "prove": prove["phases_rank0"] if prove else None},
                "prove": prove, "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "host_api": host_api, "capi_multi": capi_multi, "other_configs": other}
         # RCCL writes a version banner through C stdio when the communicator is created; push it out first so that the
         # JSON line is the LAST line on stdout
@@ -760,7 +841,8 @@ def capi_multi_leg(pb, wt, expect, np, B, world, steps):
         for _ in range(steps):
             m.range_ni_verify(host.struct(), v)
         dtv = (time.perf_counter() - t0) / steps
-        per_dev_v = [{"device": i, "proofs": hi - lo, "ms": round(ms, 1)} for i, (ms, lo, hi) in enumerate(m.last_timing())]
+        per_dev_v = [{"device": i, "proofs": hi - lo, "ms": round(ms, 1), "compute_ms": round(cm, 2), "gather_ms": round(gm, 3)}
+                     for i, ((ms, lo, hi), (cm, gm)) in enumerate(zip(m.last_timing(), m.last_phases()))]
         same = bool(np.array_equal(v, np.concatenate([expect.cpu().numpy()] * world)))
         out = zkp.RangeBatch(host.n_bits, total, host.ef, shared_key=True)
         out.n[:] = host.n; out.range[:] = host.range; out.ciphertext[:] = host.ciphertext
@@ -769,13 +851,14 @@ def capi_multi_leg(pb, wt, expect, np, B, world, steps):
         t0 = time.perf_counter()
         m.range_ni_prove(out.struct(), hw.struct(), None, None, st)
         dtp = time.perf_counter() - t0
-        per_dev_p = [{"device": i, "proofs": hi - lo, "ms": round(ms, 1)} for i, (ms, lo, hi) in enumerate(m.last_timing())]
+        per_dev_p = [{"device": i, "proofs": hi - lo, "ms": round(ms, 1), "compute_ms": round(cm, 2), "gather_ms": round(gm, 3)}
+                     for i, ((ms, lo, hi), (cm, gm)) in enumerate(zip(m.last_timing(), m.last_phases()))]
         same = same and not st.any()
         _, stride, nbytes = m.gathered(0, 1)
     finally:
         m.close()
     return {"engine": "zkp_multi_* (one process, one ctx + host thread per device, proof-index blocks; outputs by the grouped ncclAllGather inside libzkp_hip.so: ZKP_GATHER_RCCL)",
-            "n_devices": world, "proofs_total": total, "scaling": "weak",
+            "n_devices": world, "proofs_total": total, "scaling": "weak", "rccl_ranks_seen": m.size(),
             "verify": {"value": total / dtv, "unit": "verifies/s", "ms_per_step": 1e3 * dtv, "steps": steps, "per_device_last_step": per_dev_v},
             "prove": {"value": total / dtp, "unit": "proofs/s", "ms_per_step": 1e3 * dtp, "steps": 1, "per_device_last_step": per_dev_p,
                       "gathered_c1_bytes_per_device": nbytes, "gathered_block_stride": stride},

@@ -147,6 +147,7 @@ extern "C" {
     pub fn zkp_multi_ctx(m: *mut zkp_multi, i: u32) -> *mut zkp_ctx;
     pub fn zkp_multi_last_error_string(m: *mut zkp_multi) -> *const c_char;
     pub fn zkp_multi_last_timing(m: *mut zkp_multi, i: u32, out_ms: *mut f64, out_lo: *mut u64, out_hi: *mut u64) -> i32;
+    pub fn zkp_multi_last_phases(m: *mut zkp_multi, i: u32, out_compute_ms: *mut f64, out_gather_ms: *mut f64) -> i32;
     pub fn zkp_multi_set_gather(m: *mut zkp_multi, mode: u32) -> i32;
     pub fn zkp_multi_gathered(m: *mut zkp_multi, device_index: u32, which: u32, out_device_ptr: *mut *mut c_void, out_block_stride_bytes: *mut u64, out_bytes: *mut u64) -> i32;
     pub fn zkp_multi_range_ni_prove_batch(m: *mut zkp_multi, p: *const zkp_range_ni_proofs, w: *const zkp_range_ni_witness, out_e: *mut u8, out_e_len: *mut u8, out_status: *mut u8) -> i32;

@@ -394,6 +394,10 @@ const char* zkp_multi_last_error_string(zkp_multi* m);
 /* the most recent batch call, per device context i: the block [lo, hi) of items it was given and the wall time of its share
  * (staging, launches and the D2H of its output slab), in milliseconds */
 int32_t zkp_multi_last_timing(zkp_multi* m, uint32_t i, double* out_ms, uint64_t* out_lo, uint64_t* out_hi);
+/* ... and its two phases on device context i's own stream (HIP events), in milliseconds: the compute of its block (staging of its inputs
+ * included) and, in the gathering modes below, the all-gather behind it — which ends when the slowest peer has delivered, so it holds the
+ * wait for stragglers as well as the exchange.  ZKP_GATHER_HOST: compute = the wall time of the context's blocking call, gather = 0. */
+int32_t zkp_multi_last_phases(zkp_multi* m, uint32_t i, double* out_compute_ms, double* out_gather_ms);
 /* Where the outputs of the batch calls below are reassembled.
  *   ZKP_GATHER_HOST (default): every context copies its output slab into the caller's host arrays (one D2H per GPU, no collective).
  *   ZKP_GATHER_RCCL: every context works on device-resident copies of its block and writes its slab into its segment of a buffer

@@ -33,8 +33,13 @@ def pytest_collection_modifyitems(config, items):
     # The narrowing is REPORTED (pytest's "deselected" count) and can be switched off: ZKP_TEST_FULL_MATRIX=1 runs every file under all five.
     narrow = ("w18-basen", "w9-pair")
     wide_files = ("test_gpu_l1", "test_golden", "test_gpu_range", "test_gpu_challenge", "test_gpu_correct_key", "test_gpu_dlog", "test_sigma_proofs", "test_verlin_proof", "test_gpu_soak")
+    # Round 6 (the suite on a budget, tests/test_gpu_suite_budget.py): the whole-document tests — 5 s of JSON per case, the arithmetic under
+    # them covered family by family elsewhere — run under ONE family, the throughput engine in base-n form.
+    one_family_tests = ("test_gpu_whole_range_proof_ni_documents", "test_consumer_on_a_simulated_document_gpu")
     if os.environ.get("ZKP_TEST_FULL_MATRIX", "0") in ("", "0"):
         def is_narrowed(it):
+            if any(t in it.nodeid for t in one_family_tests) and "w36-basen" not in it.nodeid:
+                return True
             return any(f"[{n}" in it.nodeid or f"-{n}]" in it.nodeid or f"[{n}-" in it.nodeid for n in narrow) and not any(w in it.nodeid for w in wide_files)
         dropped = [it for it in items if is_narrowed(it)]
         if dropped:

@@ -244,6 +244,93 @@ def test_sharded_bench_legs_world_size_2_gloo():
     assert c1_ok and c2_shape == [3, 128, 64]
 
 
+class _OracleCtx:
+    """what bench.scaling_leg asks of a ctx, on the oracle"""
+
+    def __init__(self, oracle):
+        self.oracle = oracle
+
+    def paillier_enc(self, n_bits, count, n, n_stride, m, r, out):
+        u = lambda t: np.ascontiguousarray(t.numpy().view(np.uint32))
+        res = self.oracle.paillier_enc(n_bits, u(n).reshape(-1), n_stride, u(m), u(r))
+        out.copy_(__import__("torch").from_numpy(res.view(np.int32)).view(out.shape))
+
+
+def _scaling_worker(rank, world, port, ret):
+    """both scaling modes of `bench.py --gpus 2` through bench.scaling_leg — the code the driver's SCALE run executes — with the oracle as
+    the engine, and the part of the JSON line that makes such a run self-validating"""
+    import argparse
+    import importlib
+    import json
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    sys.path.insert(0, H.ROOT)
+    import bench
+    shard = importlib.import_module("zk-paillier_amd.shard")
+    synth = importlib.import_module("zk-paillier_amd.synth")
+    oracle = oracle_lib.Oracle()
+    oracle.set_threads(max(1, min(8, oracle.max_threads() // world)))
+    args = argparse.Namespace(batch=2, steps=1, warmup=0, gather="all")
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        dist.barrier()
+        return time.perf_counter() - t0, 0.0, 0, 0
+
+    values, ok = {}, True
+    for kind in ("weak", "strong"):
+        values[kind], same = bench.scaling_leg(kind, args, _OracleEngine(oracle), synth, shard, torch, torch.device("cpu"), _OracleCtx(oracle), lambda: None, timed,
+                                               synth.BENCH_N, 2048, world, rank)
+        ok = ok and same
+    mine = dict(bench.gpu_identity(0, rank))
+    gpus = [None] * world
+    dist.all_gather_object(gpus, mine)
+    if rank == 0:
+        line = json.dumps({"n_gpus": world, "scaling": "weak", "value": values["weak"]["verifies_per_s"], "scaling_values": values,
+                           "rccl": bench.rccl_block(dist.get_backend(), world, gpus), "verdicts_ok": ok})
+        ret.put(line)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_two_rank_bench_line_carries_both_scaling_modes_and_says_who_answered():
+    """round-5 verdict item 5: the line of `bench.py --gpus N` reports the STRONG-scaling value (BASELINE.json: "batch=4096, 1/2/4/8 GPU" —
+    the batch IN ALL) beside the weak one, compute apart from gather, and how many ranks really took part"""
+    import json
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scaling_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    line = json.loads(ret.get(timeout=900))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert line["verdicts_ok"] and line["rccl"]["ranks_seen"] == line["n_gpus"] == line["rccl"]["world_size"] == 2 and line["rccl"]["backend"] == "gloo"
+    sv = line["scaling_values"]
+    assert sv["weak"]["proofs_total"] == 4 and sv["weak"]["proofs_per_rank"] == 2
+    assert sv["strong"]["proofs_total"] == 2 and sv["strong"]["proofs_per_rank"] == 1
+    for kind in ("weak", "strong"):
+        v = sv[kind]
+        assert v["verifies_per_s"] > 0 and v["proofs_per_s"] > 0
+        for ph in (v["verify_phases_rank0"], v["prove_phases_rank0"]):
+            assert ph["steps"] == 1 and ph["compute_ms"] > 0 and ph["gather_ms"] >= 0
+            assert ph["compute_ms"] + ph["gather_ms"] <= 1.05 * max(v["verify_ms_per_step"], v["prove_ms_per_step"]) + 50
+    assert line["value"] == sv["weak"]["verifies_per_s"]
+
+
 def test_bench_refuses_a_world_size_that_is_not_gpus():
     """`--gpus 8` under a 1-rank launcher must not print a 1-GPU line: exit status 2 before any GPU work"""
     import subprocess

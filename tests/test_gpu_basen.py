@@ -100,7 +100,7 @@ def test_enc_batch_equals_python_and_the_n2_sized_kernels(ctx, n_bits):
     kw = n_bits // 32
     n = odd_modulus(rnd, n_bits)
     nn = n * n
-    count = 70                                                  # more than one wavefront of groups, ragged
+    count = 70 if n_bits == 2048 else 24                        # more than one wavefront of groups, ragged (Python's pow on 8192-bit operands is the test's time: 0.3 s each)
     ms = [rnd.randrange(n) for _ in range(count)]
     rs = [rnd.getrandbits(n_bits) for _ in range(count)]        # r >= n included: (r + k n)^n == r^n (mod n^2)
     ms[0], rs[0] = 0, 1
@@ -146,7 +146,7 @@ def test_enc_batch_with_per_item_keys_equals_python(ctx, n_bits):
     """n_stride != 0: every item under its own key (fixed-window ladder over the item's n, constants per key, C3 from global memory)"""
     rnd = random.Random(n_bits + 2)
     kw = n_bits // 32
-    count = 40 if n_bits == 2048 else 20
+    count = 40 if n_bits == 2048 else 12
     ns = [odd_modulus(rnd, n_bits - (i % 3 == 2)) for i in range(count)]       # some keys one bit short of the field
     ms = [rnd.randrange(n) for n in ns]
     rs = [rnd.getrandbits(n_bits) for _ in range(count)]
@@ -263,6 +263,8 @@ def test_one_enc_per_wavefront_ladder_of_the_latency_engine(lanes):
                 outs.append(out)
             assert np.array_equal(outs[0], outs[1])
             for i in range(count):
+                if i >= 48 and i % 23:                              # (the two kernels agree on every item, above; Python checks the edge cases and a sample)
+                    continue
                 got = sum(int(w) << (32 * j) for j, w in enumerate(outs[0][i]))
                 assert got == (1 + ms[i] * n) * pow(rs[i], n, nn) % nn, (trial, i)
             c.set_r2l(2)

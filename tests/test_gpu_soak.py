@@ -29,7 +29,7 @@ def _seed():
 
 
 def _box():
-    return float(os.environ.get("ZKP_SOAK_SECONDS", "25"))
+    return float(os.environ.get("ZKP_SOAK_SECONDS", "12"))      # (the driver's GPU run is on a budget: tests/test_gpu_suite_budget.py; the stand-alone soaks tests/soak_gpu*.py run as long as asked)
 
 
 def test_randomised_soak_l1(zkp, oracle):

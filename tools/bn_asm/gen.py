@@ -1,5 +1,5 @@
-"""Generator of the fixed-register base-n product engine of k_enc_basen<2> (gfx950, W = 36 limbs per lane, G lanes per n-sized
-integer) — csrc/kernels_basen_asm_g2.inc.
+"""Generator of the fixed-register base-n product engine of k_enc_basen<G> (gfx950, W = 36 limbs per lane, G = 2 / 4 lanes per n-sized
+integer: n of 2048 / 4096 bits) — csrc/kernels_basen_asm_g2.inc, csrc/kernels_basen_asm_g4.inc.
 
 Why assembler: the compiled product bodies of csrc/kernels_basen.hpp are clean (89 % multiply-adds, no
 scratch access), but every attempt to change what surrounds them — ONE copy of the product body for all call sites, the a part of a
@@ -22,8 +22,8 @@ Register map (VGPRs):
     A[k]   v[72 + k]                    this lane's block of the register operand
     N[k]   v[108 + k]                   this lane's block of M~ (the Orup multiple of n)
     v144 .. v183                        temporaries of the row loops (staged limbs, quotient digits, carries)
-    v184 .. v191                        per-lane inputs, never written here (LDS addresses, lane mask, global addresses)
-    U[k]   v[192 + k]                   the parked cross product rb * a of a base-n product
+    v184 .. v193                        per-lane inputs, never written here (LDS addresses, lane mask, global addresses)
+    U[k]   v[194 + k]                   the cross product rb * a of a base-n product: its low half, then (from global scratch) its high half
 Scalar registers s30 .. s51 (see Layout)."""
 import os
 import sys
@@ -98,9 +98,13 @@ class Layout:
     VCST = v(187)        # LDS byte address of this lane's block of C3 pairs (constant block + 2 * VGLO)
     VSRC = v(188, 2)     # product: global address of this lane's block of ra (rb: + pair_b bytes)
     VDST = v(190, 2)     # product: global address of this lane's block of the destination pair
+    VSCR = v(192, 2)     # product: global address of this lane's block of the group's scratch entry (the high half of the wide cross product)
     @staticmethod
-    def U(k): return v(192 + k)
-    LAST_VGPR = 227
+    def U(k): return v(194 + k)
+    LAST_VGPR = 229
+    # the per-key flavour (k_enc_basen_keys: every group under a key of its own): no constant block in LDS —
+    VN1 = v(187)         # n1 of this lane's key (in place of VCST)
+    VKEY = v(230, 2)     # global address of this lane's block of M~ in its key's record (BnConst: C3 one integer behind)
 
     # scalar registers
     RET = s(30, 2)       # return address of the entry point
@@ -304,6 +308,97 @@ class Gen:
         block(W, {}, tail=True)
         p.s_setpc_b64(L.RET2)
 
+
+    def rows_wide(self):
+        """The cross product rb * a of a base-n product as the EXACT integer HI R' + LO — no reduction, half the multiply-adds of a product on
+        M~ (kernels_basen.hpp bn_mul_full; profiles/r05/experiments/README.md: the variant the compiler could not hold in registers).
+        Every sub-step finishes one digit of LO in lane 0's bottom column; the lane whose block that digit belongs to (row s = its gl) keeps
+        it.  LO joins the b side's initial columns before that side's ONE reduction, HI is added to its result:
+            (ra b + LO - Q n1 + q M~) / R' + HI  ==  (ra b + rb a - Q n1) / R'   (mod n).
+        In: A[] = rb, VROW = row 0 of the staged a.  Out: U[] = this lane's block of LO, c[] = the columns of HI.  Returns through RET2."""
+        L, p = self.L, self.p
+        from machine import VCC
+        VDOWN = L.VT                                                # (the scratch address register is free inside the row loop)
+
+        def mad(col, a, b, fresh):
+            src = fresh.pop(col % W, None)
+            p.v_mad_u64_u32(L.C(col), L.SINK, a, b, L.C(col) if src is None else src)
+
+        def read_quad(q, row_off=0):
+            p.ds_read(128, L.BQquad(q), L.VROW, row_off + (q % 9) * 16)
+
+        def block(t, tail=False):
+            tm = t - 1
+            i2 = t & 1
+            fresh = {}
+            fill = [] if tail else [(lambda k=k: mad(t + k, L.A(k), L.BQ(t), fresh)) for k in range(W - 1)]
+            top = None if tail else (lambda: mad(t + W - 1, L.A(W - 1), L.BQ(t), fresh))
+
+            def finish_mask(): p.v_and_b32(L.TL(i2), MASK, L.Clo(tm))
+            # what goes down to the lane below: nothing from lane 0 of a group — the top lane of the group below opens its fresh column at
+            # 0 (nothing was reduced: a group's bottom limb is not zero here as it is in a product on M~)
+            def down_mask(): p.v_and_b32(L.B2(i2), VDOWN, L.Clo(tm))
+            def finish_shift(): p.v_lshrrev_b64(L.SH(i2), LB, L.C(tm))
+            def carry(): p.v_lshl_add_u64(L.C(tm + 1), L.C(tm + 1), 0, L.SH(i2))
+            def bcast(): p.v_mov_b32_dpp(L.TQ(i2), L.TL(i2), L.bcast)
+            def capture(): p.v_cndmask_b32(L.U(tm % W), L.U(tm % W), L.TQ(i2))
+
+            def pass_down():
+                if tail:
+                    p.v_mov_b32_dpp(L.Clo(tm), L.B2(i2), "row_shl:1")
+                    p.v_mov_b32(L.Chi(tm), 0)
+                else:
+                    p.v_mov_b32_dpp(L.X(i2), L.B2(i2), "row_shl:1")
+                    fresh[tm % W] = L.XZ(i2)
+
+            seq = ["f", "f", "f", finish_mask, down_mask, finish_shift, "f", "f", carry, bcast, "f", "f", pass_down, capture, "f", "f"]
+            if top:
+                seq.append(top)
+            tq = t % W
+            if not tail and tq % 4 == 0:
+                nxt = tq // 4 + 1
+                seq.insert(0, (lambda: read_quad(nxt % 9, ROWB if nxt == 9 else 0)))
+            it = iter(fill)
+            for x in seq:
+                if x == "f":
+                    th = next(it, None)
+                    if th:
+                        th()
+                    else:
+                        p.s_nop(0)
+                else:
+                    x()
+            for th in it:
+                th()
+            if not tail and tq % 4 == 3:
+                p.s_waitcnt(lgkm=0)
+            assert not fresh
+
+        p.label(self.lbl("wide_rows"))
+        read_quad(0)
+        read_quad(1)
+        p.s_mov_b32(L.SROW, self.G)
+        p.s_mov_b32(("vcc_lo", 0, 1), L.qmask32)                   # the lanes whose block row 0 is: lane 0 of every group
+        p.s_mov_b32(("vcc_hi", 0, 1), L.qmask32)
+        p.v_and_b32(VDOWN, MASK, L.VGLM)                            # the limb mask, or 0 in lane 0 of a group
+        p.s_waitcnt(lgkm=1)
+        fresh = {k: 0 for k in range(W)}
+        for k in range(W):
+            mad(k, L.A(k), L.BQ(0), fresh)
+        p.label(self.lbl("wide_loop"))
+        for t in range(1, W):
+            block(t)
+        p.s_sub_u32(L.SROW, L.SROW, 1)
+        p.s_cmp_eq_u32(L.SROW, 0)
+        p.s_cbranch_scc1(self.lbl("wide_tail"))
+        p.v_add_u32(L.VROW, ROWB, L.VROW)
+        block(W)
+        p.s_lshl_b64(VCC, VCC, 1)                                   # the next row's digits belong to the next lane of every group
+        p.s_branch(self.lbl("wide_loop"))
+        p.label(self.lbl("wide_tail"))
+        block(W, tail=True)
+        p.s_setpc_b64(L.RET2)
+
     # ------------------------------------------------------------------------------------------------ between the row loops
     def chain_chunk(self, base, dst0, state):
         """carry chain over columns base .. base + CH - 1: limb k -> v[dst0 + k - base]; the carry travels in SH(0)"""
@@ -347,6 +442,12 @@ class Gen:
             for k in range(base, base + CH):
                 p.v_sub_u32(v(Q0 + k - base), 1 << LB, v(Q0 + k - base))
             p.s_waitcnt(lgkm=0)
+            nolo = self.fresh_label("fin_a_nolo")
+            p.s_bitcmp1_b32(L.SFLAGS, 0)
+            p.s_cbranch_scc0(nolo)
+            for k in range(base, base + CH):                       # + LO of the wide cross product (limbs below 2^29 on limbs below 2^29)
+                p.v_add_u32(L.Clo(k), L.Clo(k), L.U(k))
+            p.label(nolo)
             for k in range(base, base + CH):
                 p.v_mad_u64_u32(L.C(k), L.SINK, v(Q0 + k - base), L.SN1, L.C(k))
         self.carry_to_next_lane(L.TL(1))
@@ -362,6 +463,7 @@ class Gen:
         p.v_add_u32(L.VT, L.VAREA, L.VGLO)
         p.s_bitcmp1_b32(L.SFLAGS, 0)
         p.s_cbranch_scc0(self.lbl("fin_b_chain"))
+        p.s_waitcnt(vm=0)                                           # (the high half of the cross product, on its way back from the scratch entry)
         for k in range(W):                                          # c_k += U_k
             p.v_mad_u64_u32(L.C(k), L.SINK, L.U(k), 1, L.C(k))
         p.label(self.lbl("fin_b_chain"))
@@ -409,14 +511,51 @@ class Gen:
         p.v_add_u32(L.A(0), L.A(0), t0)
         p.s_setpc_b64(L.RET2)
 
-    def lane_setup(self):
-        """M~ into N[] from the constant block; the zero halves of the fresh-column pairs"""
+    def lane_setup(self, per_key=False):
+        """M~ into N[] from the constant block (per-key flavour: from the key's record in global memory); the zero halves of the
+        fresh-column pairs"""
         L, p = self.L, self.p
-        p.v_sub_u32(L.VT, L.VCST, L.VGLO)                           # constant block + this lane's ROWB
-        for j in range(0, W, 4):
-            p.ds_read(128, v(108 + j, 4), L.VT, L.mt_off + j * 4)
+        if per_key:
+            for j in range(0, W, 4):
+                p.global_load(4, v(108 + j, 4), L.VKEY, j * 4)
+        else:
+            p.v_sub_u32(L.VT, L.VCST, L.VGLO)                       # constant block + this lane's ROWB
+            for j in range(0, W, 4):
+                p.ds_read(128, v(108 + j, 4), L.VT, L.mt_off + j * 4)
         p.v_mov_b32(L.Z(0), 0)
         p.v_mov_b32(L.Z(1), 0)
+
+    def load_c3(self, first_reg):
+        """per-key flavour: this lane's block of its key's C3 -> 36 registers from `first_reg`"""
+        L, p = self.L, self.p
+        for j in range(0, W, 4):
+            p.global_load(4, v(first_reg + j, 4), L.VKEY, L.pair_b + j * 4)
+
+    def fin_a_init_b_k(self):
+        """fin_a_init_b of the per-key flavour: the b side's additive block — C3 of the lane's key, plus LO of the wide cross product in a
+        product — waits in U[]; c_k = (2^29 - Q_k) n1 + U_k with n1 in a vector register."""
+        L, p = self.L, self.p
+        p.label(self.lbl("fin_a_init_b_k"))
+        p.v_add_u32(L.VT, L.VAREA, L.VGLO)
+        p.s_waitcnt(vm=0)                                           # (C3 on its way into U[])
+        Q0, R0 = 144, 156
+        state = {"first": True}
+        for base in range(0, W, CH):
+            for j in range(0, CH, 4):
+                p.ds_read(128, v(Q0 + j, 4), L.VT, (base + j) * 4)
+            self.chain_chunk(base, R0, state)
+            for j in range(0, CH, 4):
+                p.ds_write(128, L.VT, v(R0 + j, 4), (base + j) * 4)
+            p.s_waitcnt(lgkm=CH // 4)
+            for k in range(base, base + CH):
+                p.v_sub_u32(v(Q0 + k - base), 1 << LB, v(Q0 + k - base))
+            for k in range(base, base + CH):
+                p.v_mad_u64_u32(L.C(k), L.SINK, v(Q0 + k - base), L.VN1, 0)
+            for k in range(base, base + CH):
+                p.v_mad_u64_u32(L.C(k), L.SINK, L.U(k), 1, L.C(k))
+        self.carry_to_next_lane(L.TL(1))
+        p.ds_add_u32(L.VT, L.TL(1), 0)
+        p.s_setpc_b64(L.RET2)
 
     def set_qmask(self, on):
         L, p = self.L, self.p
@@ -427,68 +566,89 @@ class Gen:
             p.s_mov_b64(L.QMASK, 0)
 
     # ------------------------------------------------------------------------------------------------ entry points
-    def sqr_run(self):
-        """(a, b) staged <- (a, b)^(2^SCNT).  In: v184 .. v187 (Layout), s41 = count (>= 1), s42 = n1."""
+    def sqr_run(self, per_key=False):
+        """(a, b) staged <- (a, b)^(2^SCNT).  In: v184 .. v187 (Layout), s41 = count (>= 1), s42 = n1 (per-key flavour: v187 = n1,
+        v[230:231] = the key's record)."""
         L, p = self.L, self.p
-        p.label(f"zkp_bn_sqr_run_g{self.G}")
+        k = "_k" if per_key else ""
+        p.label(f"zkp_bn_sqr_run{k}_g{self.G}")
         p.s_waitcnt(vm=0, lgkm=0)                                   # (what the caller left in flight: its stores feed this code's loads)
-        self.lane_setup()
+        self.lane_setup(per_key)
         p.s_mov_b32(L.SFLAGS, 0)
-        p.label(self.lbl("sqr_next"))
+        p.label(self.lbl("sqr_next" + k))
+        if per_key:
+            self.load_c3(194)                                       # C3 -> U[]: it has the whole a side to arrive
         p.v_add_u32(L.VT, L.VAREA, L.VGLO)
         for j in range(0, W, 4):
             p.ds_read(128, v(72 + j, 4), L.VT, j * 4)
         p.v_mov_b32(L.VROW, L.VAREA)
         self.set_qmask(True)
-        p.s_waitcnt(lgkm=0)
+        if per_key:
+            p.s_waitcnt(vm=W // 4, lgkm=0)                          # (M~ is here — the first pass — ; C3 may still be under way)
+        else:
+            p.s_waitcnt(lgkm=0)
         p.s_call_b64(L.RET2, self.lbl("sqr_rows_zero"))          # a^2: digits over the staged a
         p.s_call_b64(L.RET2, self.lbl("double_a"))               # 2 a: the register operand of the b side
-        p.s_call_b64(L.RET2, self.lbl("fin_a_init_b"))           # a' staged; columns = C3 + (2^29 - Q) n1
+        p.s_call_b64(L.RET2, self.lbl("fin_a_init_b" + k))       # a' staged; columns = C3 + (2^29 - Q) n1
         p.v_add_u32(L.VROW, L.area_b, L.VAREA)
         self.set_qmask(False)
         p.s_call_b64(L.RET2, self.lbl("mul_rows_init"))          # 2 a b + the quotient term
         p.s_call_b64(L.RET2, self.lbl("fin_b"))                  # b' staged
         p.s_sub_u32(L.SCNT, L.SCNT, 1)
         p.s_cmp_lg_u32(L.SCNT, 0)
-        p.s_cbranch_scc1(self.lbl("sqr_next"))
+        p.s_cbranch_scc1(self.lbl("sqr_next" + k))
         p.s_setpc_b64(L.RET)
 
-    def product(self):
-        """(a, b) staged <- (a, b) x (ra, rb), the pair read from global memory at VSRC.  In: v184 .. v191, s42 = n1, s44 = flags:
+    def product(self, per_key=False):
+        """(a, b) staged <- (a, b) x (ra, rb), the pair read from global memory at VSRC.  In: v184 .. v193, s42 = n1, s44 = flags:
         bit 0 = the pair has a b part, bit 2 = the result is also stored to global memory at VDST.  Slots as in kernels_basen.hpp
         (k_enc_basen): P0 rb * a -> U (registers), P1 ra * a with the digits out, P2 ra * b with the quotient term, + U."""
         L, p = self.L, self.p
-        p.label(f"zkp_bn_product_g{self.G}")
+        k = "_k" if per_key else ""
+        p.label(f"zkp_bn_product{k}_g{self.G}")
         p.s_waitcnt(vm=0, lgkm=0)
-        self.lane_setup()
+        self.lane_setup(per_key)
         p.s_bitcmp1_b32(L.SFLAGS, 0)
-        p.s_cbranch_scc0(self.lbl("prod_p1"))
-        # ---- P0: rb * a -> U
+        p.s_cbranch_scc0(self.lbl("prod_p1" + k))
+        # ---- P0: rb * a = HI R' + LO, exactly: LO -> U[], HI -> the group's scratch entry (it comes back into U[] once LO is spent)
         for j in range(0, W, 4):
             p.global_load(4, v(72 + j, 4), L.VSRC, L.pair_b + j * 4)
         p.v_mov_b32(L.VROW, L.VAREA)
-        self.set_qmask(False)
         p.s_waitcnt(vm=0, lgkm=0)
-        p.s_call_b64(L.RET2, self.lbl("mul_rows_zero"))
-        cy = L.SH(0)
-        for k in range(W):
-            if k:
-                p.v_lshl_add_u64(L.C(k), L.C(k), 0, cy)
-            p.v_and_b32(L.U(k), MASK, L.Clo(k))
-            p.v_lshrrev_b64(cy, LB, L.C(k))
+        p.s_call_b64(L.RET2, self.lbl("wide_rows"))
+        R0 = 156
+        state = {"first": True}
+        for base in range(0, W, CH):
+            self.chain_chunk(base, R0, state)
+            if base == 0:
+                p.v_mov_b32(L.TQ(0), v(R0))                         # limb 0 waits for the carry of the lane below
+            for j in range(0, CH, 4):
+                p.global_store(4, L.VSCR, v(R0 + j, 4), (base + j) * 4)
+            p.s_nop(1)
         self.carry_to_next_lane(L.TL(1))
-        p.v_add_u32(L.U(0), L.U(0), L.TL(1))
+        p.v_add_u32(L.TQ(0), L.TQ(0), L.TL(1))
+        p.global_store(1, L.VSCR, L.TQ(0), 0)
+        if per_key:
+            # the b side's additive block: LO + C3 of the lane's key (the columns are free between the row loops: C3 lands there)
+            self.load_c3(0)
+            p.s_waitcnt(vm=0)
+            for i in range(W):
+                p.v_add_u32(L.U(i), L.U(i), v(i))
+            p.s_branch(self.lbl("prod_p1_go" + k))
         # ---- P1: ra * a, digits out
-        p.label(self.lbl("prod_p1"))
+        p.label(self.lbl("prod_p1" + k))
+        if per_key:
+            self.load_c3(194)                                       # no cross product: the additive block is C3 alone
+            p.label(self.lbl("prod_p1_go" + k))
         for j in range(0, W, 4):
             p.global_load(4, v(72 + j, 4), L.VSRC, j * 4)
         p.v_mov_b32(L.VROW, L.VAREA)
         self.set_qmask(True)
         p.s_waitcnt(vm=0, lgkm=0)
         p.s_call_b64(L.RET2, self.lbl("mul_rows_zero"))
-        p.s_call_b64(L.RET2, self.lbl("fin_a_init_b"))
+        p.s_call_b64(L.RET2, self.lbl("fin_a_init_b" + k))
         p.s_bitcmp1_b32(L.SFLAGS, 2)
-        p.s_cbranch_scc0(self.lbl("prod_p2"))
+        p.s_cbranch_scc0(self.lbl("prod_p2" + k))
         # the a part as staged (the carry into limb 0 is in place: LDS operations of a wavefront execute in order) -> global memory
         p.v_add_u32(L.VT, L.VAREA, L.VGLO)
         for base in range(0, W, CH):
@@ -498,20 +658,33 @@ class Gen:
             for j in range(0, CH, 4):
                 p.global_store(4, L.VDST, v(144 + j, 4), (base + j) * 4)
             p.s_nop(1)
-        # ---- P2: ra * b + the quotient term (+ U)
-        p.label(self.lbl("prod_p2"))
+        # ---- P2: ra * b + the quotient term + LO (in the columns already), + HI at the end
+        p.label(self.lbl("prod_p2" + k))
+        p.s_bitcmp1_b32(L.SFLAGS, 0)
+        p.s_cbranch_scc0(self.lbl("prod_p2_rows" + k))
+        p.s_waitcnt(vm=0)                                           # (the stores of HI: same wavefront, same addresses)
+        for j in range(0, W, 4):
+            p.global_load(4, v(194 + j, 4), L.VSCR, j * 4)
+        p.label(self.lbl("prod_p2_rows" + k))
         p.v_add_u32(L.VROW, L.area_b, L.VAREA)
         self.set_qmask(False)
         p.s_call_b64(L.RET2, self.lbl("mul_rows_init"))
         p.s_call_b64(L.RET2, self.lbl("fin_b"))
         p.s_setpc_b64(L.RET)
 
-    def build(self):
+    def build(self, per_key=True):
+        """per_key=False: the shared-key entry points only (what k_enc_basen executes: the size that has to fit the instruction cache)"""
         self.sqr_run()
         self.product()
+        if per_key:
+            self.sqr_run(per_key=True)
+            self.product(per_key=True)
         self.rows("sqr")
         self.rows("mul")
+        self.rows_wide()
         self.fin_a_init_b()
+        if per_key:
+            self.fin_a_init_b_k()
         self.fin_b()
         self.double_a()
         return self.p
@@ -535,7 +708,7 @@ def clobber_text(G):
     """the registers the engine writes, as the clobber list of the C++ call sites (the per-lane inputs v184 .. v191 and the scalar inputs
     s41 / s42 / s44 are operands there, not clobbers)"""
     L = Layout(G)
-    vs = [f'"v{i}"' for i in range(0, 184)] + [f'"v{i}"' for i in range(192, L.LAST_VGPR + 1)]
+    vs = [f'"v{i}"' for i in range(0, 184)] + [f'"v{i}"' for i in range(194, L.LAST_VGPR + 1)]      # (v230 / v231: an input of the per-key flavour)
     ss = [f'"s{i}"' for i in range(30, L.LAST_SGPR + 1) if i not in (32, 33, 41, 42, 44)]
     out = ["// GENERATED by tools/bn_asm/gen.py: what the engine of kernels_basen_asm_g%d.inc writes\n" % G]
     regs = vs + ss + ['"vcc"', '"scc"', '"memory"']
@@ -550,7 +723,7 @@ def inc_path(G):
 
 
 if __name__ == "__main__":
-    for G in (2,):
+    for G in (2, 4):
         prog, text = inc_text(G)
         with open(inc_path(G), "w") as f:
             f.write(text)

@@ -47,7 +47,7 @@ def fmt(o):
     if isinstance(o, str):
         return o
     k, i, n = o
-    if k in ("exec", "vcc", "off"):
+    if k in ("exec", "vcc", "off", "vcc_lo", "vcc_hi"):
         return k
     return f"{k}{i}" if n == 1 else f"{k}[{i}:{i + n - 1}]"
 
@@ -116,9 +116,17 @@ class Program:
     def v_lshl_add_u64(self, d, a, sh, c): self._e("v_lshl_add_u64", (d, a, sh, c), rd=(a, c), wr=(d,))
     def v_add3_u32(self, d, a, b, c): self._e("v_add3_u32", (d, a, b, c), rd=(a, b, c), wr=(d,))
 
-    def v_mov_b32_dpp(self, d, a, ctrl):
-        """ctrl: 'quad_perm:[0,0,2,2]' | 'row_shl:1' | 'row_shr:1' (all rows and banks, invalid source lanes read 0)"""
-        self._e("v_mov_b32_dpp", (d, a), ctrl + " row_mask:0xf bank_mask:0xf bound_ctrl:1", rd=(a,), wr=(d,), kind="dpp")
+    def v_mov_b32_dpp(self, d, a, ctrl, bank_mask=0xF):
+        """ctrl: 'quad_perm:[0,0,2,2]' | 'row_shl:1' | 'row_shr:1' (all rows, invalid source lanes read 0); bank_mask: the BANKS of every
+        row of 16 lanes that are written — bit j = lanes 4 j .. 4 j + 3 of the row (NOT lane j of every quad: the first build of the wide
+        cross product read it that way, the lane model agreed with it and the GPU did not) —, the others keep what they hold"""
+        self._e("v_mov_b32_dpp", (d, a), ctrl + f" row_mask:0xf bank_mask:{hex(bank_mask)} bound_ctrl:1", rd=(a,) if bank_mask == 0xF else (a, d), wr=(d,), kind="dpp")
+
+    def v_cndmask_b32(self, d, a, b):
+        """d = vcc ? b : a"""
+        self._e("v_cndmask_b32_e32", (d, a, b, VCC), rd=(a, b), wr=(d,))
+
+    def s_lshl_b64(self, d, a, sh): self._e("s_lshl_b64", (d, a, sh), rd=(a,), wr=(d,), kind="salu")
 
     # LDS
     def ds_read(self, bits, d, addr, offset=0):
@@ -231,6 +239,8 @@ class Wave:
             return self.s[i] | (self.s[i + 1] << 32)
         if k == "exec":
             return self.exec
+        if k == "vcc":
+            return self.vcc
         raise ValueError(o)
 
     def wr32(self, o, lane, x):
@@ -345,10 +355,22 @@ def run(prog, wave, entry, max_steps=10_000_000, check=True):
                 x = (wave.rd64(o[1], l) << wave.rd32(o[2], l)) + wave.rd64(o[3], l)
                 assert x <= M64, f"#{pc - 1} {i.text()}: 64-bit add overflow"
                 wave.wr64(o[0], l, x)
+        elif op == "v_cndmask_b32_e32":
+            for l in wave.lanes(): wave.wr32(o[0], l, wave.rd32(o[2], l) if (wave.vcc >> l) & 1 else wave.rd32(o[1], l))
+        elif op == "s_lshl_b64":
+            x = (wave.rd64(o[1], 0) << (wave.rd32(o[2], 0) & 63)) & M64
+            if o[0][0] == "vcc":
+                wave.vcc = x
+            else:
+                wave.s[o[0][1]], wave.s[o[0][1] + 1] = x & M32, x >> 32
+            wave.scc = int(x != 0)
         elif op == "v_mov_b32_dpp":
             ctrl = i.mods.split(" row_mask")[0]
+            banks = int(i.mods.split("bank_mask:")[1].split()[0], 16)
             src = [wave.v[o[1][1]][l] for l in range(64)]
             for l in wave.lanes():
+                if not (banks >> ((l & 15) >> 2)) & 1:
+                    continue
                 sl = dpp_source(ctrl, l)
                 # (a source lane that is disabled by exec reads 0 under bound_ctrl as well)
                 wave.wr32(o[0], l, src[sl] if sl is not None and (wave.exec >> sl) & 1 else 0)
@@ -407,11 +429,18 @@ def run(prog, wave, entry, max_steps=10_000_000, check=True):
                 keep = vms[len(vms) - vm:] if vm else []
                 pending = [p for p in pending if not p[0].startswith("vm_")] + keep
         elif op == "s_mov_b32":
-            wave.s[o[0][1]] = wave.rd32(o[1], 0)
+            if o[0][0] == "vcc_lo":
+                wave.vcc = (wave.vcc & ~M32) | wave.rd32(o[1], 0)
+            elif o[0][0] == "vcc_hi":
+                wave.vcc = (wave.vcc & M32) | (wave.rd32(o[1], 0) << 32)
+            else:
+                wave.s[o[0][1]] = wave.rd32(o[1], 0)
         elif op == "s_mov_b64":
             x = wave.rd64(o[1], 0)
             if o[0][0] == "exec":
                 wave.exec = x
+            elif o[0][0] == "vcc":
+                wave.vcc = x
             else:
                 wave.s[o[0][1]], wave.s[o[0][1] + 1] = x & M32, x >> 32
         elif op == "s_add_u32":

@@ -123,6 +123,7 @@ EXPORTS = {
     "zkp_multi_ctx": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "zkp_multi_last_error_string": (C.c_char_p, [C.c_void_p]),
     "zkp_multi_last_timing": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "zkp_multi_last_phases": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "zkp_ctx_create_on_stream": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "zkp_ctx_set_geometry": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_ctx_last_geometry": (C.c_int32, [C.c_void_p]),
@@ -228,6 +229,15 @@ class MultiContext:
             ms, lo, hi = C.c_double(), C.c_uint64(), C.c_uint64()
             self.check(self.lib.zkp_multi_last_timing(self.h, i, C.byref(ms), C.byref(lo), C.byref(hi)))
             out.append((ms.value, lo.value, hi.value))
+        return out
+
+    def last_phases(self):
+        """[(compute_ms, gather_ms)] per device context for the most recent batch call (HIP events on each context's stream)"""
+        out = []
+        for i in range(self.size()):
+            cm, gm = C.c_double(), C.c_double()
+            self.check(self.lib.zkp_multi_last_phases(self.h, i, C.byref(cm), C.byref(gm)))
+            out.append((cm.value, gm.value))
         return out
 
     def set_gather(self, mode: int):
