@@ -119,16 +119,19 @@ def executed_lane_mads_per_enc(n: int, n_bits: int, verify: bool):
     return L29 * (L29 // 36) * (54.5 * sq + 72.0 * (mul + (9 if verify else 5)))      # L sub-steps x L/36 lanes x multiply-adds per lane per sub-step
 
 
-def executed_lane_mads_per_enc_basen(n: int, n_bits: int):
+def executed_lane_mads_per_enc_basen(n: int, n_bits: int, engine: bool = True):
     """lane multiply-adds k_enc_basen EXECUTES for one Enc (csrc/kernels_basen.hpp; 29-bit limbs, Lh = 72 / 144 limbs per n-sized integer):
-    a squaring = the a side at 54.5 + the b side at 72 multiply-adds per lane per sub-step, any other base-n product = three n-sized
-    products at 72; Lh more per b side for its initial columns.  Products besides the script: to the Montgomery domain (2 n-sized), the
-    final one by (1, m) (3).  The canonicalisation (k_basen_finish: ~5 n-sized products per Enc) and the Mask rows' k_expected run in
-    kernels of their own inside the same timed region; they are not counted here."""
+    a squaring = the a side at 54.5 + the b side at 72 multiply-adds per lane per sub-step; any other base-n product = three n-sized
+    products at 72 under the compiled bodies, 2.5 under the assembler engine (engine=True: the cross product rb * a without a reduction,
+    36 per lane per sub-step — tools/bn_asm/gen.py rows_wide); Lh more per b side for its initial columns.  Products besides the script:
+    to the Montgomery domain (2 n-sized: the pair (r, 0) has no b part), the final one by (1, m).  The canonicalisation (k_basen_finish:
+    ~5 n-sized products per Enc) and the Mask rows' k_expected run in kernels of their own inside the same timed region; they are not
+    counted here."""
     Lh = 72 if n_bits <= 2048 else 144
     per_product = Lh * (Lh // 36) * 72.0                      # one n-sized product: Lh sub-steps x Lh/36 lanes x 72
+    base_n_product = (2.5 * per_product + 2 * Lh) if engine else (3.0 * per_product + Lh)      # (engine: the high half of the cross product joins the result by Lh multiply-adds by 1)
     sq, mul = sliding_ladder_products(n)
-    return sq * (Lh * (Lh // 36) * 54.5 + per_product + Lh) + mul * (3 * per_product + Lh) + 5 * per_product + 2 * Lh
+    return sq * (Lh * (Lh // 36) * 54.5 + per_product + Lh) + mul * base_n_product + (2 * per_product + Lh) + base_n_product
 
 
 HBM_PEAK_GBS = 8000.0
@@ -651,7 +654,7 @@ def main():
     if basen:
         roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc_basen<{bn_lanes}> (Enc in base-n form: {bn_lanes} lanes x 36 limbs per 2048-bit half, {64 // bn_lanes} Enc per wavefront; sliding-window ladder; "
                                 "canonicalisation + comparison in k_basen_finish, Mask-row products in k_expected, inside the same timed region)", clk.summary(),
-                                executed_lane_mads_per_enc_basen(n, n_bits), basen=True)
+                                executed_lane_mads_per_enc_basen(n, n_bits, bool(zkp.load().zkp_diag_basen_engine())), basen=True)
     else:
         roofline = enc_roofline(kms, launches, modexps, n_bits, f"k_enc<{144 // lpl}, true> (fused Enc-and-compare; {144 // lpl} lanes x {lpl} limbs per 4096-bit integer; sliding-window ladder, squarings at 3/4 of a product)", clk.summary(), executed_lane_mads_per_enc(n, n_bits, True))
     ms_per_step = 1e3 * dt / args.steps
@@ -916,15 +919,19 @@ def other_configs(env):
         pb1 = pb.slice(1, 2).to(None); wt1 = wt.slice(1, 2).to(None)
         v1 = np.zeros(1, np.uint8)
 
-        def one_proof():
+        def one_proof(calls=None):
+            """`calls` timed prove + verify calls of ONE proof -> the best call's record, and min / median / max of each leg over all calls
+            (the verify of round 5 was bimodal — where the transcript-hash wavefront landed —: the spread is part of the result)"""
+            calls = max(1, calls or reps)
             ctx.range_ni_prove(pb1.struct(), wt1.struct(), None, None, None, device=False)      # warm-up
-            best = None
-            for _ in range(max(1, reps)):
+            best, pms, vms = None, [], []
+            for _ in range(calls):
                 t0 = time.perf_counter()
                 ctx.range_ni_prove(pb1.struct(), wt1.struct(), None, None, None, device=False)
                 t1 = time.perf_counter()
                 ctx.range_ni_verify(pb1.struct(), v1, device=False)
                 t2 = time.perf_counter()
+                pms.append(1e3 * (t1 - t0)); vms.append(1e3 * (t2 - t1))
                 rec = {"prove_ms": 1e3 * (t1 - t0), "verify_ms": 1e3 * (t2 - t1), "prove_plus_verify_ms": 1e3 * (t2 - t0), "accepted": bool(v1[0] == 1),
                        "limbs_per_lane": ctx.last_geometry(),
                        "enc_kernel": (("k_enc_basen_r2l5 (FIVE wavefronts per Enc, one per role of the right-to-left base-n ladder: 36 lanes x 2 limbs per n-sized integer, quotient digits wave-uniform in "
@@ -933,12 +940,14 @@ def other_configs(env):
                                       if ctx.r2l_last() else ("k_enc<16, false, true> (pair ladder on the n^2-sized product: 2058 products of 144 sub-steps)" if ctx.last_geometry() == 9 else "k_enc<4, true>"))}
                 if best is None or rec["prove_plus_verify_ms"] < best["prove_plus_verify_ms"]:
                     best = rec
-            best["reps"] = max(1, reps)
+            best["reps"] = calls
+            stats = lambda x: {"min": min(x), "median": statistics.median(x), "max": max(x), "max_over_min": max(x) / min(x), "calls": len(x)}
+            best["prove_ms_stats"], best["verify_ms_stats"] = stats(pms), stats(vms)
             return best
 
         ctx.set_geometry(0)                      # automatic geometry: a call this small runs on the latency engine (W = 9) when it is loaded
         try:
-            rec0 = one_proof()
+            rec0 = one_proof(max(20, reps))      # (20 calls: min / median / max of each leg are part of the record)
         finally:
             ctx.set_geometry(lpl)                # the batch legs are pinned to the throughput engine
         rec0["on_the_throughput_engine"] = one_proof()
@@ -961,7 +970,7 @@ def other_configs(env):
             ctx.set_key_cache(True); ctx.set_geometry(lpl)
         rec0["key_constants"] = "kept across calls (zkp_diag_set_key_cache; DESIGN.md section 3 item 13): prove_ms / verify_ms are calls under a key the ctx has seen"
         ok = ok and rec0["accepted"] and rec0["on_the_throughput_engine"]["accepted"] and rec0["latency_engine_one_wavefront_per_enc"]["accepted"] and rec0["latency_engine_pair_ladder_on_n2"]["accepted"] and rec0["without_the_key_constants_cache"]["accepted"]
-        other["configs[0] one RangeProofNi, n=2048, host buffers (GPU latency, best of reps)"] = rec0
+        other["configs[0] one RangeProofNi, n=2048, host buffers (GPU latency: best call, and min / median / max over 20 calls)"] = rec0
 
     # ---- configs[3]: 65536 NiCorrectKeyProof verifies, n = 2048, 65536 distinct (pseudo-)moduli cut into `world` blocks of keys:
     # pure throughput shape, every record is expected to be rejected (random sigma); accept parity: tests/test_gpu_fullsize.py

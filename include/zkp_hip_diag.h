@@ -31,6 +31,12 @@ int32_t zkp_diag_basen(zkp_ctx* ctx, uint32_t n_bits, const uint32_t* n, int32_t
  * (0: there was none), out_qualified: 1 when the key passed the form's set-up (else the n^2-sized kernel did the work). */
 int32_t zkp_diag_basen_last(zkp_ctx* ctx, int32_t* out_lanes, uint32_t* out_qualified);
 
+/* How this library's base-n kernels of the throughput engine were built: 1 = their squarings and products run through the fixed-register
+ * assembler engine (csrc/kernels_basen_asm_g*.inc: ONE product body, the cross product of a base-n product without a reduction — 2.5
+ * instead of 3 n-sized products per product modulo n^2), 0 = the compiled bodies (-DZKP_BN_ASM=0, A/B builds; the other geometries).
+ * bench.py prices the EXECUTED multiply-adds of a launch by it. */
+int32_t zkp_diag_basen_engine(void);
+
 /* Which Paillier launches of this ctx run in base-n form (csrc/kernels_basen.hpp) and which on the n^2-sized kernels.  The product's
  * rule is AUTO; the other values exist for A/B measurements and for the parity tests, which pin BOTH forms against the oracle at sizes
  * where AUTO would only ever pick one.  $ZKP_BASEN (0 | shared | always) presets the value when a ctx is created — the environment is

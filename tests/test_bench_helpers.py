@@ -80,11 +80,17 @@ def test_base_n_work_model_and_its_roofline_identity():
     assert abs(bench.enc_limb_macs_basen(2048) / 4.396e7 - 1) < 1e-3
     assert abs(bench.enc_limb_macs_basen(2048) / bench.enc_limb_macs(2048) - 0.5438) < 1e-3
     assert abs(bench.enc_limb_macs_basen(4096) / 3.503e8 - 1) < 1e-3
-    ex = bench.executed_lane_mads_per_enc_basen(synth.BENCH_N, 2048)
+    ex = bench.executed_lane_mads_per_enc_basen(synth.BENCH_N, 2048, engine=False)      # the compiled bodies (rounds 4 - 5; -DZKP_BN_ASM=0)
     sq, mul = bench.sliding_ladder_products(synth.BENCH_N)
     # a squaring: 72 sub-steps x 2 lanes x (54.5 + 72) multiply-adds + 72 for the b side's columns; a product: three n-sized products
     assert ex == sq * (72 * 2 * 126.5 + 72) + mul * (3 * 72 * 2 * 72.0 + 72) + 5 * 72 * 2 * 72.0 + 2 * 72
     assert 4.7e7 < ex < 4.8e7 and ex < bench.executed_lane_mads_per_enc(synth.BENCH_N, 2048, True) * 0.62
+    # the assembler engine (round 6): the cross product of a base-n product without a reduction — 2.5 n-sized products per product
+    eng = bench.executed_lane_mads_per_enc_basen(synth.BENCH_N, 2048)
+    assert eng == ex - (mul + 1) * (0.5 * 72 * 2 * 72.0 - 72) and 0.96 < eng / ex < 0.97
+    # ... which is what the lane model counts when it EXECUTES the generated instructions (tests/test_bn_asm.py; a wave instruction is
+    # 64 lanes = 32 Enc x 2 lanes): 2 x (1962 + 2592) + 36 multiply-add instructions per squaring, 5 x 2 x 1296 + 72 per product
+    assert 72 * 2 * 126.5 + 72 == 2 * (2 * (1962 + 2592) + 36) and 2.5 * 72 * 2 * 72.0 + 2 * 72 == 2 * (5 * 2 * 1296 + 72)
     for kernel in ("k_enc_basen<2>", "k_enc_basen<4>"):
         per, src = bench.pmc_traffic_per_modexp(kernel)
         assert per and per > 1e5 and os.path.exists(os.path.join(H.ROOT, src)), kernel

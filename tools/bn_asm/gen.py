@@ -101,10 +101,11 @@ class Layout:
     VSCR = v(192, 2)     # product: global address of this lane's block of the group's scratch entry (the high half of the wide cross product)
     @staticmethod
     def U(k): return v(194 + k)
-    LAST_VGPR = 229
+    LAST_VGPR = 232
     # the per-key flavour (k_enc_basen_keys: every group under a key of its own): no constant block in LDS —
     VN1 = v(187)         # n1 of this lane's key (in place of VCST)
     VKEY = v(230, 2)     # global address of this lane's block of M~ in its key's record (BnConst: C3 one integer behind)
+    VMASK = v(232)       # the limb mask 2^29 - 1 (operand of v_and_b32_dpp: FUSE_AND_DPP)
 
     # scalar registers
     RET = s(30, 2)       # return address of the entry point
@@ -128,12 +129,18 @@ def take_sqr(t, k):
     return 2 if ((1 <= d < H) or (d == H and t < H)) else 0
 
 
+# (cross-lane move, limb mask) as ONE v_and_b32_dpp in the row loops of the products on M~: 2 of the 8 bookkeeping instructions of a
+# sub-step.  The compiled kernels tried this in round 4 (ZKP_AND_DPP) and gained nothing at the power cap; A/B on the engine: profiles/r06/.
+FUSE_AND_DPP = os.environ.get("ZKP_BN_ASM_FUSE", "1") != "0"
+
+
 class Gen:
-    def __init__(self, G):
+    def __init__(self, G, fuse=None):
         self.L = Layout(G)
         self.G = G
         self.p = Program()
         self.uid = 0
+        self.fuse = FUSE_AND_DPP if fuse is None else fuse
 
     def lbl(self, name):
         return f".Lzkp_bn{self.G}_{name}"
@@ -191,11 +198,14 @@ class Gen:
             assert prods[0][0] == 0
             for n_, (col, k, m) in enumerate(prods):
                 mad(col, L.A(k), bmul(0, m), fresh)
-                if n_ == 3:
+                if n_ == 3 and not self.fuse:
                     p.v_and_b32(L.TQ(0), MASK, L.Clo(0))
             for col in sorted(fresh):                             # columns a squaring does not touch at position 0
                 p.v_mov_b64(L.C(col), 0)
-            p.v_mov_b32_dpp(L.QD(0), L.TQ(0), L.bcast)
+            if self.fuse:
+                p.v_and_b32_dpp(L.QD(0), L.Clo(0), L.VMASK, L.bcast)
+            else:
+                p.v_mov_b32_dpp(L.QD(0), L.TQ(0), L.bcast)
             if not mul:
                 p.v_lshlrev_b32(L.B2(1), 1, L.BQ(1))
             for (col, k, m) in self.a_products(kind, 1):          # the product of position 1 that lands in column 1: block 1's digit waits for it
@@ -241,21 +251,35 @@ class Gen:
             def carry(): p.v_lshl_add_u64(L.C(tm + 1), L.C(tm + 1), 0, L.SH(i2))
 
             def pass_down():
-                if tail or (settle and not fresh_mad):
-                    p.v_mov_b32_dpp(L.Clo(tm), L.TL(i2), "row_shl:1")
+                direct = tail or (settle and not fresh_mad)
+                dst = L.Clo(tm) if direct else L.X(i2)
+                if self.fuse:
+                    p.v_and_b32_dpp(dst, L.Clo(tm), L.VMASK, "row_shl:1")
+                else:
+                    p.v_mov_b32_dpp(dst, L.TL(i2), "row_shl:1")
+                if direct:
                     p.v_mov_b32(L.Chi(tm), 0)
                 else:
-                    p.v_mov_b32_dpp(L.X(i2), L.TL(i2), "row_shl:1")
                     fresh[tm % W] = L.XZ(i2)
 
             def digit_mask(): p.v_and_b32(L.TQ(i2), MASK, L.Clo(t))
-            def digit(): p.v_mov_b32_dpp(L.QD(t % W), L.TQ(i2), L.bcast)
+
+            def digit():
+                if self.fuse:
+                    p.v_and_b32_dpp(L.QD(t % W), L.Clo(t), L.VMASK, L.bcast)
+                else:
+                    p.v_mov_b32_dpp(L.QD(t % W), L.TQ(i2), L.bcast)
 
             if not tail and not mul and t == W:
                 p.v_lshlrev_b32(L.B2(t), 1, L.BQ(t))
-            seq = lead + ["f", "f", finish_mask, finish_shift, "f", "f", "f", carry, pass_down, "f", "f", "f"]
-            if not tail:
-                seq += [digit_mask, fresh_mad if fresh_mad else "f", "f", "f", digit]
+            if self.fuse:
+                seq = lead + ["f", "f", finish_shift, "f", "f", "f", carry, pass_down, "f", "f", "f"]
+                if not tail:
+                    seq += [fresh_mad if fresh_mad else "f", "f", digit]
+            else:
+                seq = lead + ["f", "f", finish_mask, finish_shift, "f", "f", "f", carry, pass_down, "f", "f", "f"]
+                if not tail:
+                    seq += [digit_mask, fresh_mad if fresh_mad else "f", "f", "f", digit]
             tq = t % W
             if not tail and tq % 4 == 0:
                 nxt = tq // 4 + 1                                  # the quad after this one; behind a row's ninth comes the next row's first
@@ -524,6 +548,7 @@ class Gen:
                 p.ds_read(128, v(108 + j, 4), L.VT, L.mt_off + j * 4)
         p.v_mov_b32(L.Z(0), 0)
         p.v_mov_b32(L.Z(1), 0)
+        p.v_mov_b32(L.VMASK, MASK)
 
     def load_c3(self, first_reg):
         """per-key flavour: this lane's block of its key's C3 -> 36 registers from `first_reg`"""
@@ -708,7 +733,7 @@ def clobber_text(G):
     """the registers the engine writes, as the clobber list of the C++ call sites (the per-lane inputs v184 .. v191 and the scalar inputs
     s41 / s42 / s44 are operands there, not clobbers)"""
     L = Layout(G)
-    vs = [f'"v{i}"' for i in range(0, 184)] + [f'"v{i}"' for i in range(194, L.LAST_VGPR + 1)]      # (v230 / v231: an input of the per-key flavour)
+    vs = [f'"v{i}"' for i in range(0, 184)] + [f'"v{i}"' for i in range(194, L.LAST_VGPR + 1) if i not in (230, 231)]      # (v230 / v231: an input of the per-key flavour)
     ss = [f'"s{i}"' for i in range(30, L.LAST_SGPR + 1) if i not in (32, 33, 41, 42, 44)]
     out = ["// GENERATED by tools/bn_asm/gen.py: what the engine of kernels_basen_asm_g%d.inc writes\n" % G]
     regs = vs + ss + ['"vcc"', '"scc"', '"memory"']

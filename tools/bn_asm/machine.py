@@ -122,6 +122,10 @@ class Program:
         cross product read it that way, the lane model agreed with it and the GPU did not) —, the others keep what they hold"""
         self._e("v_mov_b32_dpp", (d, a), ctrl + f" row_mask:0xf bank_mask:{hex(bank_mask)} bound_ctrl:1", rd=(a,) if bank_mask == 0xF else (a, d), wr=(d,), kind="dpp")
 
+    def v_and_b32_dpp(self, d, a, b, ctrl):
+        """d = DPP(a) & b — one instruction for (cross-lane move, limb mask); b is a register"""
+        self._e("v_and_b32_dpp", (d, a, b), ctrl + " row_mask:0xf bank_mask:0xf bound_ctrl:1", rd=(a, b), wr=(d,), kind="dpp")
+
     def v_cndmask_b32(self, d, a, b):
         """d = vcc ? b : a"""
         self._e("v_cndmask_b32_e32", (d, a, b, VCC), rd=(a, b), wr=(d,))
@@ -364,6 +368,13 @@ def run(prog, wave, entry, max_steps=10_000_000, check=True):
             else:
                 wave.s[o[0][1]], wave.s[o[0][1] + 1] = x & M32, x >> 32
             wave.scc = int(x != 0)
+        elif op == "v_and_b32_dpp":
+            ctrl = i.mods.split(" row_mask")[0]
+            src = [wave.v[o[1][1]][l] for l in range(64)]
+            for l in wave.lanes():
+                sl = dpp_source(ctrl, l)
+                x = src[sl] if sl is not None and (wave.exec >> sl) & 1 else 0
+                wave.wr32(o[0], l, x & wave.rd32(o[2], l))
         elif op == "v_mov_b32_dpp":
             ctrl = i.mods.split(" row_mask")[0]
             banks = int(i.mods.split("bank_mask:")[1].split()[0], 16)

@@ -20,6 +20,8 @@ sizes = [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 8
 LAT = ctx.latency_limbs_per_lane()          # 9 as shipped; $ZKP_HIP_LAT_LIB may name another build of the secondary engine (A/B runs)
 MID = ctx.mid_limbs_per_lane()
 FAMILIES = (("w36_n2", 36, "n2"), ("w36_basen", 36, "basen")) + ((("w18_basen", 18, "basen"),) if MID == 18 else ()) + ((f"w{LAT}_n2", LAT, "n2"), (f"w{LAT}_basen", LAT, "basen"), ("auto", 0, "auto"))
+if os.environ.get("ZKP_SWEEP_AUTO_ONLY") == "1":      # the library's own choice only (A/B of whole engine sets: $ZKP_HIP_MID_LIB=/nonexistent removes the mid engine)
+    FAMILIES = (("auto", 0, "auto"),)
 
 
 def best_of(fn, reps=3):
@@ -36,7 +38,7 @@ for B in sizes:
     ctx.set_geometry(0); ctx.set_enc_form("auto")
     ctx.paillier_enc(2048, B, pb.n, 0, wt.x, wt.r, pb.ciphertext); ctx.synchronize()
     v = torch.zeros(B, dtype=torch.uint8, device=dev)
-    rec = {"B": B}
+    rec = {"B": B, "mid_engine": MID}
     for name, geom, form in FAMILIES:
         if geom == LAT and B > 256 or (name == "w36_basen" and B < 8):
             continue

@@ -67,6 +67,7 @@ EXPORTS = {
     "zkp_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "zkp_backend_name": (C.c_char_p, []),
     "zkp_build_limbs_per_lane": (C.c_int32, []),
+    "zkp_diag_basen_engine": (C.c_int32, []),
     "zkp_last_error_string": (C.c_char_p, [C.c_void_p]),
     "zkp_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "zkp_ctx_synchronize": (C.c_int32, [C.c_void_p]),

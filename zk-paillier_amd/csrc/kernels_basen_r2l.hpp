@@ -31,6 +31,9 @@
 #include <utility>
 #include "kernels_basen.hpp"
 
+#ifndef ZKP_R2L_PRIO
+#define ZKP_R2L_PRIO 3
+#endif
 namespace zkp {
 
 #if ZKP_W == 9
@@ -636,6 +639,9 @@ __global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_
   using BC = BnConst<8>;
   constexpr int L = LIMBS, E = 2 * L;
   if (!bcst[BC::OFF_OK]) return;
+  // The five role wavefronts are ONE dependent chain in lockstep: a stranger on one of their SIMDs — the transcript-hash wavefront of a
+  // one-proof verify, which runs beside this launch — holds all five up.  They issue ahead of it (ZKP_R2L_PRIO, A/B: profiles/r06/one_proof/).
+  __builtin_amdgcn_s_setprio(ZKP_R2L_PRIO);
   __shared__ __align__(16) uint32_t lds[LDS_WORDS];
   __shared__ unsigned long long claim;
   const int tid = threadIdx.x, lane = tid & 63, gl = lane;

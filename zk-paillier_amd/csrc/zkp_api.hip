@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <new>
@@ -859,6 +860,11 @@ extern "C" int32_t zkp_ctx_release_staging(zkp_ctx* c) try {
 
 extern "C" const char* zkp_backend_name(void) { return "hip-gfx950"; }
 extern "C" int32_t zkp_build_limbs_per_lane(void) { return W; }
+#if ZKP_HAS_BASEN
+extern "C" int32_t zkp_diag_basen_engine(void) { return (ZKP_BN_ASM && W == 36) ? 1 : 0; }
+#else
+extern "C" int32_t zkp_diag_basen_engine(void) { return 0; }
+#endif
 extern "C" const char* zkp_last_error_string(zkp_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 extern "C" void* zkp_ctx_stream(zkp_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int32_t zkp_ctx_synchronize(zkp_ctx* c) try {
