@@ -7,7 +7,7 @@
 #      ZKP_BASEN=0 in the environment brings the n^2-sized k_enc<4, true> / k_enc<8, true> / k_enc<4, false> back for a comparison pass)
 #   3. aggregation with the calibrated factors and the effective clock -> gpurun_out/pmc_${ROUND}_<tag>/*.json (copy into profiles/)
 TAG=${1:-final}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=gpurun_out/pmc_${ROUND}_$TAG
 mkdir -p $OUT
 for shape in tabread enc2048full enc2048keys enc4096b1024 ck2048full; do

@@ -516,23 +516,25 @@ class Gen:
         p.s_setpc_b64(L.RET2)
 
     def double_a(self):
-        """A[] <- 2 A[], limbs normalised (kernels_basen.hpp bn_double)."""
+        """A[] <- 2 A[], limbs normalised again (kernels_basen.hpp bn_double) — WITHOUT a carry chain: 2 a_k is even, so
+        (2 a_k mod 2^29) + carry_in < 2^29 whatever the carry: a carry never ripples, and the carry out of limb k is just the top bit(s) of
+        a_k: R_k = ((a_k << 1) & MASK) + (a_(k-1) >> 28).  Three independent instructions per limb instead of four dependent ones (a lone
+        wavefront in a dependent chain leaves its SIMD half idle).  A limb that arrives almost normalised (limb 0 of a lane's block after
+        the carry of the lane below: < 2^29 + 2^8) hands up 2 or 3 instead of 0 or 1: the result stays within the same tolerance."""
         L, p = self.L, self.p
         p.label(self.lbl("double_a"))
-        t0, t1 = L.TL(0), L.TL(1)
-        for k in range(W):
-            if k == 0:
-                p.v_lshlrev_b32(t0, 1, L.A(0))
-            else:
-                p.v_lshrrev_b32(t1, LB, t0)
-                p.v_lshlrev_b32(t0, 1, L.A(k))
-                p.v_add_u32(t0, t0, t1)
-            p.v_and_b32(L.A(k), MASK, t0)
-        p.v_lshrrev_b32(t1, LB, t0)
-        p.s_nop(1)
-        p.v_mov_b32_dpp(t0, t1, "row_shr:1")
-        p.v_and_b32(t0, t0, L.VGLM)
-        p.v_add_u32(L.A(0), L.A(0), t0)
+        t = [L.TL(0), L.TL(1), L.TQ(0), L.TQ(1)]
+        # the carry into limb 0 comes from the top limb of the lane below (before that limb is overwritten)
+        p.v_lshrrev_b32(L.SHlo(0), LB - 1, L.A(W - 1))
+        for k in range(W - 1, 0, -1):                               # top down: limb k reads limb k-1 before it is rewritten
+            tk = t[k & 3]
+            p.v_lshrrev_b32(tk, LB - 1, L.A(k - 1))
+            p.v_and_b32(L.A(k), MASK >> 1, L.A(k))
+            p.v_lshl_add_u32(L.A(k), L.A(k), 1, tk)
+        p.v_mov_b32_dpp(L.TL(0), L.SHlo(0), "row_shr:1")
+        p.v_and_b32(L.A(0), MASK >> 1, L.A(0))
+        p.v_and_b32(L.TL(0), L.TL(0), L.VGLM)
+        p.v_lshl_add_u32(L.A(0), L.A(0), 1, L.TL(0))
         p.s_setpc_b64(L.RET2)
 
     def lane_setup(self, per_key=False):
@@ -698,20 +700,21 @@ class Gen:
         p.s_setpc_b64(L.RET)
 
     def build(self, per_key=True):
-        """per_key=False: the shared-key entry points only (what k_enc_basen executes: the size that has to fit the instruction cache)"""
+        """per_key=False: the shared-key entry points only (what k_enc_basen executes: the size that has to fit the instruction cache).
+        Layout: [shared-key entry points and their fin_a_init_b] [the row loops, fin_b, double_a: both flavours] [per-key entry points and
+        theirs] — what either kernel executes is one contiguous stretch of the text."""
         self.sqr_run()
         self.product()
-        if per_key:
-            self.sqr_run(per_key=True)
-            self.product(per_key=True)
+        self.fin_a_init_b()
         self.rows("sqr")
         self.rows("mul")
         self.rows_wide()
-        self.fin_a_init_b()
-        if per_key:
-            self.fin_a_init_b_k()
         self.fin_b()
         self.double_a()
+        if per_key:
+            self.fin_a_init_b_k()
+            self.sqr_run(per_key=True)
+            self.product(per_key=True)
         return self.p
 
 

@@ -114,6 +114,7 @@ class Program:
     def v_mov_b64(self, d, a): self._e("v_mov_b64_e32", (d, a), rd=(a,), wr=(d,))
     def v_lshrrev_b64(self, d, sh, a): self._e("v_lshrrev_b64", (d, sh, a), rd=(a,), wr=(d,))
     def v_lshl_add_u64(self, d, a, sh, c): self._e("v_lshl_add_u64", (d, a, sh, c), rd=(a, c), wr=(d,))
+    def v_lshl_add_u32(self, d, a, sh, c): self._e("v_lshl_add_u32", (d, a, sh, c), rd=(a, c), wr=(d,))          # (a << sh) + c
     def v_add3_u32(self, d, a, b, c): self._e("v_add3_u32", (d, a, b, c), rd=(a, b, c), wr=(d,))
 
     def v_mov_b32_dpp(self, d, a, ctrl, bank_mask=0xF):
@@ -201,7 +202,7 @@ class Program:
         for i in self.ins:
             if i.kind in ("label", "comment"):
                 continue
-            big = i.op in ("v_mad_u64_u32", "v_lshrrev_b64", "v_lshl_add_u64", "v_add3_u32") or i.kind in ("dpp", "ds_read", "ds_write", "vm_read", "vm_write")
+            big = i.op in ("v_mad_u64_u32", "v_lshrrev_b64", "v_lshl_add_u64", "v_add3_u32", "v_lshl_add_u32") or i.kind in ("dpp", "ds_read", "ds_write", "vm_read", "vm_write")
             lit = any(isinstance(o, int) and not (-16 <= o <= 64) for o in i.ops)
             n += 8 if (big or lit) else 4
         return n
@@ -338,6 +339,8 @@ def run(prog, wave, entry, max_steps=10_000_000, check=True):
             for l in wave.lanes(): wave.wr32(o[0], l, wave.rd32(o[1], l) & wave.rd32(o[2], l))
         elif op == "v_add_u32_e32":
             for l in wave.lanes(): wave.wr32(o[0], l, wave.rd32(o[1], l) + wave.rd32(o[2], l))
+        elif op == "v_lshl_add_u32":
+            for l in wave.lanes(): wave.wr32(o[0], l, (wave.rd32(o[1], l) << (wave.rd32(o[2], l) & 31)) + wave.rd32(o[3], l))
         elif op == "v_add3_u32":
             for l in wave.lanes(): wave.wr32(o[0], l, wave.rd32(o[1], l) + wave.rd32(o[2], l) + wave.rd32(o[3], l))
         elif op == "v_sub_u32_e32":

@@ -1,10 +1,11 @@
 #!/bin/bash
 # everything the round's evidence is made of, on one box: bash tools/dev/run_final_evidence.sh [tag]
 TAG=${1:-final}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 R=$PWD
-timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/${ROUND}_pytest_gpu_$TAG.txt
-tail -3 gpurun_out/${ROUND}_pytest_gpu_$TAG.txt
+# (the whole output with every duration: profiles/${ROUND}/pytest_gpu_durations.txt is what tests/test_gpu_suite_budget.py reads)
+timeout 2400 python -m pytest tests -m gpu -q -x --durations=0 --durations-min=1.0 > gpurun_out/${ROUND}_pytest_gpu_durations_$TAG.txt 2>&1
+tail -3 gpurun_out/${ROUND}_pytest_gpu_durations_$TAG.txt
 python bench.py > gpurun_out/bench_${ROUND}_$TAG.json 2> gpurun_out/bench_${ROUND}_$TAG.err; echo bench rc=$?
 (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${ROUND}_$TAG -- python $R/bench.py --cpu-sample 0 --no-pcie-leg --no-host-api-leg --no-capi-multi-leg --other-reps 1 > $R/gpurun_out/prof_${ROUND}_$TAG.log 2>&1; echo rocprof rc=$?)
 cp "$(ls -S $(find gpurun_out/prof_${ROUND}_$TAG -name "*kernel_stats.csv") | head -1)" gpurun_out/${ROUND}_kernel_stats_bench_$TAG.csv      # (the bench process: the largest table)

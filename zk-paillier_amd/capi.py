@@ -44,6 +44,7 @@ DIAG_EXPORTS = {
     "zkp_diag_table_traffic": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     "zkp_diag_basen": (C.c_int32, [C.c_void_p, C.c_uint32] + [C.c_void_p, C.c_int32] + [C.c_void_p] * 5),
     "zkp_diag_basen_last": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
+    "zkp_diag_basen_engine": (C.c_int32, []),
     "zkp_diag_set_enc_form": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_enc_form": (C.c_int32, [C.c_void_p]),
     "zkp_diag_last_host_blocks": (C.c_int32, [C.c_void_p]),
@@ -67,7 +68,6 @@ EXPORTS = {
     "zkp_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "zkp_backend_name": (C.c_char_p, []),
     "zkp_build_limbs_per_lane": (C.c_int32, []),
-    "zkp_diag_basen_engine": (C.c_int32, []),
     "zkp_last_error_string": (C.c_char_p, [C.c_void_p]),
     "zkp_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "zkp_ctx_synchronize": (C.c_int32, [C.c_void_p]),
