@@ -858,10 +858,11 @@ def capi_multi_leg(pb, wt, expect, np, B, world, steps):
                      for i, ((ms, lo, hi), (cm, gm)) in enumerate(zip(m.last_timing(), m.last_phases()))]
         same = same and not st.any()
         _, stride, nbytes = m.gathered(0, 1)
+        contexts = m.size()
     finally:
         m.close()
     return {"engine": "zkp_multi_* (one process, one ctx + host thread per device, proof-index blocks; outputs by the grouped ncclAllGather inside libzkp_hip.so: ZKP_GATHER_RCCL)",
-            "n_devices": world, "proofs_total": total, "scaling": "weak", "rccl_ranks_seen": m.size(),
+            "n_devices": world, "proofs_total": total, "scaling": "weak", "rccl_ranks_seen": contexts,
             "verify": {"value": total / dtv, "unit": "verifies/s", "ms_per_step": 1e3 * dtv, "steps": steps, "per_device_last_step": per_dev_v},
             "prove": {"value": total / dtp, "unit": "proofs/s", "ms_per_step": 1e3 * dtp, "steps": 1, "per_device_last_step": per_dev_p,
                       "gathered_c1_bytes_per_device": nbytes, "gathered_block_stride": stride},
