@@ -116,6 +116,48 @@ __global__ void __launch_bounds__(256) k_lshl_add_u64(uint32_t* out, uint32_t a0
   out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
 }
 
+// round 6: the bookkeeping instructions of a sub-step of the assembler engine (tools/bn_asm/gen.py) — is the 64-bit shift a full-rate op?
+__global__ void __launch_bounds__(256) k_lshrrev_b64(uint32_t* out, uint32_t a0, uint32_t b0) {
+  uint64_t acc[16], src[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { acc[i] = 0; src[i] = ((uint64_t)(a0 + i + threadIdx.x) << 33) ^ b0; }
+  for (int it = 0; it < ITER; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) asm volatile("v_lshrrev_b64 %0, 29, %1" : "=v"(acc[i]) : "v"(src[i]));
+  }
+  uint64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) s ^= acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+__global__ void __launch_bounds__(256) k_alignbit_pair(uint32_t* out, uint32_t a0, uint32_t b0) {
+  // the same shift as two 32-bit instructions: v_alignbit_b32 (low word) + v_lshrrev_b32 (high word)
+  uint32_t lo[16], hi[16], sl[16], sh[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { lo[i] = hi[i] = 0; sl[i] = a0 + i + threadIdx.x; sh[i] = b0 ^ (i * 77 + threadIdx.x); }
+  for (int it = 0; it < ITER; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) asm volatile("v_alignbit_b32 %0, %3, %2, 29\n\tv_lshrrev_b32_e32 %1, 29, %3" : "=v"(lo[i]), "=v"(hi[i]) : "v"(sl[i]), "v"(sh[i]));
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) s ^= lo[i] ^ hi[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_and_dpp(uint32_t* out, uint32_t a0, uint32_t b0) {
+  uint32_t acc[16], src[16]; uint32_t m = b0 | 0x1fffffff;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { acc[i] = 0; src[i] = a0 + i + threadIdx.x; }
+  for (int it = 0; it < ITER; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) asm volatile("v_and_b32_dpp %0, %1, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(acc[i]) : "v"(src[i]), "v"(m));
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) s ^= acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void __launch_bounds__(256) k_fma_f64(uint32_t* out, uint32_t a0, uint32_t b0) {
   double acc[16]; double a = 1.0 + 1e-9 * (a0 + threadIdx.x), b = 1e-9 * (b0 ^ threadIdx.x);
 #pragma unroll
@@ -280,6 +322,11 @@ int main() {
   run("v_xor_b32", k_xor_b32, 8, 16, dout, ncu, clk);
   run("v_addc_co_u32 chain", k_addc_chain, 8, 16, dout, ncu, clk);
   run("v_lshl_add_u64", k_lshl_add_u64, 8, 16, dout, ncu, clk);
+  for (int w : {2, 8}) run("v_lshrrev_b64", k_lshrrev_b64, w, 16, dout, ncu, clk);
+  for (int w : {2, 8}) run("v_alignbit_b32 + v_lshrrev_b32 (per pair)", k_alignbit_pair, w, 16, dout, ncu, clk);
+  for (int w : {2, 8}) run("v_and_b32_dpp quad_perm", k_and_dpp, w, 16, dout, ncu, clk);
+  for (int w : {2}) run("v_lshl_add_u64", k_lshl_add_u64, w, 16, dout, ncu, clk);
+  for (int w : {2}) run("v_add_u32", k_add_u32, w, 16, dout, ncu, clk);
   run("v_fma_f64", k_fma_f64, 8, 16, dout, ncu, clk);
   run("v_fma_f32", k_fma_f32, 8, 16, dout, ncu, clk);
   run("v_mov_b32_dpp row_shr:1 (+s_nop 1)", k_dpp_row_shr, 8, 16, dout, ncu, clk);
