@@ -5,7 +5,6 @@
 #include <dlfcn.h>
 
 #include <algorithm>
-#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <new>
