@@ -141,6 +141,31 @@ def test_enc_batch_equals_python_and_the_n2_sized_kernels(ctx, n_bits):
     assert list(ok) == [0 if i == 8 else 1 for i in range(count)]
 
 
+def test_enc_under_keys_with_long_runs_of_equal_bits(ctx):
+    """exponents the window script treats specially: runs of more than 31 squarings (the compact script of the assembler engine counts a
+    run in one byte, 1 .. 31, and takes several for a longer one — kernels_modexp.hpp k_sliding_schedule), and runs of ones (a window
+    multiplication after every window).  Shared key, 40 items each, against Python"""
+    rnd = random.Random(99)
+    n_bits, kw = 2048, 64
+    keys = [(1 << 2047) + (1 << 1000) + 1,                                   # two runs of ~1000 zero bits
+            (1 << 2048) - (1 << 900) - 1 - (1 << 37),                         # ones almost everywhere
+            (1 << 2047) | (rnd.getrandbits(300) << 1500) | rnd.getrandbits(200) | 1]     # islands of random bits in zeros
+    for n in keys:
+        assert n & 1 and n.bit_length() == n_bits
+        nn = n * n
+        count = 40
+        ms = [rnd.randrange(n) for _ in range(count)]
+        rs = [rnd.randrange(n) for _ in range(count)]
+        nw = words(n, kw)
+        mw = np.stack([words(v, kw) for v in ms]); rw = np.stack([words(v, kw) for v in rs])
+        out = np.zeros((count, 2 * kw), np.uint32)
+        ctx.paillier_enc(n_bits, count, nw, 0, mw, rw, out)
+        lanes, ok = ctx.diag_basen_last()
+        for i in range(count):
+            got = sum(int(w) << (32 * j) for j, w in enumerate(out[i]))
+            assert got == (1 + ms[i] * n) * pow(rs[i], n, nn) % nn, (hex(n)[:20], i, lanes, ok)
+
+
 @pytest.mark.parametrize("n_bits", [2048, 4096])
 def test_enc_batch_with_per_item_keys_equals_python(ctx, n_bits):
     """n_stride != 0: every item under its own key (fixed-window ladder over the item's n, constants per key, C3 from global memory)"""
