@@ -114,4 +114,6 @@ def test_base_n_work_model_and_its_roofline_identity():
         d6 = next(v["_derived"] for k, v in p6.items() if "k_enc_basen<2>" in k)
         busy6, share6 = 4.0 / d6["simd_cycles_per_valu_instr"], eng * 32 / 64.0 / d6["valu_wave_instr_per_wave_modexp"]
         assert abs(r6["executed_lane_mads_per_enc"] - eng) < 1 and 0.87 < share6 < 0.90
-        assert abs(busy6 * share6 / r6["executed_over_algorithmic"] - r6["frac_at_sampled_clock"]) < 0.03
+        # (the PMC pass ran on another board, alone; the timed verify launch shares the chip with the transcript hash of its call since
+        # the two-stream rule of round 6: the identity holds to 4 % here, to 3 % on round 4's single-stream evidence)
+        assert abs(busy6 * share6 / r6["executed_over_algorithmic"] - r6["frac_at_sampled_clock"]) < 0.04
