@@ -8,7 +8,8 @@
  *   ZKP_GATHER=rccl ZKP_DEVICES=0,1,2,3,4,5,6,7 ./multi_gpu_verify     # outputs reassembled by RCCL all-gathers inside the library (distinct
  *                                                                      # GPUs): the whole c1 / c2 / verdicts end up device-resident on EVERY GPU
  *
- * Prints the block and the wall time of every device context for the prove and the verify call (zkp_multi_last_timing), then runs
+ * Prints the block, the wall time and the compute / gather phases of every device context for the prove and the verify call
+ * (zkp_multi_last_timing, zkp_multi_last_phases), then runs
  * the SAME batch through ONE context (device of the first id) and compares ciphertexts, responses and verdicts byte for byte:
  * exit status 0 only if they are identical, 63/64 (B-1 of B) proofs are accepted and the tampered one is rejected.
  *
@@ -54,9 +55,10 @@ static void hex_to_limbs(const char* hex, uint32_t* out, int nlimbs) {
 
 static void print_timing(zkp_multi* m, const int32_t* devs, const char* what) {
   for (uint32_t i = 0; i < zkp_multi_size(m); i++) {
-    double ms = 0; uint64_t lo = 0, hi = 0;
-    if (zkp_multi_last_timing(m, i, &ms, &lo, &hi) == ZKP_OK)
-      printf("  %-6s context %u (device %d): proofs [%llu, %llu)  %.1f ms\n", what, i, devs[i], (unsigned long long)lo, (unsigned long long)hi, ms);
+    double ms = 0, compute_ms = 0, gather_ms = 0; uint64_t lo = 0, hi = 0;
+    if (zkp_multi_last_timing(m, i, &ms, &lo, &hi) == ZKP_OK && zkp_multi_last_phases(m, i, &compute_ms, &gather_ms) == ZKP_OK)
+      printf("  %-6s context %u (device %d): proofs [%llu, %llu)  %.1f ms of host time; on its stream: compute %.1f ms, gather %.2f ms\n", what, i, devs[i],
+             (unsigned long long)lo, (unsigned long long)hi, ms, compute_ms, gather_ms);
   }
 }
 
