@@ -87,6 +87,12 @@ int32_t zkp_diag_r2l_last(zkp_ctx* ctx);
  * zkp_diag_last_split: the proofs of the most recent RangeProofNi call that went to the latency engine beside the mid engine (0: not split). */
 int32_t zkp_diag_set_split(zkp_ctx* ctx, int32_t on);
 int32_t zkp_diag_last_split(zkp_ctx* ctx);
+/* A verify call whose Enc launch gives every Enc a compute unit of its own (one proof at n = 2048 on the latency engine, k_enc_basen_r2l5)
+ * carries its transcript hash as ONE MORE WORKGROUP of that launch — a unit to itself — instead of a launch of its own on a second stream,
+ * where the hash wavefront shared a SIMD with two wavefronts of an Enc one call in four (6.2 or 8.0 ms).  On by default; $ZKP_FUSE_HASH=0 at
+ * ctx create or zkp_diag_set_fuse_hash(ctx, 0) turn it off.  zkp_diag_last_fused_hash: 1 when the most recent verify call ran that way. */
+int32_t zkp_diag_set_fuse_hash(zkp_ctx* ctx, int32_t on);
+int32_t zkp_diag_last_fused_hash(zkp_ctx* ctx);
 int32_t zkp_diag_set_key_cache(zkp_ctx* ctx, int32_t on);
 int32_t zkp_diag_key_cache_state(zkp_ctx* ctx, int32_t which, uint32_t* out);
 

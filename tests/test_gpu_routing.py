@@ -247,3 +247,52 @@ def test_split_call_device_resident_and_switched_off(actx, oracle):
         assert np.array_equal(v, expect)
     finally:
         actx.set_split(True); actx.set_geometry(0); actx.set_enc_form("auto")
+
+
+def test_one_proof_verify_carries_its_transcript_hash_inside_the_enc_launch(actx, oracle):
+    """A verify call whose Enc launch gives every Enc a compute unit (k_enc_basen_r2l5: one proof at 128 rows, three at 40) runs its transcript
+    hashes as workgroups OF that launch (csrc/zkp_api_proofs.inc range_verify_impl, zkp_diag_last_fused_hash) instead of beside it on a second
+    stream: same verdicts as the oracle and as the two-stream shape, on honest proofs, on a tampered transcript (the digest changes: every
+    row's kind contradicts its challenge bit with probability 1/2) and on tampered responses."""
+    n_bits, kw = 2048, 64
+    if actx.latency_limbs_per_lane() != 9:
+        pytest.skip("the latency engine is not loaded")
+    n = H.fixture_key()[2]
+    oracle.set_threads(min(16, oracle.max_threads()))
+    actx.set_geometry(0)
+    actx.set_enc_form("auto")
+    for B, ef in ((1, 128), (3, 40), (2, 64)):
+        if 2 * ef * B > compute_units():
+            continue
+        cases = H.build_range_case(b"fused-hash-%d-%d" % (B, ef), [n], n_bits, B, ef=ef)
+        pb, wt = H.fill_batch(cases, n_bits, True, oracle)
+        oracle.range_generate_encrypted_pairs(pb.struct(), wt.struct())
+        e = np.zeros((B, 32), np.uint8); elen = np.zeros(B, np.uint8)
+        for b in range(B):
+            d = oracle.fs_challenge(n_bits, ef, pb.n[0], pb.c1[b], pb.c2[b])
+            e[b, :len(d)] = np.frombuffer(d, np.uint8); elen[b] = len(d)
+        st = np.full(B, 9, np.uint8)
+        oracle.range_generate_proof(pb.struct(), wt.struct(), e, elen, st)
+        assert not st.any()
+        variants = [("honest", lambda q: None),
+                    ("transcript", lambda q: q.c2.__setitem__((B - 1, ef // 2, 5), q.c2[B - 1, ef // 2, 5] ^ 4)),
+                    ("response", lambda q: q.resp_r1.__setitem__((0, ef - 1, 0), q.resp_r1[0, ef - 1, 0] ^ 1))]
+        for name, tamper in variants:
+            q = zkp.RangeBatch(n_bits, B, ef, shared_key=True)
+            for f in ("n", "range", "ciphertext") + FIELDS:
+                getattr(q, f)[:] = getattr(pb, f)
+            tamper(q)
+            want = np.full(B, 9, np.uint8)
+            oracle.range_ni_verify(q.struct(), want)
+            if name == "honest":
+                assert (want == 1).all()
+            else:
+                assert (want == 0).any()
+            for fused in (True, False, True):
+                actx.set_fuse_hash(fused)
+                v = np.full(B, 9, np.uint8)
+                actx.range_ni_verify(q.struct(), v, device=False)
+                assert actx.r2l_last() and actx.r2l_lanes_last() == 36, (B, ef, name)
+                assert actx.last_fused_hash() == fused, (B, ef, name, fused)
+                assert np.array_equal(v, want), (B, ef, name, fused, v, want)
+    actx.set_fuse_hash(True)

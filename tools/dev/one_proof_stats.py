@@ -1,5 +1,5 @@
 """one RangeProofNi (BASELINE configs[0]) proved and verified N times on host buffers: per-call milliseconds, min / median / max of each leg.
-python tools/dev/one_proof_stats.py [calls] [proofs]     (ZKP_HIP_LAT_LIB selects a build of the latency engine for A/B runs)"""
+python tools/dev/one_proof_stats.py [calls] [proofs]     (ZKP_HIP_LAT_LIB selects a build of the latency engine for A/B runs; ZKP_FUSE_HASH=0: the transcript hash of a verify in a launch of its own)"""
 import importlib, json, os, statistics, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,5 +22,5 @@ for _ in range(calls):
     t2 = time.perf_counter()
     pv.append(1e3 * (t1 - t0)); vv.append(1e3 * (t2 - t1))
 st = lambda x: {"min": round(min(x), 3), "median": round(statistics.median(x), 3), "max": round(max(x), 3), "max_over_min": round(max(x) / min(x), 3)}
-print(json.dumps({"proofs": B, "calls": calls, "lat_lib": os.environ.get("ZKP_HIP_LAT_LIB", "in-tree"), "accepted": bool(v.all()), "geometry": ctx.last_geometry(),
+print(json.dumps({"proofs": B, "calls": calls, "lat_lib": os.environ.get("ZKP_HIP_LAT_LIB", "in-tree"), "fuse_hash_env": os.environ.get("ZKP_FUSE_HASH", "unset"), "fused": ctx.last_fused_hash(), "accepted": bool(v.all()), "geometry": ctx.last_geometry(),
                   "prove_ms": st(pv), "verify_ms": st(vv), "verify_all": [round(x, 2) for x in vv]}))

@@ -53,6 +53,8 @@ DIAG_EXPORTS = {
     "zkp_diag_set_r2l_lanes": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_r2l_lanes_last": (C.c_int32, [C.c_void_p]),
     "zkp_diag_mid_limbs_per_lane": (C.c_int32, [C.c_void_p]),
+    "zkp_diag_set_fuse_hash": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "zkp_diag_last_fused_hash": (C.c_int32, [C.c_void_p]),
     "zkp_diag_set_split": (C.c_int32, [C.c_void_p, C.c_int32]),
     "zkp_diag_last_split": (C.c_int32, [C.c_void_p]),
     "zkp_diag_set_key_cache": (C.c_int32, [C.c_void_p, C.c_int32]),
@@ -342,6 +344,14 @@ class Context:
     def last_split(self) -> int:
         """proofs of the most recent RangeProofNi call that ran on the latency engine beside the mid engine (0: the call was not split)"""
         return self.lib.zkp_diag_last_split(self.h)
+
+    def set_fuse_hash(self, on: bool):
+        """the transcript hash of a one-proof verify as a workgroup of its Enc launch (include/zkp_hip_diag.h); on by default"""
+        self.check(self.lib.zkp_diag_set_fuse_hash(self.h, 1 if on else 0))
+
+    def last_fused_hash(self) -> bool:
+        """did the most recent verify call carry its transcript hash inside its Enc launch?"""
+        return self.lib.zkp_diag_last_fused_hash(self.h) == 1
 
     def set_key_cache(self, on: bool):
         """keep the constants of the one key of a shared-key call across calls (include/zkp_hip_diag.h); on by default"""

@@ -634,10 +634,20 @@ __device__ __forceinline__ void product(uint32_t (&R)[RW], uint32_t (&Qd)[RW], c
 }
 }  // namespace r2l5
 
-__global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_t* __restrict__ bcst, uint32_t* __restrict__ raw) {
+// `h`: the transcript hashes of a verify call that travel with this launch (h.batch of them, 0: none): workgroup b < h.batch is not an Enc
+// workgroup — its first wavefront hashes proof b (range_hash_wave_body; the launch then carries hw_lds_words(kw) words of dynamic LDS), the
+// others leave.  Why here and not in a launch of its own on a second stream: the dispatcher gives every workgroup of a launch of at most
+// one per compute unit a unit to itself, so the hash wavefront shares its SIMD with nobody; as a launch of its own it landed beside the
+// role wavefronts of an Enc workgroup three times out of four, and on the SIMD that carries two of them once in four: the slow mode of the
+// one-proof verify (profiles/r06/one_proof/).
+__global__ void __launch_bounds__(320) k_enc_basen_r2l5(EncArgs a, const uint32_t* __restrict__ bcst, uint32_t* __restrict__ raw, RangeHashArgs h) {
   using namespace r2l5;
   using BC = BnConst<8>;
   constexpr int L = LIMBS, E = 2 * L;
+  if (blockIdx.x < h.batch) {
+    if (threadIdx.x < 64) range_hash_wave_body(h, (int)threadIdx.x, blockIdx.x);
+    return;
+  }
   if (!bcst[BC::OFF_OK]) return;
   // The five role wavefronts are ONE dependent chain in lockstep: a stranger on one of their SIMDs — the transcript-hash wavefront of a
   // one-proof verify, which runs beside this launch — holds all five up.  They issue ahead of it (ZKP_R2L_PRIO, A/B: profiles/r06/one_proof/).

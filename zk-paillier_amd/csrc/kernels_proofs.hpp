@@ -265,11 +265,10 @@ struct WaveSha {
   }
 };
 
-#ifndef ZKP_TEMPLATE_KERNELS_ONLY
-__global__ void __launch_bounds__(64) k_range_hash_wave(RangeHashArgs a) {
+// The transcript hash of proof b on ONE wavefront (the body of k_range_hash_wave; k_enc_basen_r2l5 runs it in a workgroup of its own launch
+// for a one-proof verify: kernels_basen_r2l.hpp).  The caller's launch provides hw_lds_words(kw) words of dynamic LDS.
+__device__ __forceinline__ void range_hash_wave_body(const RangeHashArgs& a, int lane, uint64_t b) {
   extern __shared__ __align__(16) uint32_t hash_lds[];
-  const int lane = threadIdx.x;
-  const uint64_t b = blockIdx.x;
   const int kw = (int)a.kw;
   WaveSha s;
   s.init(hash_lds, kw, lane);
@@ -317,6 +316,9 @@ __global__ void __launch_bounds__(64) k_range_hash_wave(RangeHashArgs a) {
   uint32_t carry = 0;
   for (uint32_t w = 0; w < a.kw; w++) { const uint32_t v = t1[w]; t2[w] = (v << 1) | carry; carry = v >> 31; }
 }
+
+#ifndef ZKP_TEMPLATE_KERNELS_ONLY
+__global__ void __launch_bounds__(64) k_range_hash_wave(RangeHashArgs a) { range_hash_wave_body(a, (int)threadIdx.x, blockIdx.x); }
 #endif
 
 // ------------------------------------------------------------------------------------------

@@ -97,6 +97,11 @@ struct zkp_ctx {
                                        // SIMDs, else one wavefront of five groups of 12 lanes x 6 limbs); 36 / 12 / 8 (x 9 limbs) pin one ($ZKP_R2L_LANES at ctx create, zkp_diag_set_r2l_lanes)
   int bn_last_r2l_lanes = 0;           // ... and the geometry the most recent such launch ran on
   int bn_r2l = 1;                      // that ladder: 0 = never, 1 = the library's rule (launches of up to two wavefronts per SIMD), 2 = whenever it can run (tests); $ZKP_R2L at ctx create
+  // The transcript hashes of a verify call of a few proofs as workgroups of its Enc launch (k_enc_basen_r2l5): range_verify_impl names them here
+  // before launch_k_enc, the launch that takes them says so; $ZKP_FUSE_HASH=0 at zkp_ctx_create keeps them in a launch of their own on `side`.
+  const RangeHashArgs* fuse_hash = nullptr;
+  bool fuse_hash_taken = false;
+  int fuse_hash_on = 1;
   DevBuf bn_flag;                      // device word: every key of the last batched base-n set-up qualified   // base-n form (kernels_basen.hpp): set-up record of n, its base-n constants, window tables, Mask-row products
   // timing of the dominant kernels
   bool timing = false;
@@ -141,7 +146,8 @@ static int32_t zkp_caught(zkp_ctx* c, int32_t st, const char* what) noexcept {
   X(zkp_zero_proof_prove_batch) X(zkp_zero_proof_verify_batch) X(zkp_ciphertext_proof_prove_batch)                               \
   X(zkp_ciphertext_proof_verify_batch) X(zkp_verlin_proof_prove_batch) X(zkp_verlin_proof_verify_batch)                          \
   X(zkp_mul_proof_prove_batch) X(zkp_mul_proof_verify_batch) X(zkp_correct_message_prove_batch) X(zkp_correct_message_verify_batch)           \
-  X(zkp_diag_basen) X(zkp_diag_basen_last) X(zkp_diag_set_enc_form) X(zkp_diag_set_r2l) X(zkp_diag_r2l_last) X(zkp_diag_set_r2l_lanes) X(zkp_diag_r2l_lanes_last) X(zkp_diag_set_key_cache) X(zkp_diag_key_cache_state)
+  X(zkp_diag_basen) X(zkp_diag_basen_last) X(zkp_diag_set_enc_form) X(zkp_diag_set_r2l) X(zkp_diag_r2l_last) X(zkp_diag_set_r2l_lanes) X(zkp_diag_r2l_lanes_last) X(zkp_diag_set_key_cache) X(zkp_diag_key_cache_state) \
+  X(zkp_diag_set_fuse_hash) X(zkp_diag_last_fused_hash)
 
 struct LatEngine {
   void* handle = nullptr;
@@ -714,8 +720,20 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
         // one wavefront of five groups of 12 lanes x 6 limbs beyond; 8 lanes x 9 limbs only when pinned (A/B runs)
         const int lanes = c->bn_r2l_lanes ? c->bn_r2l_lanes : (a.count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus ? 36 : 12);
         c->bn_last_r2l_lanes = lanes;
-        if (lanes == 36) hipLaunchKernelGGL(k_enc_basen_r2l5, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(a.count, 4ull * (uint64_t)c->cus))), dim3(320), 0, c->stream, a,
-                                            (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
+        if (lanes == 36) {
+          // (with the call's transcript hashes aboard: one workgroup each in front of the Enc workgroups, the launch as a whole within one workgroup per
+          //  compute unit — an Enc workgroup claims items until none is left, so fewer of them than items is only a longer loop for some)
+          RangeHashArgs h{};
+          uint64_t enc_wgs = std::max<uint64_t>(1, std::min<uint64_t>(a.count, 4ull * (uint64_t)c->cus));
+          size_t dyn = 0;
+          if (c->fuse_hash && c->fuse_hash->batch < (uint64_t)c->cus) {
+            h = *c->fuse_hash;
+            c->fuse_hash_taken = true;
+            enc_wgs = std::max<uint64_t>(1, std::min<uint64_t>(enc_wgs, (uint64_t)c->cus - h.batch));
+            dyn = (size_t)hw_lds_words((int)h.kw) * sizeof(uint32_t);
+          }
+          hipLaunchKernelGGL(k_enc_basen_r2l5, dim3((unsigned)(h.batch + enc_wgs)), dim3(320), dyn, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p, h);
+        }
         else if (lanes == 8) hipLaunchKernelGGL(k_enc_basen_r2l<9>, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
         else hipLaunchKernelGGL(k_enc_basen_r2l<6>, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
       }
@@ -735,6 +753,21 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
 }
 #endif
 
+// Will launch_basen<GS> hand a verify launch of at most `count` Enc under the key of this call to k_enc_basen_r2l5 (five wavefronts per Enc, one
+// workgroup per compute unit)?  The same conditions as below, asked ahead of the launch by range_verify_impl; a launch that then does not take
+// the call's transcript hashes aboard (out of memory for the form's buffers) leaves them to a launch of their own.
+template <int GS> static bool basen_r2l5_expected(const zkp_ctx* c, uint64_t n_stride, uint32_t n_bits, uint64_t count) {
+#if ZKP_W == 9
+  if constexpr (GS == 2 * BN_GA) {
+    const int mode = c->enc_form;
+    if (mode == ZKP_ENC_FORM_N2 || n_stride != 0 || n_bits != 2048 || !c->bn_r2l) return false;
+    if (!(c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && count <= 2ull * 4 * (uint64_t)c->cus))) return false;
+    return c->bn_r2l_lanes ? c->bn_r2l_lanes == 36 : count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus;
+  }
+#endif
+  (void)c; (void)n_stride; (void)n_bits; (void)count;
+  return false;
+}
 template <int G> static void launch_k_enc(zkp_ctx* c, unsigned blocks, const EncArgs& a_in) {
   using LL = LdsLayout<G>;
   EncArgs a = a_in;
@@ -773,6 +806,7 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
   if (const char* kc = std::getenv("ZKP_KEY_CACHE")) c->key_cache = std::atoi(kc) != 0;
   if (const char* sp = std::getenv("ZKP_SPLIT")) c->split_calls = std::atoi(sp) != 0;
   if (const char* rl = std::getenv("ZKP_R2L")) c->bn_r2l = std::atoi(rl);
+  if (const char* fh = std::getenv("ZKP_FUSE_HASH")) c->fuse_hash_on = std::atoi(fh);
   if (const char* rl = std::getenv("ZKP_R2L_LANES")) { const int v = std::atoi(rl); c->bn_r2l_lanes = (v == 8 || v == 12 || v == 36) ? v : 0; }
   c->owns_stream = own_stream;
   c->stream = stream;
@@ -966,6 +1000,23 @@ extern "C" int32_t zkp_diag_set_r2l(zkp_ctx* c, int32_t mode) try {
 #endif
   return ZKP_OK;
 } ZKP_CATCH(c)
+// The transcript hash of a one-proof verify as a workgroup of its Enc launch (k_enc_basen_r2l5; csrc/zkp_api_proofs.inc range_verify_impl): on / off;
+// did the most recent verify call of the ctx run that way?
+extern "C" int32_t zkp_diag_set_fuse_hash(zkp_ctx* c, int32_t on) try {
+  if (!c) return ZKP_EINVAL;
+  c->fuse_hash_on = on != 0;
+#ifndef ZKP_SECONDARY_ENGINE
+  for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_diag_set_fuse_hash(c->eng_ctx[k], on);
+#endif
+  return ZKP_OK;
+} ZKP_CATCH(c)
+extern "C" int32_t zkp_diag_last_fused_hash(zkp_ctx* c) {
+  if (!c) return -1;
+#ifndef ZKP_SECONDARY_ENGINE
+  if (c->lat_ctx && c->last_geometry == c->lat->limbs_per_lane) return c->lat->p_zkp_diag_last_fused_hash(c->lat_ctx);
+#endif
+  return c->fuse_hash_taken ? 1 : 0;
+}
 // ... and its lane geometry: 0 = the library's rule, 36 = five wavefronts per Enc, 12 / 8 = one wavefront of five 12- / 8-lane groups
 extern "C" int32_t zkp_diag_set_r2l_lanes(zkp_ctx* c, int32_t lanes) try {
   if (!c || (lanes != 0 && lanes != 8 && lanes != 12 && lanes != 36)) return ZKP_EINVAL;
