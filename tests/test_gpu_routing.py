@@ -250,8 +250,8 @@ def test_split_call_device_resident_and_switched_off(actx, oracle):
 
 
 def test_one_proof_verify_carries_its_transcript_hash_inside_the_enc_launch(actx, oracle):
-    """A verify call whose Enc launch gives every Enc a compute unit (k_enc_basen_r2l5: one proof at 128 rows, three at 40) runs its transcript
-    hashes as workgroups OF that launch (csrc/zkp_api_proofs.inc range_verify_impl, zkp_diag_last_fused_hash) instead of beside it on a second
+    """A verify call whose Enc launch gives every Enc a compute unit (k_enc_basen_r2l5: one proof at 128 rows, three at 40) or every wavefront a
+    SIMD (k_enc_basen_r2l: 2 - 4 proofs) runs its transcript hashes as workgroups OF that launch (csrc/zkp_api_proofs.inc range_verify_impl, zkp_diag_last_fused_hash) instead of beside it on a second
     stream: same verdicts as the oracle and as the two-stream shape, on honest proofs, on a tampered transcript (the digest changes: every
     row's kind contradicts its challenge bit with probability 1/2) and on tampered responses."""
     n_bits, kw = 2048, 64
@@ -261,9 +261,9 @@ def test_one_proof_verify_carries_its_transcript_hash_inside_the_enc_launch(actx
     oracle.set_threads(min(16, oracle.max_threads()))
     actx.set_geometry(0)
     actx.set_enc_form("auto")
-    for B, ef in ((1, 128), (3, 40), (2, 64)):
-        if 2 * ef * B > compute_units():
-            continue
+    for B, ef in ((1, 128), (3, 40), (2, 64), (2, 128), (4, 128), (5, 128)):
+        five = 2 * ef * B <= compute_units()                       # k_enc_basen_r2l5; beyond: one wavefront per Enc, hashes aboard up to one per SIMD
+        takes = 2 * ef * B <= 4 * compute_units()
         cases = H.build_range_case(b"fused-hash-%d-%d" % (B, ef), [n], n_bits, B, ef=ef)
         pb, wt = H.fill_batch(cases, n_bits, True, oracle)
         oracle.range_generate_encrypted_pairs(pb.struct(), wt.struct())
@@ -292,7 +292,7 @@ def test_one_proof_verify_carries_its_transcript_hash_inside_the_enc_launch(actx
                 actx.set_fuse_hash(fused)
                 v = np.full(B, 9, np.uint8)
                 actx.range_ni_verify(q.struct(), v, device=False)
-                assert actx.r2l_last() and actx.r2l_lanes_last() == 36, (B, ef, name)
-                assert actx.last_fused_hash() == fused, (B, ef, name, fused)
+                assert actx.r2l_last() and actx.r2l_lanes_last() == (36 if five else 12), (B, ef, name)
+                assert actx.last_fused_hash() == (fused and takes), (B, ef, name, fused)
                 assert np.array_equal(v, want), (B, ef, name, fused, v, want)
     actx.set_fuse_hash(True)

@@ -734,8 +734,22 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
           }
           hipLaunchKernelGGL(k_enc_basen_r2l5, dim3((unsigned)(h.batch + enc_wgs)), dim3(320), dyn, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p, h);
         }
-        else if (lanes == 8) hipLaunchKernelGGL(k_enc_basen_r2l<9>, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
-        else hipLaunchKernelGGL(k_enc_basen_r2l<6>, dim3(waves), dim3(64), 0, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p);
+        else {
+          // one wavefront per Enc: the call's transcript hashes aboard while the launch as a whole stays within one wavefront per SIMD (2 - 4 proofs)
+          RangeHashArgs h{};
+          uint64_t enc_wgs = waves;
+          size_t dyn = 0;
+          const uint64_t simds = 4ull * (uint64_t)c->cus;
+          if (c->fuse_hash && a.count <= simds && c->fuse_hash->batch < simds) {
+            h = *c->fuse_hash;
+            c->fuse_hash_taken = true;
+            enc_wgs = std::max<uint64_t>(1, std::min<uint64_t>(enc_wgs, simds - h.batch));
+            dyn = (size_t)hw_lds_words((int)h.kw) * sizeof(uint32_t);
+          }
+          const dim3 grid((unsigned)(h.batch + enc_wgs));
+          if (lanes == 8) hipLaunchKernelGGL(k_enc_basen_r2l<9>, grid, dim3(64), dyn, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p, h);
+          else hipLaunchKernelGGL(k_enc_basen_r2l<6>, grid, dim3(64), dyn, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p, h);
+        }
       }
     } else
 #endif
@@ -754,15 +768,16 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
 #endif
 
 // Will launch_basen<GS> hand a verify launch of at most `count` Enc under the key of this call to k_enc_basen_r2l5 (five wavefronts per Enc, one
-// workgroup per compute unit)?  The same conditions as below, asked ahead of the launch by range_verify_impl; a launch that then does not take
+// workgroup per compute unit) or to k_enc_basen_r2l at one wavefront per SIMD — the launches that take the call's transcript hashes aboard?  The same conditions as below, asked ahead of the launch by range_verify_impl; a launch that then does not take
 // the call's transcript hashes aboard (out of memory for the form's buffers) leaves them to a launch of their own.
-template <int GS> static bool basen_r2l5_expected(const zkp_ctx* c, uint64_t n_stride, uint32_t n_bits, uint64_t count) {
+template <int GS> static bool basen_r2l_takes_hashes(const zkp_ctx* c, uint64_t n_stride, uint32_t n_bits, uint64_t count) {
 #if ZKP_W == 9
   if constexpr (GS == 2 * BN_GA) {
     const int mode = c->enc_form;
     if (mode == ZKP_ENC_FORM_N2 || n_stride != 0 || n_bits != 2048 || !c->bn_r2l) return false;
     if (!(c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && count <= 2ull * 4 * (uint64_t)c->cus))) return false;
-    return c->bn_r2l_lanes ? c->bn_r2l_lanes == 36 : count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus;
+    const bool five = c->bn_r2l_lanes ? c->bn_r2l_lanes == 36 : count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus;
+    return five || count <= 4ull * (uint64_t)c->cus;          // k_enc_basen_r2l5, or one wavefront per Enc and per SIMD
   }
 #endif
   (void)c; (void)n_stride; (void)n_bits; (void)count;
