@@ -642,6 +642,13 @@ template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uin
   HIPCHK(c, hipGetLastError());
   return ZKP_OK;
 }
+// Does a launch of the one-wavefront-per-Enc ladder over at most `count` items (`listed`: a verify's work list, of which about three quarters
+// exist) fit one wavefront per SIMD together with `hashes` transcript-hash wavefronts?
+static bool r2l_one_per_simd(const zkp_ctx* c, uint64_t count, bool listed, uint64_t hashes) {
+  const uint64_t simds = 4ull * (uint64_t)c->cus;
+  const uint64_t expect = listed ? (3 * count + 3) / 4 + count / 32 : count;      // (3 % above the mean: 5 proofs 960 + 40 of 1280)
+  return hashes < simds && expect + hashes <= simds;
+}
 // The base-n launch of an Enc call (GS: lanes per n^2-sized integer of the k_enc launch it stands in for).  It claims work from the SAME
 // counter as the k_enc launch that follows it: when the keys qualify it leaves nothing to claim, when they do not it returns at once
 // and k_enc runs as before.  Returns false when nothing was launched.
@@ -736,15 +743,20 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
         }
         else {
           // one wavefront per Enc: the call's transcript hashes aboard while the launch as a whole stays within one wavefront per SIMD (2 - 4 proofs)
+          // (a verify's work list holds 128 + the Open rows of every proof — about 192 — of the 256 Enc per proof the launch is sized for: while the
+          //  items EXPECTED fit one wavefront per SIMD the grid stops there — five proofs: 960 of 1280 — and a wavefront claims until none is left)
           RangeHashArgs h{};
           uint64_t enc_wgs = waves;
           size_t dyn = 0;
           const uint64_t simds = 4ull * (uint64_t)c->cus;
-          if (c->fuse_hash && a.count <= simds && c->fuse_hash->batch < simds) {
-            h = *c->fuse_hash;
-            c->fuse_hash_taken = true;
-            enc_wgs = std::max<uint64_t>(1, std::min<uint64_t>(enc_wgs, simds - h.batch));
-            dyn = (size_t)hw_lds_words((int)h.kw) * sizeof(uint32_t);
+          const uint64_t hashes = c->fuse_hash ? c->fuse_hash->batch : 0;
+          if (r2l_one_per_simd(c, a.count, a.count_ptr != nullptr, hashes)) {
+            enc_wgs = std::max<uint64_t>(1, std::min<uint64_t>(enc_wgs, simds - hashes));
+            if (c->fuse_hash) {
+              h = *c->fuse_hash;
+              c->fuse_hash_taken = true;
+              dyn = (size_t)hw_lds_words((int)h.kw) * sizeof(uint32_t);
+            }
           }
           const dim3 grid((unsigned)(h.batch + enc_wgs));
           if (lanes == 8) hipLaunchKernelGGL(k_enc_basen_r2l<9>, grid, dim3(64), dyn, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p, h);
@@ -770,17 +782,17 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
 // Will launch_basen<GS> hand a verify launch of at most `count` Enc under the key of this call to k_enc_basen_r2l5 (five wavefronts per Enc, one
 // workgroup per compute unit) or to k_enc_basen_r2l at one wavefront per SIMD — the launches that take the call's transcript hashes aboard?  The same conditions as below, asked ahead of the launch by range_verify_impl; a launch that then does not take
 // the call's transcript hashes aboard (out of memory for the form's buffers) leaves them to a launch of their own.
-template <int GS> static bool basen_r2l_takes_hashes(const zkp_ctx* c, uint64_t n_stride, uint32_t n_bits, uint64_t count) {
+template <int GS> static bool basen_r2l_takes_hashes(const zkp_ctx* c, uint64_t n_stride, uint32_t n_bits, uint64_t count, uint64_t hashes) {
 #if ZKP_W == 9
   if constexpr (GS == 2 * BN_GA) {
     const int mode = c->enc_form;
     if (mode == ZKP_ENC_FORM_N2 || n_stride != 0 || n_bits != 2048 || !c->bn_r2l) return false;
     if (!(c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && count <= 2ull * 4 * (uint64_t)c->cus))) return false;
     const bool five = c->bn_r2l_lanes ? c->bn_r2l_lanes == 36 : count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus;
-    return five || count <= 4ull * (uint64_t)c->cus;          // k_enc_basen_r2l5, or one wavefront per Enc and per SIMD
+    return five || r2l_one_per_simd(c, count, true, hashes);  // k_enc_basen_r2l5, or one wavefront per Enc and per SIMD
   }
 #endif
-  (void)c; (void)n_stride; (void)n_bits; (void)count;
+  (void)c; (void)n_stride; (void)n_bits; (void)count; (void)hashes;
   return false;
 }
 template <int G> static void launch_k_enc(zkp_ctx* c, unsigned blocks, const EncArgs& a_in) {
