@@ -246,14 +246,20 @@ __device__ __forceinline__ void product2(uint32_t (&R)[RW], const uint32_t (&X)[
 // one — which claims from the same counter — does the work.
 // `h`: the transcript hashes of a verify call that travel with this launch (as in k_enc_basen_r2l5 below): workgroup b < h.batch hashes proof b.
 // A launch of at most one wavefront per SIMD gives every wavefront a SIMD to itself; as a launch of its own on a second stream the hash
-// wavefront of 2 - 4 proofs shared one with an Enc wavefront in 4 calls of 10 (verify 10.0 or 12.5 ms).
+// wavefront of 2 - 4 proofs shared one with an Enc wavefront in 4 calls of 10 (verify 10.0 or 12.5 ms).  Beyond (two wavefronts per SIMD:
+// 6 - 8 proofs) the hashes are the launch's first workgroups all the same — one of a SIMD's two wavefronts instead of a third (14.6 or
+// 17.2 ms) — at 16 blocks per batch, so that the LDS every workgroup of the launch then carries (6.6 KB) leaves eight of them on a unit.
 template <int RW>
 __global__ void __launch_bounds__(64) k_enc_basen_r2l(EncArgs a, const uint32_t* __restrict__ bcst, uint32_t* __restrict__ raw, RangeHashArgs h) {
   using namespace r2l;
   using GM = Geom<RW>;
   using BC = BnConst<8>;                     // (the key's record: limb-linear arrays of 72 limbs, whatever the lanes)
   constexpr int L = LIMBS, E = 2 * L, RG = GM::RG, AW = GM::AW, RBLK = GM::RBLK;
-  if (blockIdx.x < h.batch) { range_hash_wave_body(h, (int)threadIdx.x, blockIdx.x); return; }
+  if (blockIdx.x < h.batch) {
+    if (h.wave_blocks == 16) range_hash_wave_body<16>(h, (int)threadIdx.x, blockIdx.x);
+    else range_hash_wave_body<HW_BLOCKS>(h, (int)threadIdx.x, blockIdx.x);
+    return;
+  }
   if (!bcst[BC::OFF_OK]) return;
   __shared__ __align__(16) uint32_t lds[GM::LDS_WORDS];
   const int lane = threadIdx.x & 63, role = lane / RG, gl = lane - role * RG;

@@ -35,6 +35,7 @@ struct RangeHashArgs {
   uint8_t* verdict;    // [B] verify: ACCEPT or MALFORMED to start with; prove: status 0 / MALFORMED
   uint8_t ok_value;    // value written when the challenge is long enough
   const uint8_t* e_in; const uint8_t* e_len_in;   // externally supplied challenge (interactive protocol): no hashing
+  uint32_t wave_blocks;   // hashes that travel with an Enc launch (kernels_basen_r2l.hpp): blocks per batch of the wave hash, 16 or 64 (0 = 64)
 };
 
 // One wavefront per 64 proofs, one proof per lane (SHA-256 is sequential per proof).  The operands are read with
@@ -128,22 +129,25 @@ __global__ void __launch_bounds__(HASH_PROOFS) k_range_hash(RangeHashArgs a) {
 // funnel-shifted into stream position by the pending bytes), each lane expands the schedule of one of 64 consecutive blocks
 // (W[r] + K[r] into LDS), and then all lanes walk the 64 x 64 rounds in lockstep reading those sums as broadcasts — about half
 // the instructions of a compression leave the serial path (9.5 -> ~5 ms per 131 KB transcript).
-constexpr int HW_BLOCKS = 64;                      // blocks per batch: one schedule per lane
-constexpr int HW_WORDS = 16 * HW_BLOCKS;
+// NB = blocks per batch: 64 — one schedule per lane, 22.8 KB of LDS at n = 2048 — wherever the hash has a launch or a compute unit to itself;
+// 16 (6.6 KB; the schedules of a batch on a quarter of the lanes: ~4 % more instructions per transcript) where its LDS rides on every
+// workgroup of an Enc launch of two wavefronts per SIMD (k_enc_basen_r2l: 5 - 8 proofs).
+constexpr int HW_BLOCKS = 64;
 constexpr int HW_KW_STRIDE = 68;                   // 64 sums per block, padded: 16-byte aligned rows for ds_read_b128
 __host__ __device__ constexpr int hw_pidx(int s) { return s + (s >> 4); }      // stream word -> LDS slot (a block's 16 words stay apart in the banks)
-__host__ __device__ constexpr int hw_kw_offset(int kw) { return (hw_pidx(HW_WORDS + 2 * kw + 8) + 4) & ~3; }   // 16-byte aligned
-__host__ __device__ constexpr int hw_lds_words(int kw) { return hw_kw_offset(kw) + HW_BLOCKS * HW_KW_STRIDE + (2 * kw + 4); }
+template <int NB = HW_BLOCKS> __host__ __device__ constexpr int hw_kw_offset(int kw) { return (hw_pidx(16 * NB + 2 * kw + 8) + 4) & ~3; }   // 16-byte aligned
+template <int NB = HW_BLOCKS> __host__ __device__ constexpr int hw_lds_words(int kw) { return hw_kw_offset<NB>(kw) + NB * HW_KW_STRIDE + (2 * kw + 4); }
 
 struct WaveShaState { uint32_t h[8]; };
 
 // Compress the first nblk (<= 64) blocks of the chunk buffer.  One out-of-line copy (two unrolled SHA bodies per call site in
 // one function is more than the register allocator of this compiler survives); the LDS areas are derived from the kernel's
 // dynamic shared array here so that they stay LDS pointers (a pointer handed through memory becomes a flat one).
+template <int NB>
 __device__ __noinline__ WaveShaState hw_compress(WaveShaState st, int nblk, int kw, int lane) {
   extern __shared__ __align__(16) uint32_t hash_lds[];
   uint32_t* chunk = hash_lds;
-  uint32_t* kwbuf = hash_lds + hw_kw_offset(kw);
+  uint32_t* kwbuf = hash_lds + hw_kw_offset<NB>(kw);
   wave_lds_fence();
   if (lane < nblk) {                                          // this lane's block: schedule + round constants
     uint32_t w[16];
@@ -187,7 +191,8 @@ __device__ __noinline__ WaveShaState hw_compress(WaveShaState st, int nblk, int 
   return st;
 }
 
-struct WaveSha {
+template <int NB>
+struct WaveShaT {
   WaveShaState st;
   uint32_t* chunk;      // stream words not yet compressed (padded index)
   uint32_t* row;        // one staged value + two words of head room
@@ -200,13 +205,13 @@ struct WaveSha {
     st.h[0] = 0x6a09e667; st.h[1] = 0xbb67ae85; st.h[2] = 0x3c6ef372; st.h[3] = 0xa54ff53a;
     st.h[4] = 0x510e527f; st.h[5] = 0x9b05688c; st.h[6] = 0x1f83d9ab; st.h[7] = 0x5be0cd19;
     chunk = lds;
-    row = lds + hw_kw_offset(kw_) + HW_BLOCKS * HW_KW_STRIDE;
+    row = lds + hw_kw_offset<NB>(kw_) + NB * HW_KW_STRIDE;
     wpos = 0; pend = 0; npend = 0; nbytes = 0; lane = lane_; kw = kw_;
   }
 
   // compress the first nblk blocks and move the rest of the chunk down
   __device__ __forceinline__ void flush(int nblk) {
-    st = hw_compress(st, nblk, kw, lane);
+    st = hw_compress<NB>(st, nblk, kw, lane);
     const int rest = wpos - 16 * nblk;                       // <= 2kw + 8 words
     uint32_t t[5];
 #pragma unroll
@@ -267,10 +272,11 @@ struct WaveSha {
 
 // The transcript hash of proof b on ONE wavefront (the body of k_range_hash_wave; k_enc_basen_r2l5 runs it in a workgroup of its own launch
 // for a one-proof verify: kernels_basen_r2l.hpp).  The caller's launch provides hw_lds_words(kw) words of dynamic LDS.
+template <int NB = HW_BLOCKS>
 __device__ __forceinline__ void range_hash_wave_body(const RangeHashArgs& a, int lane, uint64_t b) {
   extern __shared__ __align__(16) uint32_t hash_lds[];
   const int kw = (int)a.kw;
-  WaveSha s;
+  WaveShaT<NB> s;
   s.init(hash_lds, kw, lane);
   const int nvalues = 1 + 2 * (int)a.ef;                      // n, c1[0..ef), c2[0..ef)
   const uint64_t pstride = (uint64_t)a.ef * 2 * kw;
@@ -281,13 +287,13 @@ __device__ __forceinline__ void range_hash_wave_body(const RangeHashArgs& a, int
       const int idx = v - 1, half = idx >= (int)a.ef;
       const uint32_t* src = v == 0 ? a.n + b * a.n_stride : (half ? a.c2 : a.c1) + b * pstride + (uint64_t)(idx - half * (int)a.ef) * 2 * kw;
       s.put_bigint(src, v == 0 ? kw : 2 * kw);
-      if (s.wpos < HW_WORDS) continue;
+      if (s.wpos < 16 * NB) continue;
     } else if (!padded) {
       s.pad();
       padded = true;
     }
     if (s.wpos == 0) break;
-    s.flush(s.wpos / 16 < HW_BLOCKS ? s.wpos / 16 : HW_BLOCKS);
+    s.flush(s.wpos / 16 < NB ? s.wpos / 16 : NB);
   }
   if (lane != 0) return;
   // the digest as bytes in LDS (byte j at byte address j): the dynamic byte indexing below stays out of the register file

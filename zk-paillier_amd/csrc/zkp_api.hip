@@ -754,9 +754,17 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
             enc_wgs = std::max<uint64_t>(1, std::min<uint64_t>(enc_wgs, simds - hashes));
             if (c->fuse_hash) {
               h = *c->fuse_hash;
+              h.wave_blocks = HW_BLOCKS;
               c->fuse_hash_taken = true;
-              dyn = (size_t)hw_lds_words((int)h.kw) * sizeof(uint32_t);
+              dyn = (size_t)hw_lds_words<HW_BLOCKS>((int)h.kw) * sizeof(uint32_t);
             }
+          } else if (c->fuse_hash && hashes < simds && a.count <= 2 * simds) {
+            // two wavefronts per SIMD: the hashes among them (the first workgroups) instead of beside them — with the small LDS footprint
+            h = *c->fuse_hash;
+            h.wave_blocks = 16;
+            c->fuse_hash_taken = true;
+            enc_wgs = std::max<uint64_t>(1, std::min<uint64_t>(enc_wgs, 2 * simds - hashes));
+            dyn = (size_t)hw_lds_words<16>((int)h.kw) * sizeof(uint32_t);
           }
           const dim3 grid((unsigned)(h.batch + enc_wgs));
           if (lanes == 8) hipLaunchKernelGGL(k_enc_basen_r2l<9>, grid, dim3(64), dyn, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p, h);
@@ -789,7 +797,7 @@ template <int GS> static bool basen_r2l_takes_hashes(const zkp_ctx* c, uint64_t 
     if (mode == ZKP_ENC_FORM_N2 || n_stride != 0 || n_bits != 2048 || !c->bn_r2l) return false;
     if (!(c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && count <= 2ull * 4 * (uint64_t)c->cus))) return false;
     const bool five = c->bn_r2l_lanes ? c->bn_r2l_lanes == 36 : count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus;
-    return five || r2l_one_per_simd(c, count, true, hashes);  // k_enc_basen_r2l5, or one wavefront per Enc and per SIMD
+    return five || r2l_one_per_simd(c, count, true, hashes) || (hashes < 4ull * (uint64_t)c->cus && count <= 8ull * (uint64_t)c->cus);  // k_enc_basen_r2l5, or one wavefront per Enc at one or two per SIMD
   }
 #endif
   (void)c; (void)n_stride; (void)n_bits; (void)count; (void)hashes;
