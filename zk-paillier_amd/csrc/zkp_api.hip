@@ -102,6 +102,7 @@ struct zkp_ctx {
   const RangeHashArgs* fuse_hash = nullptr;
   bool fuse_hash_taken = false;
   int fuse_hash_on = 1;
+  int grid_expected = 1;               // the base-n launch of a verify sized by the items expected, not by the bound (launch_basen); $ZKP_GRID_EXPECTED=0 at zkp_ctx_create: A/B runs
   DevBuf bn_flag;                      // device word: every key of the last batched base-n set-up qualified   // base-n form (kernels_basen.hpp): set-up record of n, its base-n constants, window tables, Mask-row products
   // timing of the dominant kernels
   bool timing = false;
@@ -163,6 +164,9 @@ static int32_t lat_forward_plain(zkp_ctx* c, int32_t st) {
   return st;
 }
 
+// the items a verify's work list is expected to hold when the launch is sized for `bound` (2 per row: an Open row has two Enc checks, a Mask
+// row one, the challenge bits are fair): three quarters, + 3 % (5 proofs: 960 + 40 of 1280; the spread of 5 proofs is 13)
+static uint64_t expected_items(uint64_t bound) { return (3 * bound + 3) / 4 + bound / 32; }
 // which of the ctx's secondary engines has this many limbs per lane (-1: none; always -1 inside a secondary engine)
 static int engine_with(const zkp_ctx* c, int limbs_per_lane) {
   for (int k = 0; k < 2; k++) if (c->eng_ctx[k] && c->eng[k]->limbs_per_lane == limbs_per_lane) return k;
@@ -225,7 +229,10 @@ static void select_engine(zkp_ctx* c, int k) {
 // from there to 64 proofs — one wavefront per SIMD at 16 Enc each — the mid engine (64 proofs 41.4 / 38.5 against 45.9 / 44.4), the latency
 // engine again up to 96 (80 proofs 61.1 / 59.7 against 65.2 / 63.9), the throughput engine beyond — except 129 ... 192 proofs, where two mid
 // wavefronts per SIMD beat its second round of 32-Enc claims (160 proofs 90.7 / 67.7 against 111.7 / 66.1, 192: 93.2 / 89.8 against 113.6 / 111.2).
-static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits, bool one_key_paillier = false) {
+// `listed`: the items are the bound of a verify's work list (2 per row; about three quarters exist): the mid engine's one-wavefront-per-SIMD
+// window is then judged by the items EXPECTED — its grid is sized by them too (launch_basen) — so that 65 ... 81 proofs verify in one round
+// there (37.4 ms) instead of as two concurrent calls (46.3; tools/dev/two_streams_sweep.py with the engine pinned, profiles/r06/expected_items/).
+static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits, bool one_key_paillier = false, bool listed = false) {
   c->last_geometry = W;
   if (!c->eng_ctx[0] && !c->eng_ctx[1]) return false;
   if (c->geometry == W || items == 0) return false;
@@ -238,7 +245,8 @@ static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits, bool on
   const uint64_t simds = 4 * (uint64_t)c->cus;
   if (one_key_paillier && mod_bits == 4096 && c->enc_form != ZKP_ENC_FORM_N2) {
     const int lat9 = engine_with(c, 9), mid18 = engine_with(c, 18);
-    if (mid18 >= 0 && ((items > 10 * simds && items <= 16 * simds) || (items > 32 * simds && items <= 48 * simds))) { select_engine(c, mid18); return true; }
+    const bool fits_one_round = items <= 16 * simds || (listed && c->grid_expected && expected_items(items) <= 16 * simds);
+    if (mid18 >= 0 && ((items > 10 * simds && fits_one_round) || (items > 32 * simds && items <= 48 * simds))) { select_engine(c, mid18); return true; }
     if (lat9 >= 0 && items <= 3 * simds * 8) { select_engine(c, lat9); return true; }
     if (lat9 >= 0) return false;
   }
@@ -261,12 +269,15 @@ static bool route_latency(zkp_ctx* c, uint64_t items, uint32_t mod_bits, bool on
   if ((c) && route_latency((c), (items), (mod_bits))) return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__));
 #define ZKP_ROUTE_ENC(c, items, mod_bits, one_key, fn, ...)                                 \
   if ((c) && route_latency((c), (items), (mod_bits), (one_key))) return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__));
+#define ZKP_ROUTE_VERIFY(c, items, mod_bits, one_key, fn, ...)                              \
+  if ((c) && route_latency((c), (items), (mod_bits), (one_key), true)) return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__));
 // (diagnostics: only when the caller PINNED the latency engine)
 #define ZKP_ROUTE_PINNED(c, fn, ...)                                                        \
   if ((c) && (c)->geometry && engine_with((c), (c)->geometry) >= 0) { select_engine((c), engine_with((c), (c)->geometry)); return lat_forward_plain((c), (c)->lat->p_##fn((c)->lat_ctx, __VA_ARGS__)); }
 #else
 #define ZKP_ROUTE(c, items, mod_bits, fn, ...)
 #define ZKP_ROUTE_ENC(c, items, mod_bits, one_key, fn, ...)
+#define ZKP_ROUTE_VERIFY(c, items, mod_bits, one_key, fn, ...)
 #define ZKP_ROUTE_PINNED(c, fn, ...)
 #endif
 
@@ -646,7 +657,7 @@ template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uin
 // exist) fit one wavefront per SIMD together with `hashes` transcript-hash wavefronts?
 static bool r2l_one_per_simd(const zkp_ctx* c, uint64_t count, bool listed, uint64_t hashes) {
   const uint64_t simds = 4ull * (uint64_t)c->cus;
-  const uint64_t expect = listed ? (3 * count + 3) / 4 + count / 32 : count;      // (3 % above the mean: 5 proofs 960 + 40 of 1280)
+  const uint64_t expect = listed ? expected_items(count) : count;
   return hashes < simds && expect + hashes <= simds;
 }
 // The base-n launch of an Enc call (GS: lanes per n^2-sized integer of the k_enc launch it stands in for).  It claims work from the SAME
@@ -694,7 +705,17 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
       if (e != hipSuccess || per_cu < 1) per_cu = 1;
     }
     const uint64_t need = (a.count + BL::GROUPS_PER_BLOCK - 1) / BL::GROUPS_PER_BLOCK;
-    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)per_cu * c->cus));
+    uint64_t grid = std::min<uint64_t>(need, (uint64_t)per_cu * c->cus);
+    // A verify's work list (a.count_ptr) holds 128 + the Open rows of every proof — about three quarters — of the 2 Enc per row the launch is
+    // sized for.  A workgroup claims until nothing is left, so the grid only has to hold the items EXPECTED: when those need fewer workgroups
+    // per compute unit than the bound, the launch stops there (40 proofs on the latency engine: 320 workgroups of 32 Enc for 7680 items put
+    // two working wavefronts on a quarter of the SIMDs — 29.5 ms; 256 workgroups: one per unit, 24.5).  expected_items: 3 % above the mean.
+    if (a.count_ptr && a.mode == 1 && c->grid_expected) {
+      const uint64_t need_e = (expected_items(a.count) + BL::GROUPS_PER_BLOCK - 1) / BL::GROUPS_PER_BLOCK;
+      const uint64_t per_cu_e = (need_e + (uint64_t)c->cus - 1) / (uint64_t)c->cus;
+      grid = std::min<uint64_t>(grid, per_cu_e * (uint64_t)c->cus);
+    }
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, grid);
     const size_t entries = per_key ? BN_KEYS_TAB_ENTRIES : BN_TAB_ENTRIES;
     if (!r2l_launch && ensure(c, c->bn_table, (size_t)blocks * BL::GROUPS_PER_BLOCK * entries * 2 * Geo<G>::L * sizeof(uint32_t))) return give_up();
     if (ensure(c, c->bn_raw, (size_t)a.count * 2 * Geo<G>::L * sizeof(uint32_t))) return give_up();
@@ -842,6 +863,7 @@ static int32_t ctx_create(int32_t device_id, hipStream_t stream, bool own_stream
   if (const char* sp = std::getenv("ZKP_SPLIT")) c->split_calls = std::atoi(sp) != 0;
   if (const char* rl = std::getenv("ZKP_R2L")) c->bn_r2l = std::atoi(rl);
   if (const char* fh = std::getenv("ZKP_FUSE_HASH")) c->fuse_hash_on = std::atoi(fh);
+  if (const char* ge = std::getenv("ZKP_GRID_EXPECTED")) c->grid_expected = std::atoi(ge);
   if (const char* rl = std::getenv("ZKP_R2L_LANES")) { const int v = std::atoi(rl); c->bn_r2l_lanes = (v == 8 || v == 12 || v == 36) ? v : 0; }
   c->owns_stream = own_stream;
   c->stream = stream;
