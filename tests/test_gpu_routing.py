@@ -48,7 +48,8 @@ def expected_family(c, items, listed=False):
     lat, mid = c.latency_limbs_per_lane(), c.mid_limbs_per_lane()
     simds = 4 * compute_units()
     one_round = items <= 16 * simds or (listed and (3 * items + 3) // 4 + items // 32 <= 16 * simds)
-    if lat == 9 and mid == 18 and ((16 * simds < items <= 24 * simds and not one_round) or 4 * simds < items <= 5 * simds):
+    lat_round = listed and (3 * items + 3) // 4 + items // 32 <= 8 * simds      # a verify that fits one round of the latency engine's k_enc_basen<8>
+    if lat == 9 and mid == 18 and ((16 * simds < items <= 24 * simds and not one_round) or 4 * simds < items <= 5 * simds or (8 * simds < items <= 9 * simds and not lat_round)):
         return "split"                                         # two concurrent calls (expected_tail below)
     if mid == 18 and ((10 * simds < items and one_round) or 32 * simds < items <= 48 * simds):
         return "mid-basen"                                     # 16 Enc per wavefront: one (two) wavefronts per SIMD of the mid engine
@@ -65,6 +66,8 @@ def expected_tail(B):
     full, least = 16 * simds // 256, 4 * simds // 256
     if B * 256 <= 5 * simds:
         return B - least                                       # 17 ... 20 proofs: 16 on the window ladder, the rest on the one-Enc-per-wavefront ladder
+    if B * 256 <= 9 * simds:
+        return B - 8 * simds // 256                            # 33 ... 36 proofs (prove): 32 on k_enc_basen<8>, the rest on the one-Enc-per-wavefront ladder
     return B - full if B - full >= least else least            # 65 ... 96: 64 on the mid engine | at least 16 on the latency engine
 
 
@@ -93,7 +96,7 @@ def sub_batch(pb, idx, n_bits):
     return s
 
 
-@pytest.mark.parametrize("B", [1, 2, 4, 12, 18, 32, 64, 65, 80, 96, 128, 160, 300])
+@pytest.mark.parametrize("B", [1, 2, 4, 12, 18, 32, 34, 64, 65, 80, 96, 128, 160, 300])
 def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     n_bits, kw = 2048, 64
     n = H.fixture_key()[2]
