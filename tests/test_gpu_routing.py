@@ -49,7 +49,8 @@ def expected_family(c, items, listed=False):
     simds = 4 * compute_units()
     one_round = items <= 16 * simds or (listed and (3 * items + 3) // 4 + items // 32 <= 16 * simds)
     lat_round = listed and (3 * items + 3) // 4 + items // 32 <= 8 * simds      # a verify that fits one round of the latency engine's k_enc_basen<8>
-    if lat == 9 and mid == 18 and ((16 * simds < items <= 24 * simds and not one_round) or 4 * simds < items <= 5 * simds or (8 * simds < items <= 9 * simds and not lat_round)):
+    if lat == 9 and mid == 18 and ((16 * simds < items <= 24 * simds and not one_round) or 4 * simds < items <= 5 * simds or (8 * simds < items <= 9 * simds and not lat_round)
+                                  or (not listed and 32 * simds < items <= 40 * simds)):
         return "split"                                         # two concurrent calls (expected_tail below)
     if mid == 18 and ((10 * simds < items and one_round) or 32 * simds < items <= 48 * simds):
         return "mid-basen"                                     # 16 Enc per wavefront: one (two) wavefronts per SIMD of the mid engine
@@ -68,6 +69,9 @@ def expected_tail(B):
         return B - least                                       # 17 ... 20 proofs: 16 on the window ladder, the rest on the one-Enc-per-wavefront ladder
     if B * 256 <= 9 * simds:
         return B - 8 * simds // 256                            # 33 ... 36 proofs (prove): 32 on k_enc_basen<8>, the rest on the one-Enc-per-wavefront ladder
+    if B * 256 > 32 * simds:
+        t = B - 32 * simds // 256                              # 129 ... 160 proofs (prove): 128 on the throughput engine, the rest beside them on the latency engine
+        return 2 * simds // 256 + 1 if 3 * simds // 2 < t * 256 <= 2 * simds else t      # (not 7 or 8 proofs: the r2l ladder's workgroups would not fit beside the head)
     return B - full if B - full >= least else least            # 65 ... 96: 64 on the mid engine | at least 16 on the latency engine
 
 
@@ -96,7 +100,7 @@ def sub_batch(pb, idx, n_bits):
     return s
 
 
-@pytest.mark.parametrize("B", [1, 2, 4, 12, 18, 32, 34, 64, 65, 80, 96, 128, 160, 300])
+@pytest.mark.parametrize("B", [1, 2, 4, 12, 18, 32, 34, 64, 65, 80, 96, 128, 136, 160, 300])
 def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     n_bits, kw = 2048, 64
     n = H.fixture_key()[2]
