@@ -87,10 +87,11 @@ int32_t zkp_diag_r2l_last(zkp_ctx* ctx);
  * zkp_diag_last_split: the proofs of the most recent RangeProofNi call that went to the latency engine beside the mid engine (0: not split). */
 int32_t zkp_diag_set_split(zkp_ctx* ctx, int32_t on);
 int32_t zkp_diag_last_split(zkp_ctx* ctx);
-/* A verify call whose Enc launch gives every Enc a compute unit of its own (one proof at n = 2048 on the latency engine, k_enc_basen_r2l5)
- * carries its transcript hash as ONE MORE WORKGROUP of that launch — a unit to itself — instead of a launch of its own on a second stream,
- * where the hash wavefront shared a SIMD with two wavefronts of an Enc one call in four (6.2 or 8.0 ms).  On by default; $ZKP_FUSE_HASH=0 at
- * ctx create or zkp_diag_set_fuse_hash(ctx, 0) turn it off.  zkp_diag_last_fused_hash: 1 when the most recent verify call ran that way. */
+/* A verify call of 1 ... 8 proofs at n = 2048 under one key (the latency engine's one-Enc-per-wavefront kernels, k_enc_basen_r2l5 /
+ * k_enc_basen_r2l) carries its transcript hashes as the FIRST WORKGROUPS of its Enc launch instead of a launch of their own on a second
+ * stream, where a hash wavefront shared a SIMD with the wavefronts of an Enc one call in four to seven (one proof: 6.2 or 8.0 ms; four:
+ * 10.0 or 12.5; eight: 14.6 or 17.2).  On by default; $ZKP_FUSE_HASH=0 at ctx create or zkp_diag_set_fuse_hash(ctx, 0) turn it off.
+ * zkp_diag_last_fused_hash: 1 when the most recent verify call ran that way. */
 int32_t zkp_diag_set_fuse_hash(zkp_ctx* ctx, int32_t on);
 int32_t zkp_diag_last_fused_hash(zkp_ctx* ctx);
 int32_t zkp_diag_set_key_cache(zkp_ctx* ctx, int32_t on);

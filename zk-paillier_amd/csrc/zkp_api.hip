@@ -708,8 +708,9 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
     uint64_t grid = std::min<uint64_t>(need, (uint64_t)per_cu * c->cus);
     // A verify's work list (a.count_ptr) holds 128 + the Open rows of every proof — about three quarters — of the 2 Enc per row the launch is
     // sized for.  A workgroup claims until nothing is left, so the grid only has to hold the items EXPECTED: when those need fewer workgroups
-    // per compute unit than the bound, the launch stops there (40 proofs on the latency engine: 320 workgroups of 32 Enc for 7680 items put
-    // two working wavefronts on a quarter of the SIMDs — 29.5 ms; 256 workgroups: one per unit, 24.5).  expected_items: 3 % above the mean.
+    // per compute unit than the bound, the launch stops there (40 proofs on the latency engine: 320 workgroups of 32 Enc for 7680 items gave
+    // a quarter of the units a second workgroup, and three calls of six took 27 ... 37 ms instead of 26; 65 ... 81 proofs on the mid engine:
+    // one round, 37.3 ms — profiles/r06/expected_items/).  expected_items: 3 % above the mean.
     if (a.count_ptr && a.mode == 1 && c->grid_expected) {
       const uint64_t need_e = (expected_items(a.count) + BL::GROUPS_PER_BLOCK - 1) / BL::GROUPS_PER_BLOCK;
       const uint64_t per_cu_e = (need_e + (uint64_t)c->cus - 1) / (uint64_t)c->cus;
@@ -763,7 +764,8 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
           hipLaunchKernelGGL(k_enc_basen_r2l5, dim3((unsigned)(h.batch + enc_wgs)), dim3(320), dyn, c->stream, a, (const uint32_t*)c->bn_consts.p, (uint32_t*)c->bn_raw.p, h);
         }
         else {
-          // one wavefront per Enc: the call's transcript hashes aboard while the launch as a whole stays within one wavefront per SIMD (2 - 4 proofs)
+          // one wavefront per Enc: the call's transcript hashes aboard — at 64 blocks per batch while the launch as a whole stays within one
+          // wavefront per SIMD (2 - 5 proofs), at 16 (6.6 KB of LDS on every workgroup) beyond (6 - 8 proofs: two wavefronts per SIMD)
           // (a verify's work list holds 128 + the Open rows of every proof — about 192 — of the 256 Enc per proof the launch is sized for: while the
           //  items EXPECTED fit one wavefront per SIMD the grid stops there — five proofs: 960 of 1280 — and a wavefront claims until none is left)
           RangeHashArgs h{};
@@ -1057,13 +1059,14 @@ extern "C" int32_t zkp_diag_set_r2l(zkp_ctx* c, int32_t mode) try {
 #endif
   return ZKP_OK;
 } ZKP_CATCH(c)
-// The transcript hash of a one-proof verify as a workgroup of its Enc launch (k_enc_basen_r2l5; csrc/zkp_api_proofs.inc range_verify_impl): on / off;
+// The transcript hashes of a verify of 1 ... 8 proofs as workgroups of its Enc launch (k_enc_basen_r2l5 / k_enc_basen_r2l; csrc/zkp_api_proofs.inc range_verify_impl): on / off;
 // did the most recent verify call of the ctx run that way?
 extern "C" int32_t zkp_diag_set_fuse_hash(zkp_ctx* c, int32_t on) try {
   if (!c) return ZKP_EINVAL;
   c->fuse_hash_on = on != 0;
 #ifndef ZKP_SECONDARY_ENGINE
   for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_diag_set_fuse_hash(c->eng_ctx[k], on);
+  if (c->split_ctx) (void)c->eng[0]->p_zkp_diag_set_fuse_hash(c->split_ctx, on);      // (the tail of a split call: a second ctx of the latency engine)
 #endif
   return ZKP_OK;
 } ZKP_CATCH(c)
