@@ -1066,7 +1066,6 @@ extern "C" int32_t zkp_diag_set_fuse_hash(zkp_ctx* c, int32_t on) try {
   c->fuse_hash_on = on != 0;
 #ifndef ZKP_SECONDARY_ENGINE
   for (int k = 0; k < 2; k++) if (c->eng_ctx[k]) (void)c->eng[k]->p_zkp_diag_set_fuse_hash(c->eng_ctx[k], on);
-  if (c->split_ctx) (void)c->eng[0]->p_zkp_diag_set_fuse_hash(c->split_ctx, on);      // (the tail of a split call: a second ctx of the latency engine)
 #endif
   return ZKP_OK;
 } ZKP_CATCH(c)
