@@ -274,7 +274,7 @@ def test_one_proof_verify_carries_its_transcript_hash_inside_the_enc_launch(actx
     oracle.set_threads(min(16, oracle.max_threads()))
     actx.set_geometry(0)
     actx.set_enc_form("auto")
-    for B, ef in ((1, 128), (3, 40), (2, 64), (2, 128), (4, 128), (5, 128), (6, 128), (8, 128)):
+    for B, ef in ((1, 128), (3, 40), (2, 64), (2, 128), (4, 128), (5, 128), (6, 128), (8, 128), (60, 4), (200, 1)):      # (the last two: many short transcripts — many hash workgroups in front of few Enc workgroups)
         five = 2 * ef * B <= compute_units()                       # k_enc_basen_r2l5; beyond: one wavefront per Enc, hashes aboard up to one per SIMD
         bound = 2 * ef * B                                         # (csrc/zkp_api.hip r2l_one_per_simd: three quarters of the bound exist, + 3 %)
         one_per_simd = (3 * bound + 3) // 4 + bound // 32 + B <= 4 * compute_units()
