@@ -55,8 +55,8 @@ def expected_family(c, items, listed=False):
     if mid == 18 and ((10 * simds < items and one_round) or 32 * simds < items <= 48 * simds):
         return "mid-basen"                                     # 16 Enc per wavefront: one (two) wavefronts per SIMD of the mid engine
     if lat == 9 and items <= 3 * simds * 8:                    # the latency engine: up to three wavefronts per SIMD at 8 Enc per wavefront
-        if items <= 2 * simds:
-            return "lat-r2l"                                   # one Enc per wavefront, the five-group ladder (kernels_basen_r2l.hpp)
+        if (min(items, (3 * items + 3) // 4 + items // 32) if listed else items) <= 2 * simds:
+            return "lat-r2l"                                   # one Enc per wavefront, the five-group ladder (kernels_basen_r2l.hpp); a verify by its expected items (9, 10 proofs)
         return "lat-basen" if items > simds * 4 else "lat-n2"
     return "base-n" if items > simds * 16 else "n2"
 
@@ -100,7 +100,7 @@ def sub_batch(pb, idx, n_bits):
     return s
 
 
-@pytest.mark.parametrize("B", [1, 2, 4, 12, 18, 32, 34, 64, 65, 80, 96, 128, 136, 160, 300])
+@pytest.mark.parametrize("B", [1, 2, 4, 10, 12, 18, 32, 34, 64, 65, 80, 96, 128, 136, 160, 300])
 def test_default_routing_prove_and_verify_against_the_oracle(actx, oracle, B):
     n_bits, kw = 2048, 64
     n = H.fixture_key()[2]
@@ -274,11 +274,11 @@ def test_one_proof_verify_carries_its_transcript_hash_inside_the_enc_launch(actx
     oracle.set_threads(min(16, oracle.max_threads()))
     actx.set_geometry(0)
     actx.set_enc_form("auto")
-    for B, ef in ((1, 128), (3, 40), (2, 64), (2, 128), (4, 128), (5, 128), (6, 128), (8, 128), (60, 4), (200, 1)):      # (the last two: many short transcripts — many hash workgroups in front of few Enc workgroups)
+    for B, ef in ((1, 128), (3, 40), (2, 64), (2, 128), (4, 128), (5, 128), (6, 128), (8, 128), (10, 128), (60, 4), (200, 1)):      # (the last two: many short transcripts — many hash workgroups in front of few Enc workgroups)
         five = 2 * ef * B <= compute_units()                       # k_enc_basen_r2l5; beyond: one wavefront per Enc, hashes aboard up to one per SIMD
         bound = 2 * ef * B                                         # (csrc/zkp_api.hip r2l_one_per_simd: three quarters of the bound exist, + 3 %)
         one_per_simd = (3 * bound + 3) // 4 + bound // 32 + B <= 4 * compute_units()
-        takes = five or one_per_simd or bound <= 8 * compute_units()      # (two wavefronts per SIMD: the hashes aboard at 16 blocks per batch)
+        takes = five or one_per_simd or min(bound, (3 * bound + 3) // 4 + bound // 32) <= 8 * compute_units()      # (two wavefronts per SIMD: the hashes aboard at 16 blocks per batch)
         cases = H.build_range_case(b"fused-hash-%d-%d" % (B, ef), [n], n_bits, B, ef=ef)
         pb, wt = H.fill_batch(cases, n_bits, True, oracle)
         oracle.range_generate_encrypted_pairs(pb.struct(), wt.struct())

@@ -657,7 +657,7 @@ template <int G> static int32_t basen_prepare(zkp_ctx* c, const uint32_t* n, uin
 // exist) fit one wavefront per SIMD together with `hashes` transcript-hash wavefronts?
 static bool r2l_one_per_simd(const zkp_ctx* c, uint64_t count, bool listed, uint64_t hashes) {
   const uint64_t simds = 4ull * (uint64_t)c->cus;
-  const uint64_t expect = listed ? expected_items(count) : count;
+  const uint64_t expect = (listed && c->grid_expected) ? expected_items(count) : count;
   return hashes < simds && expect + hashes <= simds;
 }
 // The base-n launch of an Enc call (GS: lanes per n^2-sized integer of the k_enc launch it stands in for).  It claims work from the SAME
@@ -678,9 +678,12 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
     // right-to-left ladder (kernels_basen_r2l.hpp): half the chain of the pair ladder that served them (the launch behind this one, which then
     // finds nothing to claim).  c->bn_r2l: 0 = never, 1 = the library's rule, 2 = whenever the kernel can take the launch (tests).
     bool r2l_launch = false;
+    // (a verify's work list: judged by the items expected — 9 and 10 proofs, 2304 / 2560 by the bound, still fit two wavefronts per SIMD: 14.5 ms
+    //  there against 19.2 on the window ladder)
+    const uint64_t r2l_items = (a.count_ptr && a.mode == 1 && c->grid_expected) ? std::min<uint64_t>(a.count, expected_items(a.count)) : a.count;
 #if ZKP_W == 9
     if constexpr (G == 8)
-      r2l_launch = !per_key && c->bn_r2l && a.n_bits == 2048 && (c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && a.count <= 2ull * 4 * (uint64_t)c->cus));
+      r2l_launch = !per_key && c->bn_r2l && a.n_bits == 2048 && (c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && r2l_items <= 2ull * 4 * (uint64_t)c->cus));
 #endif
     if (!per_key && !a.sched && !r2l_launch) return false;       // (a shared key whose launch takes the pair ladder of the latency engine)
     if (per_key && a.n_stride != (uint64_t)kw) return false;
@@ -744,7 +747,7 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
 #if ZKP_W == 9
     if (r2l_launch) {
       if constexpr (G == 8) {
-        const unsigned waves = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(a.count, 8ull * 4 * (uint64_t)c->cus));
+        const unsigned waves = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(a.count, r2l_items < a.count ? std::max<uint64_t>(r2l_items, 2ull * 4 * (uint64_t)c->cus) : 8ull * 4 * (uint64_t)c->cus));
         // five wavefronts per Enc (36 lanes x 2 limbs each, k_enc_basen_r2l5) while the launch leaves a CU to every Enc: one proof;
         // one wavefront of five groups of 12 lanes x 6 limbs beyond; 8 lanes x 9 limbs only when pinned (A/B runs)
         const int lanes = c->bn_r2l_lanes ? c->bn_r2l_lanes : (a.count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus ? 36 : 12);
@@ -781,7 +784,7 @@ template <int GS> static bool launch_basen(zkp_ctx* c, const EncArgs& a_in, EncA
               c->fuse_hash_taken = true;
               dyn = (size_t)hw_lds_words<HW_BLOCKS>((int)h.kw) * sizeof(uint32_t);
             }
-          } else if (c->fuse_hash && hashes < simds && a.count <= 2 * simds) {
+          } else if (c->fuse_hash && hashes < simds && r2l_items <= 2 * simds) {
             // two wavefronts per SIMD: the hashes among them (the first workgroups) instead of beside them — with the small LDS footprint
             h = *c->fuse_hash;
             h.wave_blocks = 16;
@@ -818,9 +821,10 @@ template <int GS> static bool basen_r2l_takes_hashes(const zkp_ctx* c, uint64_t 
   if constexpr (GS == 2 * BN_GA) {
     const int mode = c->enc_form;
     if (mode == ZKP_ENC_FORM_N2 || n_stride != 0 || n_bits != 2048 || !c->bn_r2l) return false;
-    if (!(c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && count <= 2ull * 4 * (uint64_t)c->cus))) return false;
+    const uint64_t items = c->grid_expected ? std::min<uint64_t>(count, expected_items(count)) : count;      // (as launch_basen judges a verify's work list)
+    if (!(c->bn_r2l == 2 || (mode != ZKP_ENC_FORM_ALWAYS && items <= 2ull * 4 * (uint64_t)c->cus))) return false;
     const bool five = c->bn_r2l_lanes ? c->bn_r2l_lanes == 36 : count <= ZKP_R2L5_ITEMS_PER_CU * (uint64_t)c->cus;
-    return five || r2l_one_per_simd(c, count, true, hashes) || (hashes < 4ull * (uint64_t)c->cus && count <= 8ull * (uint64_t)c->cus);  // k_enc_basen_r2l5, or one wavefront per Enc at one or two per SIMD
+    return five || r2l_one_per_simd(c, count, true, hashes) || (hashes < 4ull * (uint64_t)c->cus && items <= 8ull * (uint64_t)c->cus);  // k_enc_basen_r2l5, or one wavefront per Enc at one or two per SIMD
   }
 #endif
   (void)c; (void)n_stride; (void)n_bits; (void)count; (void)hashes;
